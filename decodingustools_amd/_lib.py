@@ -1,0 +1,139 @@
+"""ctypes binding of libcallable_hip.so (include/callable_loci.h + include/dut_coverage.h).
+
+There is no fallback: if the shared library is missing or does not load, importing the engine
+raises.  Build it with `python -m decodingustools_amd.build` (or __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+
+class cl_options(C.Structure):
+    _fields_ = [("min_depth", C.c_uint32), ("max_depth", C.c_uint32),
+                ("min_mapping_quality", C.c_uint8), ("min_base_quality", C.c_uint8),
+                ("min_depth_for_low_mapq", C.c_uint32), ("max_low_mapq", C.c_uint8),
+                ("max_low_mapq_fraction", C.c_double)]
+
+
+class cl_read_tile(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("pos", C.c_void_p), ("mapq", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("qual_off", C.c_void_p), ("qual", C.c_void_p)]
+
+
+class cl_contig_summary(C.Structure):
+    _fields_ = [("state_counts", C.c_uint64 * 6), ("n_covered_bases", C.c_uint64),
+                ("summed_coverage", C.c_uint64), ("summed_baseq", C.c_uint64),
+                ("summed_mapq", C.c_uint64), ("quality_bases", C.c_uint64),
+                ("extent", C.c_uint64), ("max_raw_depth", C.c_uint64),
+                ("n_intervals", C.c_uint64)]
+
+
+class cl_interval(C.Structure):
+    _fields_ = [("start", C.c_uint32), ("end", C.c_uint32), ("state", C.c_uint32)]
+
+
+class cl_site_tile(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("pos", C.c_void_p), ("mapq", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("seq_off", C.c_void_p), ("seq4", C.c_void_p)]
+
+
+class dut_records(C.Structure):
+    _fields_ = [("n", C.c_uint64), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("qual_off", C.c_void_p),
+                ("qual", C.c_void_p), ("qname_off", C.c_void_p), ("qname", C.c_void_p)]
+
+
+class dut_contig_stats(C.Structure):
+    _fields_ = [("length", C.c_uint64), ("n_covered_bases", C.c_uint64),
+                ("summed_coverage", C.c_uint64), ("summed_baseq", C.c_uint64),
+                ("summed_mapq", C.c_uint64), ("quality_bases", C.c_uint64),
+                ("n_reads", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class dut_contig_derived(C.Structure):
+    _fields_ = [("coverage_percent", C.c_double), ("average_depth", C.c_double),
+                ("average_mapq", C.c_double), ("average_baseq", C.c_double),
+                ("q30_percentage", C.c_double)]
+
+
+class dut_genome_summary(C.Structure):
+    _fields_ = [("total_bases", C.c_uint64), ("callable_bases", C.c_uint64),
+                ("callable_percentage", C.c_double), ("average_depth", C.c_double),
+                ("average_mapq", C.c_double), ("average_baseq", C.c_double),
+                ("q30_percentage", C.c_double), ("total_unique_reads", C.c_uint64),
+                ("contigs_analyzed", C.c_uint64)]
+
+
+CL_K_NAMES = ("prep", "bounds", "pileup", "rle")
+CL_K_COUNT = 4
+
+# every symbol the two headers declare: (name, restype, argtypes)
+SYMBOLS = [
+    ("cl_abi_version", C.c_int, []),
+    ("cl_device_count", C.c_int, []),
+    ("cl_create", C.c_int, [C.POINTER(cl_options), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    ("cl_destroy", None, [C.c_void_p]),
+    ("cl_last_error", C.c_char_p, [C.c_void_p]),
+    ("cl_contig_begin", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint64]),
+    ("cl_push_reads", C.c_int, [C.c_void_p, C.POINTER(cl_read_tile)]),
+    ("cl_contig_finish", C.c_int, [C.c_void_p, C.POINTER(cl_contig_summary),
+                                   C.POINTER(C.POINTER(cl_interval)), C.POINTER(C.c_size_t)]),
+    ("cl_contig_upload", C.c_int, [C.c_void_p]),
+    ("cl_contig_run", C.c_int, [C.c_void_p]),
+    ("cl_contig_collect", C.c_int, [C.c_void_p, C.POINTER(cl_contig_summary),
+                                    C.POINTER(C.POINTER(cl_interval)), C.POINTER(C.c_size_t)]),
+    ("cl_sync", C.c_int, [C.c_void_p]),
+    ("cl_device_summary", C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("cl_set_profiling", C.c_int, [C.c_void_p, C.c_int]),
+    ("cl_get_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
+    ("cl_reset_kernel_ms", C.c_int, [C.c_void_p]),
+    ("cl_contig_bytes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("cl_debug_depths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("cl_site_pileup", C.c_int, [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(cl_site_tile),
+                                 C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("dut_profiler_new", C.c_void_p, [C.c_char_p]),
+    ("dut_profiler_free", None, [C.c_void_p]),
+    ("dut_profiler_contig_counts", None, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
+    ("dut_profiler_feed_contig", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
+                                           C.POINTER(C.c_uint64)]),
+    ("dut_admit_reads", C.c_int, [C.POINTER(cl_options), C.c_int32, C.c_uint32, C.POINTER(dut_records),
+                                  C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    ("dut_process_single_contig", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(dut_contig_stats),
+                                            C.POINTER(cl_options), C.c_char_p, C.c_int32, C.c_uint32,
+                                            C.c_void_p, C.c_uint64, C.POINTER(dut_records)]),
+    ("dut_contig_derive", None, [C.POINTER(dut_contig_stats), C.POINTER(dut_contig_derived)]),
+    ("dut_compare_contig_names", C.c_int, [C.c_char_p, C.c_char_p]),
+    ("dut_genome_summary_build", None, [C.POINTER(dut_contig_stats), C.POINTER(C.c_uint64), C.c_size_t,
+                                        C.POINTER(dut_genome_summary)]),
+    ("dut_state_name", C.c_char_p, [C.c_uint32]),
+]
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    """Load the shared library; raises if it is absent (no CPU fallback exists)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} is missing: build it with `python -m decodingustools_amd.build` "
+            "(needs hipcc). The engine has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, res, args in SYMBOLS:
+        fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.cl_abi_version() != 1:
+        raise RuntimeError("libcallable_hip.so ABI version mismatch")
+    _LIB = lib
+    return lib

@@ -1,0 +1,48 @@
+"""Builds libcallable_hip.so (gfx950 device code + host mirror) in-tree with hipcc.
+
+The shared library is the product's only native artefact; it lands in
+decodingustools_amd/lib/ so that it travels with the source tree (it is git-ignored).
+"""
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libcallable_hip.so")
+SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "host_coverage.cpp")]
+HEADERS = [os.path.join(CSRC, "kernels.hip.h"),
+           os.path.join(HERE, "..", "include", "callable_loci.h"),
+           os.path.join(HERE, "..", "include", "dut_coverage.h")]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    """Compile for gfx950 (cross-compiles without a GPU). Returns the library path."""
+    if not force and not _stale():
+        return LIB
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("hipcc not found: cannot build libcallable_hip.so")
+    os.makedirs(LIBDIR, exist_ok=True)
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-Wall", "-Wno-unused-function"] + SOURCES + ["-o", LIB + ".tmp"]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(LIB + ".tmp", LIB)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

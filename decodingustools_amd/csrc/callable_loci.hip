@@ -1,0 +1,609 @@
+// callable_loci.hip -- implementation of include/callable_loci.h for MI355X (gfx950).
+//
+// Host side of the engine: device buffers, uploads, kernel launches, event timing.  The work
+// itself is in kernels.hip.h.  No CPU fallback exists: without a HIP device cl_create fails.
+#include "../../include/callable_loci.h"
+#include "kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace clk;
+
+namespace {
+
+// window size (reference positions per workgroup).  2048 -> 32 KiB of LDS per workgroup,
+// five workgroups (20 waves) per CU.
+#ifndef CL_WINDOW
+#define CL_WINDOW 2048
+#endif
+constexpr uint32_t kT = CL_WINDOW;
+
+template <typename T> struct DevBuf {
+    T *p = nullptr;
+    size_t cap = 0;     // elements
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + n / 8 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), want * sizeof(T));
+        if (e != hipSuccess) { p = nullptr; return e; }
+        cap = want;
+        return hipSuccess;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+} // namespace
+
+struct cl_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    cl_options opt{};
+    Opts dopt{};
+    std::string err;
+
+    // host staging of the current contig
+    bool in_contig = false, uploaded = false, ran = false;
+    int32_t tid = 0;
+    uint32_t contig_len = 0;
+    std::vector<uint8_t> h_ref;
+    std::vector<int32_t> h_pos;
+    std::vector<uint8_t> h_mapq;
+    std::vector<uint32_t> h_cigar_off;
+    std::vector<uint32_t> h_cigar;
+    std::vector<unsigned long long> h_qual_off;
+    std::vector<uint8_t> h_qual;
+
+    // device residents
+    DevBuf<int32_t> d_pos;
+    DevBuf<uint8_t> d_mapq;
+    DevBuf<uint32_t> d_cigar_off;
+    DevBuf<uint32_t> d_cigar;
+    DevBuf<unsigned long long> d_qual_off;
+    DevBuf<uint8_t> d_qual;
+    DevBuf<uint8_t> d_ref;
+    DevBuf<uint32_t> d_end;
+    DevBuf<uint32_t> d_win_lo, d_win_hi, d_win_off;
+    DevBuf<uint8_t> d_state;
+    DevBuf<WinPartial> d_winpart;
+    DevBuf<PrepPartial> d_prep;
+    DevBuf<uint32_t> d_lut;
+    DevBuf<DevSummary> d_summary;
+    DevBuf<Interval> d_iv;
+    DevBuf<uint32_t> d_dbg;          // 3 * n_win * T
+
+    uint32_t n_reads = 0;
+    uint64_t n_cigar = 0, n_qual = 0;
+    uint32_t extent = 0, n_win = 0;
+    uint64_t ref_len_dev = 0;
+
+    std::vector<cl_interval> h_iv;
+    DevSummary h_sum{};
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[CL_K_COUNT + 1] = {};
+    bool ev_made = false, ev_pending = false;
+    double ms[CL_K_COUNT] = {};
+    uint64_t n_runs = 0;
+};
+
+namespace {
+
+cl_status fail(cl_ctx *c, cl_status s, const std::string &m)
+{
+    if (c) c->err = m;
+    return s;
+}
+
+#define HIP_TRY(ctx, call)                                                                   \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(ctx, e__ == hipErrorOutOfMemory ? CL_ERR_NOMEM : CL_ERR_DEVICE,      \
+                        std::string(#call) + ": " + hipGetErrorString(e__));                 \
+    } while (0)
+
+// constants of the byte-parallel quality threshold (kernels.hip.h qual_ge)
+void make_ge_consts(uint8_t T, Opts &o)
+{
+    uint32_t add;
+    if (T == 0) { add = 0x80u; o.ge_or = 0xFFFFFFFFu; o.ge_and = 0xFFFFFFFFu; }
+    else if (T <= 128) { add = 128u - T; o.ge_or = 0xFFFFFFFFu; o.ge_and = 0xFFFFFFFFu; }
+    else { add = 256u - T; o.ge_or = 0u; o.ge_and = 0u; }
+    o.ge_add = add * 0x01010101u;
+}
+
+// lut[raw] = smallest low_mapq_count with (low as f64 / raw as f64) > max_low_mapq_fraction
+// (callable_profiler.rs:100-101), or 0xFFFFFFFF when no count <= raw qualifies.  Built with the
+// same IEEE f64 divide and compare as the reference, so the device test `low >= lut[raw]` is
+// exact by construction (the quotient is monotone in `low`).
+void build_lut(double frac, std::vector<uint32_t> &lut)
+{
+    lut.assign(kLutSize, 0xFFFFFFFFu);
+    for (uint32_t raw = 1; raw < kLutSize; ++raw) {
+        double g = std::floor(frac * (double)raw) - 2.0;
+        if (!(g == g)) continue;                 // NaN fraction: the comparison is never true
+        if (g > (double)raw) continue;
+        uint32_t low = g < 0.0 ? 0u : (uint32_t)g;
+        while (low <= raw && !(((double)low / (double)raw) > frac)) ++low;
+        if (low <= raw) lut[raw] = low;
+    }
+}
+
+cl_status ensure_events(cl_ctx *c)
+{
+    if (c->ev_made) return CL_OK;
+    for (int i = 0; i <= CL_K_COUNT; ++i) HIP_TRY(c, hipEventCreate(&c->ev[i]));
+    c->ev_made = true;
+    return CL_OK;
+}
+
+cl_status harvest_events(cl_ctx *c)
+{
+    if (!c->ev_pending) return CL_OK;
+    HIP_TRY(c, hipEventSynchronize(c->ev[CL_K_COUNT]));
+    for (int i = 0; i < CL_K_COUNT; ++i) {
+        float t = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
+        c->ms[i] += t;
+    }
+    c->n_runs += 1;
+    c->ev_pending = false;
+    return CL_OK;
+}
+
+// allocate everything that depends on extent
+cl_status size_for_extent(cl_ctx *c, uint32_t extent)
+{
+    c->extent = extent;
+    c->n_win = (uint32_t)(((uint64_t)extent + kT - 1) / kT);
+    const size_t padded = (size_t)c->n_win * kT;
+    HIP_TRY(c, c->d_win_lo.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win_hi.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win_off.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_state.reserve(padded + 16));
+    // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80)
+    if (c->d_ref.cap < padded + 16 || c->ref_len_dev == UINT64_MAX) {
+        HIP_TRY(c, c->d_ref.reserve(padded + 16));
+    }
+    HIP_TRY(c, hipMemsetAsync(c->d_ref.p, 'N', padded + 16, c->stream));
+    const size_t nref = std::min<size_t>(c->h_ref.size(), padded);
+    if (nref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.p, c->h_ref.data(), nref, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CL_OK;
+}
+
+template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
+{
+    const uint32_t grid = a.n_win8 * 8u;
+    if (grid == 0) return;
+    hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+}
+
+cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, uint32_t *dbg_low)
+{
+    const bool prof = c->profiling && !debug;
+    if (prof) {
+        cl_status s = ensure_events(c);
+        if (s != CL_OK) return s;
+        s = harvest_events(c);
+        if (s != CL_OK) return s;
+    }
+    Reads R;
+    R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
+    R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
+
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
+                       c->d_end.p, c->d_prep.p);
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (c->n_win) {
+        hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0,
+                           c->stream, R, c->d_prep.p, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p);
+    }
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    PileupArgs a;
+    a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p;
+    a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
+    a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
+    a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
+    if (debug) launch_pileup<true>(c, a); else launch_pileup<false>(c, a);
+    if (prof) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_prep.p,
+                       c->d_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_summary.p);
+    if (c->n_win) {
+        hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream,
+                           c->d_state.p, c->d_win_off.p, c->n_win, c->extent, c->d_iv.p,
+                           (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+    }
+    if (prof) {
+        HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+        c->ev_pending = true;
+    }
+    HIP_TRY(c, hipGetLastError());
+    return CL_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+int cl_abi_version(void) { return CL_ABI_VERSION; }
+
+int cl_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx **out)
+{
+    if (!opt || !out) return CL_ERR_INVALID;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0 || device_id < 0 || device_id >= n)
+        return CL_ERR_DEVICE;
+    cl_ctx *c = new (std::nothrow) cl_ctx();
+    if (!c) return CL_ERR_NOMEM;
+    c->device = device_id;
+    c->opt = *opt;
+    if (hipSetDevice(device_id) != hipSuccess) { delete c; return CL_ERR_DEVICE; }
+    if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
+    else {
+        if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CL_ERR_DEVICE; }
+        c->own_stream = true;
+    }
+    Opts &o = c->dopt;
+    o.min_depth = opt->min_depth; o.max_depth = opt->max_depth; o.min_mapq = opt->min_mapping_quality;
+    o.min_depth_for_low_mapq = opt->min_depth_for_low_mapq; o.max_low_mapq = opt->max_low_mapq;
+    o.max_low_mapq_fraction = opt->max_low_mapq_fraction;
+    make_ge_consts(opt->min_base_quality, o);
+    std::vector<uint32_t> lut;
+    build_lut(opt->max_low_mapq_fraction, lut);
+    bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepBlocks) == hipSuccess &&
+              c->d_summary.reserve(1) == hipSuccess &&
+              hipMemcpy(c->d_lut.p, lut.data(), kLutSize * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
+    if (!ok) { cl_destroy(c); return CL_ERR_DEVICE; }
+    *out = c;
+    return CL_OK;
+}
+
+void cl_destroy(cl_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
+    c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
+    c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
+    c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
+    c->d_iv.release(); c->d_dbg.release();
+    if (c->ev_made) for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *cl_last_error(const cl_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uint8_t *ref_bases,
+                          uint64_t ref_len)
+{
+    if (!c) return CL_ERR_INVALID;
+    if (contig_len > 0xFFF00000u) return fail(c, CL_ERR_RANGE, "contig length beyond the engine's 32-bit range");
+    if (ref_len && !ref_bases) return fail(c, CL_ERR_INVALID, "ref_bases is null");
+    c->tid = tid; c->contig_len = contig_len;
+    const uint64_t nref = std::min<uint64_t>(ref_len, contig_len);
+    c->h_ref.assign(ref_bases, ref_bases + nref);
+    c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_qual.clear();
+    c->h_cigar_off.assign(1, 0u); c->h_qual_off.assign(1, 0ull);
+    c->h_iv.clear();
+    c->in_contig = true; c->uploaded = false; c->ran = false;
+    return CL_OK;
+}
+
+cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
+{
+    if (!c || !t) return CL_ERR_INVALID;
+    if (!c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_push_reads outside cl_contig_begin .. upload");
+    const uint64_t n = t->n_reads;
+    if (n == 0) return CL_OK;
+    if (!t->pos || !t->mapq || !t->cigar_off || !t->qual_off) return fail(c, CL_ERR_INVALID, "null tile array");
+    if (c->h_pos.size() + n > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 reads in one contig");
+    // validation that protects the kernels' indexing
+    int32_t last = c->h_pos.empty() ? 0 : c->h_pos.back();
+    for (uint64_t i = 0; i < n; ++i) {
+        const int32_t p = t->pos[i];
+        if (p < 0 || (uint32_t)p >= c->contig_len)
+            return fail(c, CL_ERR_INVALID, "read position outside [0, contig_len): the region fetch (mod.rs:53) never yields it");
+        if (p < last) return fail(c, CL_ERR_UNSORTED, "reads are not coordinate sorted");
+        last = p;
+        if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i])
+            return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    }
+    const uint32_t cig0 = t->cigar_off[0];
+    const uint64_t ncig = (uint64_t)t->cigar_off[n] - cig0;
+    const uint64_t q0 = t->qual_off[0];
+    const uint64_t nq = t->qual_off[n] - q0;
+    if (ncig && !t->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
+    if (nq && !t->qual) return fail(c, CL_ERR_INVALID, "null qual array");
+    if (c->h_cigar.size() + ncig > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 CIGAR operations in one contig");
+    if (c->h_qual.size() + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality bytes in one contig");
+    const uint32_t cbase = (uint32_t)c->h_cigar.size();
+    const unsigned long long qbase = c->h_qual.size();
+    try {
+        c->h_pos.insert(c->h_pos.end(), t->pos, t->pos + n);
+        c->h_mapq.insert(c->h_mapq.end(), t->mapq, t->mapq + n);
+        c->h_cigar.insert(c->h_cigar.end(), t->cigar + cig0, t->cigar + cig0 + ncig);
+        c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
+        c->h_cigar_off.reserve(c->h_cigar_off.size() + n);
+        c->h_qual_off.reserve(c->h_qual_off.size() + n);
+        for (uint64_t i = 1; i <= n; ++i) {
+            c->h_cigar_off.push_back(cbase + (t->cigar_off[i] - cig0));
+            c->h_qual_off.push_back(qbase + (t->qual_off[i] - q0));
+        }
+    } catch (const std::bad_alloc &) {
+        return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
+    }
+    return CL_OK;
+}
+
+cl_status cl_contig_upload(cl_ctx *c)
+{
+    if (!c || !c->in_contig) return fail(c, CL_ERR_INVALID, "cl_contig_upload without cl_contig_begin");
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->n_reads = (uint32_t)c->h_pos.size();
+    c->n_cigar = c->h_cigar.size();
+    c->n_qual = c->h_qual.size();
+    const size_t n = c->n_reads;
+    HIP_TRY(c, c->d_pos.reserve(n + 1));
+    HIP_TRY(c, c->d_mapq.reserve(n + 1));
+    HIP_TRY(c, c->d_end.reserve(n + 1));
+    HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
+    HIP_TRY(c, c->d_qual_off.reserve(n + 1));
+    HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 1));
+    HIP_TRY(c, c->d_qual.reserve(c->n_qual + 2 * kQualPad));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_mapq.p, c->h_mapq.data(), n, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+    if (c->n_cigar) HIP_TRY(c, hipMemcpyAsync(c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
+    if (c->n_qual) HIP_TRY(c, hipMemcpyAsync(c->d_qual.p + kQualPad, c->h_qual.data(), c->n_qual, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->ref_len_dev = UINT64_MAX;            // force the reference to be re-laid out
+    cl_status s = size_for_extent(c, c->contig_len);
+    if (s != CL_OK) return s;
+    c->ref_len_dev = c->h_ref.size();
+    if (c->d_iv.cap == 0) HIP_TRY(c, c->d_iv.reserve(1u << 20));
+    // the staged copy is no longer needed except the reference (kept for an extent re-run)
+    std::vector<int32_t>().swap(c->h_pos);
+    std::vector<uint8_t>().swap(c->h_mapq);
+    std::vector<uint32_t>().swap(c->h_cigar);
+    std::vector<uint8_t>().swap(c->h_qual);
+    std::vector<uint32_t>().swap(c->h_cigar_off);
+    std::vector<unsigned long long>().swap(c->h_qual_off);
+    c->uploaded = true; c->ran = false;
+    return CL_OK;
+}
+
+cl_status cl_contig_run(cl_ctx *c)
+{
+    if (!c || !c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_run before cl_contig_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    cl_status s = enqueue(c, false, nullptr, nullptr, nullptr);
+    if (s == CL_OK) c->ran = true;
+    return s;
+}
+
+cl_status cl_sync(cl_ctx *c)
+{
+    if (!c) return CL_ERR_INVALID;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return harvest_events(c);
+}
+
+static cl_status check_summary(cl_ctx *c)
+{
+    if (c->h_sum.err & kErrRange) return fail(c, CL_ERR_RANGE, "a read ends beyond the engine's 32-bit coordinate range");
+    if (c->h_sum.err & kErrCigar)
+        return fail(c, CL_ERR_CIGAR, "malformed CIGAR: zero-length reference-consuming operation, or a single non-match "
+                                     "operation on a read that spans reference positions (undefined in htslib's pileup)");
+    return CL_OK;
+}
+
+cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
+{
+    if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        HIP_TRY(c, hipMemcpyAsync(&c->h_sum, c->d_summary.p, sizeof(DevSummary), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        cl_status s = harvest_events(c);
+        if (s != CL_OK) return s;
+        s = check_summary(c);
+        if (s != CL_OK) return s;
+        // a read that overhangs the contig end makes the reference walk (and classify as REF_N,
+        // mod.rs:100-101) positions up to its end: redo the contig with the larger extent
+        if (c->h_sum.max_end > c->extent) {
+            s = size_for_extent(c, (uint32_t)c->h_sum.max_end);
+            if (s != CL_OK) return s;
+            s = enqueue(c, false, nullptr, nullptr, nullptr);
+            if (s != CL_OK) return s;
+            continue;
+        }
+        if (c->h_sum.n_intervals > c->d_iv.cap) {
+            HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
+            if (c->n_win)
+                hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream, c->d_state.p,
+                                   c->d_win_off.p, c->n_win, c->extent, c->d_iv.p,
+                                   (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+            HIP_TRY(c, hipGetLastError());
+        }
+        break;
+    }
+    const size_t niv = c->h_sum.n_intervals;
+    static_assert(sizeof(cl_interval) == sizeof(Interval), "interval layout");
+    try { c->h_iv.resize(niv); } catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "interval buffer"); }
+    if (niv) {
+        HIP_TRY(c, hipMemcpyAsync(c->h_iv.data(), c->d_iv.p, niv * sizeof(Interval), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (out) {
+        static_assert(offsetof(DevSummary, max_end) == sizeof(cl_contig_summary), "summary layout");
+        memcpy(out, &c->h_sum, sizeof(cl_contig_summary));
+    }
+    if (intervals) *intervals = c->h_iv.data();
+    if (n_intervals) *n_intervals = niv;
+    return CL_OK;
+}
+
+cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
+{
+    cl_status s = cl_contig_upload(c);
+    if (s != CL_OK) return s;
+    s = cl_contig_run(c);
+    if (s != CL_OK) return s;
+    return cl_contig_collect(c, out, intervals, n_intervals);
+}
+
+cl_status cl_device_summary(cl_ctx *c, void **dev_ptr, size_t *bytes)
+{
+    if (!c || !dev_ptr || !bytes) return CL_ERR_INVALID;
+    *dev_ptr = c->d_summary.p;
+    *bytes = sizeof(cl_contig_summary);
+    return CL_OK;
+}
+
+cl_status cl_set_profiling(cl_ctx *c, int on)
+{
+    if (!c) return CL_ERR_INVALID;
+    c->profiling = on != 0;
+    return CL_OK;
+}
+
+cl_status cl_get_kernel_ms(cl_ctx *c, double ms[CL_K_COUNT], uint64_t *n_runs)
+{
+    if (!c) return CL_ERR_INVALID;
+    cl_status s = harvest_events(c);
+    if (s != CL_OK) return s;
+    if (ms) for (int i = 0; i < CL_K_COUNT; ++i) ms[i] = c->ms[i];
+    if (n_runs) *n_runs = c->n_runs;
+    return CL_OK;
+}
+
+cl_status cl_reset_kernel_ms(cl_ctx *c)
+{
+    if (!c) return CL_ERR_INVALID;
+    cl_status s = harvest_events(c);
+    if (s != CL_OK) return s;
+    for (int i = 0; i < CL_K_COUNT; ++i) c->ms[i] = 0.0;
+    c->n_runs = 0;
+    return CL_OK;
+}
+
+cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_bytes)
+{
+    if (!c || !c->uploaded) return fail(c, CL_ERR_INVALID, "no resident contig");
+    // what one run must read at least once: quality bytes, per-read pos/mapq/offsets, CIGAR
+    // words, reference bytes; what it must write: one state byte per position
+    const uint64_t n = c->n_reads;
+    if (input_bytes)
+        *input_bytes = c->n_qual + n * (4 + 1 + 4 + 8) + c->n_cigar * 4 + (uint64_t)c->extent;
+    if (output_bytes) *output_bytes = (uint64_t)c->extent;
+    return CL_OK;
+}
+
+cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low, uint8_t *state, uint64_t cap)
+{
+    if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_debug_depths needs a collected contig");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (cap < c->extent) return fail(c, CL_ERR_INVALID, "cap < extent");
+    const size_t padded = (size_t)c->n_win * kT;
+    HIP_TRY(c, c->d_dbg.reserve(3 * padded + 1));
+    cl_status s = enqueue(c, true, c->d_dbg.p, c->d_dbg.p + padded, c->d_dbg.p + 2 * padded);
+    if (s != CL_OK) return s;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const size_t nb = (size_t)c->extent * sizeof(uint32_t);
+    if (raw && nb) HIP_TRY(c, hipMemcpy(raw, c->d_dbg.p, nb, hipMemcpyDeviceToHost));
+    if (qc && nb) HIP_TRY(c, hipMemcpy(qc, c->d_dbg.p + padded, nb, hipMemcpyDeviceToHost));
+    if (low && nb) HIP_TRY(c, hipMemcpy(low, c->d_dbg.p + 2 * padded, nb, hipMemcpyDeviceToHost));
+    if (state && c->extent) HIP_TRY(c, hipMemcpy(state, c->d_state.p, c->extent, hipMemcpyDeviceToHost));
+    return CL_OK;
+}
+
+cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, uint64_t ref_len,
+                         const cl_site_tile *t, const uint32_t *sites, size_t n_sites, uint32_t *hist)
+{
+    if (!c || !t || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_sites == 0) return CL_OK;
+    if (n_sites > 0x0FFFFFFFu) return fail(c, CL_ERR_RANGE, "too many sites");
+    const uint64_t n = t->n_reads;
+    if (n > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "too many reads");
+    // sites sorted by 0-based position (vcf_pos - 1, caller.rs:94); vcf_pos 0 can never match
+    std::vector<uint32_t> order(n_sites);
+    for (size_t i = 0; i < n_sites; ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sites[a] < sites[b]; });
+    std::vector<uint32_t> pos0, idx;
+    pos0.reserve(n_sites); idx.reserve(n_sites);
+    for (size_t i = 0; i < n_sites; ++i) {
+        const uint32_t s = sites[order[i]];
+        if (s == 0) continue;
+        pos0.push_back(s - 1); idx.push_back(order[i]);
+    }
+    memset(hist, 0, n_sites * 16 * sizeof(uint32_t));
+    if (n == 0 || pos0.empty()) return CL_OK;
+    for (uint64_t i = 0; i < n; ++i)
+        if (t->cigar_off[i + 1] < t->cigar_off[i] || t->seq_off[i + 1] < t->seq_off[i])
+            return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    const uint64_t ncig = t->cigar_off[n], nbase = t->seq_off[n];
+    DevBuf<int32_t> d_pos; DevBuf<uint8_t> d_mapq, d_seq; DevBuf<uint32_t> d_coff, d_cig, d_p0, d_ix, d_hist;
+    DevBuf<unsigned long long> d_soff;
+    cl_status rc = CL_OK;
+    auto cleanup = [&]() { d_pos.release(); d_mapq.release(); d_seq.release(); d_coff.release(); d_cig.release();
+                           d_p0.release(); d_ix.release(); d_hist.release(); d_soff.release(); };
+#define SITE_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = fail(c, CL_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); cleanup(); return rc; } } while (0)
+    SITE_TRY(d_pos.reserve(n)); SITE_TRY(d_mapq.reserve(n)); SITE_TRY(d_coff.reserve(n + 1)); SITE_TRY(d_soff.reserve(n + 1));
+    SITE_TRY(d_cig.reserve(ncig + 1)); SITE_TRY(d_seq.reserve((nbase + 1) / 2 + 1));
+    SITE_TRY(d_p0.reserve(pos0.size())); SITE_TRY(d_ix.reserve(pos0.size())); SITE_TRY(d_hist.reserve(n_sites * 16));
+    SITE_TRY(hipMemcpy(d_pos.p, t->pos, n * 4, hipMemcpyHostToDevice));
+    SITE_TRY(hipMemcpy(d_mapq.p, t->mapq, n, hipMemcpyHostToDevice));
+    SITE_TRY(hipMemcpy(d_coff.p, t->cigar_off, (n + 1) * 4, hipMemcpyHostToDevice));
+    SITE_TRY(hipMemcpy(d_soff.p, t->seq_off, (n + 1) * 8, hipMemcpyHostToDevice));
+    if (ncig) SITE_TRY(hipMemcpy(d_cig.p, t->cigar, ncig * 4, hipMemcpyHostToDevice));
+    if (nbase) SITE_TRY(hipMemcpy(d_seq.p, t->seq4, (nbase + 1) / 2, hipMemcpyHostToDevice));
+    SITE_TRY(hipMemcpy(d_p0.p, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice));
+    SITE_TRY(hipMemcpy(d_ix.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
+    SITE_TRY(hipMemsetAsync(d_hist.p, 0, n_sites * 16 * 4, c->stream));
+    SiteReads R;
+    R.pos = d_pos.p; R.mapq = d_mapq.p; R.cigar_off = d_coff.p; R.cigar = d_cig.p; R.seq_off = d_soff.p;
+    R.seq4 = d_seq.p; R.n = (uint32_t)n;
+    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, 8192);
+    hipLaunchKernelGGL(k_site_pileup, dim3(grid), dim3(kBlock), 0, c->stream, R, (uint32_t)min_quality, contig_len,
+                       (unsigned long long)ref_len, d_p0.p, d_ix.p, (uint32_t)pos0.size(), d_hist.p);
+    SITE_TRY(hipGetLastError());
+    SITE_TRY(hipMemcpyAsync(hist, d_hist.p, n_sites * 16 * 4, hipMemcpyDeviceToHost, c->stream));
+    SITE_TRY(hipStreamSynchronize(c->stream));
+#undef SITE_TRY
+    cleanup();
+    return CL_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,350 @@
+// host_coverage.cpp -- implementation of include/dut_coverage.h: the host-side part of the
+// `coverage` path (read admission, BED writer, per-contig driver, derived statistics).
+// The per-position work is done by the device engine (callable_loci.hip); nothing here computes
+// depths or states.
+#include "../../include/dut_coverage.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <queue>
+#include <string>
+#include <vector>
+
+namespace {
+
+const char *const kStateNames[6] = {"REF_N", "CALLABLE", "NO_COVERAGE", "LOW_COVERAGE",
+                                    "EXCESSIVE_COVERAGE", "POOR_MAPPING_QUALITY"};
+
+inline bool ref_consuming(uint32_t op) { return op == 0 || op == 2 || op == 3 || op == 7 || op == 8; }
+
+uint64_t ref_length(const uint32_t *cig, uint32_t n)
+{
+    uint64_t l = 0;
+    for (uint32_t k = 0; k < n; ++k)
+        if (ref_consuming(cig[k] & 15u)) l += cig[k] >> 4;
+    return l;
+}
+
+// exact set of byte strings (HashSet<Vec<u8>>, contig_profiler.rs:20,59-62): open addressing on a
+// 64-bit hash, full comparison on hash match
+struct NameSet {
+    std::vector<uint64_t> hash;
+    std::vector<uint64_t> idx;
+    uint64_t count = 0;
+    const dut_records *rec = nullptr;
+
+    static uint64_t mix(const uint8_t *s, uint32_t n)
+    {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ n;
+        uint32_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            uint64_t v; memcpy(&v, s + i, 8);
+            h = (h ^ v) * 0xff51afd7ed558ccdull; h ^= h >> 32;
+        }
+        uint64_t v = 0;
+        if (i < n) memcpy(&v, s + i, n - i);
+        h = (h ^ v) * 0xc4ceb9fe1a85ec53ull; h ^= h >> 29;
+        h *= 0xff51afd7ed558ccdull; h ^= h >> 32;
+        return h ? h : 1;
+    }
+    void grow()
+    {
+        const size_t ncap = hash.empty() ? 4096 : hash.size() * 2;
+        std::vector<uint64_t> nh(ncap, 0), ni(ncap, 0);
+        for (size_t i = 0; i < hash.size(); ++i)
+            if (hash[i]) {
+                size_t j = hash[i] & (ncap - 1);
+                while (nh[j]) j = (j + 1) & (ncap - 1);
+                nh[j] = hash[i]; ni[j] = idx[i];
+            }
+        hash.swap(nh); idx.swap(ni);
+    }
+    bool insert(uint64_t r)
+    {
+        if ((count + 1) * 2 > hash.size()) grow();
+        const uint8_t *nm = rec->qname + rec->qname_off[r];
+        const uint32_t nl = rec->qname_off[r + 1] - rec->qname_off[r];
+        const uint64_t h = mix(nm, nl);
+        size_t j = h & (hash.size() - 1);
+        while (hash[j]) {
+            if (hash[j] == h) {
+                const uint64_t o = idx[j];
+                const uint32_t ol = rec->qname_off[o + 1] - rec->qname_off[o];
+                if (ol == nl && memcmp(rec->qname + rec->qname_off[o], nm, nl) == 0) return false;
+            }
+            j = (j + 1) & (hash.size() - 1);
+        }
+        hash[j] = h; idx[j] = r; ++count;
+        return true;
+    }
+};
+
+} // namespace
+
+struct dut_profiler {
+    FILE *bed = nullptr;
+    bool has_state = false;
+    std::string cur_contig;
+    uint64_t cur_start = 0, cur_end = 0;
+    uint32_t cur_state = 0;
+    std::vector<std::pair<std::string, std::vector<uint64_t>>> counts;
+
+    void write_state()                       // callable_profiler.rs:39-62
+    {
+        if (has_state)
+            fprintf(bed, "%s\t%llu\t%llu\t%s\n", cur_contig.c_str(), (unsigned long long)cur_start,
+                    (unsigned long long)cur_end, kStateNames[cur_state]);
+    }
+};
+
+extern "C" {
+
+const char *dut_state_name(uint32_t s) { return s < 6 ? kStateNames[s] : "?"; }
+
+dut_profiler *dut_profiler_new(const char *bed_path)
+{
+    if (!bed_path) return nullptr;
+    FILE *f = fopen(bed_path, "wb");                       // File::create, :31
+    if (!f) return nullptr;
+    setvbuf(f, nullptr, _IOFBF, 1 << 20);
+    dut_profiler *p = new dut_profiler();
+    p->bed = f;
+    return p;
+}
+
+void dut_profiler_free(dut_profiler *p)
+{
+    if (!p) return;
+    if (p->bed) fclose(p->bed);
+    delete p;
+}
+
+void dut_profiler_contig_counts(const dut_profiler *p, const char *contig, uint64_t out[6])
+{
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    if (!p || !contig) return;
+    for (const auto &e : p->counts)
+        if (e.first == contig) { for (int i = 0; i < 6; ++i) out[i] = e.second[i]; return; }
+}
+
+int dut_profiler_feed_contig(dut_profiler *p, const char *contig, const cl_interval *iv, size_t n_iv,
+                             const uint64_t state_counts[6])
+{
+    if (!p || !contig || (!iv && n_iv)) return CL_ERR_INVALID;
+    // contig_counts[contig][state] += 1 per position (:124-126): the device counted them
+    if (n_iv) {
+        std::vector<uint64_t> *slot = nullptr;
+        for (auto &e : p->counts) if (e.first == contig) slot = &e.second;
+        if (!slot) { p->counts.emplace_back(contig, std::vector<uint64_t>(6, 0)); slot = &p->counts.back().second; }
+        for (int i = 0; i < 6; ++i) (*slot)[i] += state_counts ? state_counts[i] : 0;
+    }
+    for (size_t i = 0; i < n_iv; ++i) {
+        const uint64_t start = iv[i].start, end = iv[i].end;
+        const uint32_t state = iv[i].state;
+        if (state > 5 || end <= start) return CL_ERR_INVALID;
+        if (!p->has_state) {                                  // first position ever, :128-141
+            if (state == CL_REF_N) {
+                p->cur_contig = contig; p->cur_start = 0; p->cur_end = start + 1; p->cur_state = state;
+                p->has_state = true;
+            } else {
+                if (start > 0) {
+                    p->cur_contig = contig; p->cur_start = 0; p->cur_end = start; p->cur_state = CL_REF_N;
+                    p->has_state = true;
+                    p->write_state();
+                }
+                p->cur_contig = contig; p->cur_start = start; p->cur_end = start + 1; p->cur_state = state;
+                p->has_state = true;
+            }
+            p->cur_end = end;                                 // the remaining positions of the run extend it
+            continue;
+        }
+        if (p->cur_contig == contig && p->cur_state == state) {
+            p->cur_end = end;                                 // :144-146
+        } else {
+            p->write_state();                                 // :147-151
+            p->cur_contig = contig; p->cur_start = start; p->cur_end = end; p->cur_state = state;
+        }
+    }
+    p->write_state();                                         // finish_contig, :64-66 (state kept)
+    return CL_OK;
+}
+
+int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, const dut_records *rec,
+                    uint8_t *accepted, uint32_t *n_unique_names, uint64_t *n_accepted)
+{
+    if (!opt || !rec || (!accepted && rec->n)) return CL_ERR_INVALID;
+    const uint64_t maxcnt = opt->max_depth > 0 ? opt->max_depth : 500;   // mod.rs:56-60
+    // Ends of the reads the pileup list holds.  When the cursor sits on start position s the
+    // list holds exactly the appended reads with end >= s (reads that ended earlier were freed
+    // while the columns before s were produced; a read ending AT s is freed only when column s
+    // itself is walked).
+    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> live;
+    NameSet names; names.rec = rec;
+    bool any_pushed = false;
+    int64_t cur_start = -1;
+    uint64_t nacc = 0;
+    for (uint64_t i = 0; i < rec->n; ++i) {
+        accepted[i] = 0;
+        const int64_t p = rec->pos[i];
+        if (p >= (int64_t)contig_len) continue;              // not yielded by fetch((tid,0,len))
+        if (rec->flag[i] & 0x4) continue;                    // BAM_FUNMAP: bam_plp_push skips it
+        const uint64_t rl = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]);
+        const uint64_t end = (uint64_t)p + rl;
+        bool appended;
+        if (!any_pushed) {
+            // the iterator starts at (tid 0, pos 0): the cap test can only see an empty list here
+            appended = end > 0 || tid > 0;
+            any_pushed = true; cur_start = p;
+        } else if (p == cur_start) {
+            // not the first read at this start: the cursor sits here, the cap applies
+            if (live.size() >= maxcnt) continue;
+            appended = end > (uint64_t)p;
+        } else {
+            if (p < cur_start) return CL_ERR_UNSORTED;
+            cur_start = p;
+            while (!live.empty() && live.top() < (uint64_t)p) live.pop();
+            appended = true;                                  // cursor still on the previous start
+        }
+        if (!appended) continue;
+        live.push(end);
+        if (rl > 0) {
+            accepted[i] = 1; ++nacc;
+            if (rec->qname_off) names.insert(i);
+        }
+    }
+    if (n_unique_names) *n_unique_names = (uint32_t)names.count;
+    if (n_accepted) *n_accepted = nacc;
+    return CL_OK;
+}
+
+int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats *stats, const cl_options *opt,
+                              const char *contig_name, int32_t tid, uint32_t contig_len, const uint8_t *ref,
+                              uint64_t ref_len, const dut_records *rec)
+{
+    if (!ctx || !prof || !stats || !opt || !contig_name || !rec) return CL_ERR_INVALID;
+    std::vector<uint8_t> acc(rec->n ? rec->n : 1);
+    uint32_t n_names = 0; uint64_t n_acc = 0;
+    int rc = dut_admit_reads(opt, tid, contig_len, rec, acc.data(), &n_names, &n_acc);
+    if (rc != CL_OK) return rc;
+    rc = cl_contig_begin(ctx, tid, contig_len, ref, ref_len);
+    if (rc != CL_OK) return rc;
+    // compact the accepted reads into SoA tiles
+    const uint64_t kTile = 1u << 20;
+    std::vector<int32_t> pos; std::vector<uint8_t> mapq; std::vector<uint32_t> coff, cig;
+    std::vector<uint64_t> qoff; std::vector<uint8_t> qual;
+    uint64_t i = 0;
+    while (i < rec->n) {
+        pos.clear(); mapq.clear(); cig.clear(); qual.clear();
+        coff.assign(1, 0u); qoff.assign(1, 0ull);
+        for (; i < rec->n && pos.size() < kTile; ++i) {
+            if (!acc[i]) continue;
+            pos.push_back(rec->pos[i]); mapq.push_back(rec->mapq[i]);
+            cig.insert(cig.end(), rec->cigar + rec->cigar_off[i], rec->cigar + rec->cigar_off[i + 1]);
+            qual.insert(qual.end(), rec->qual + rec->qual_off[i], rec->qual + rec->qual_off[i + 1]);
+            coff.push_back((uint32_t)cig.size()); qoff.push_back(qual.size());
+        }
+        if (pos.empty()) continue;
+        cl_read_tile t;
+        t.n_reads = pos.size(); t.pos = pos.data(); t.mapq = mapq.data(); t.cigar_off = coff.data();
+        t.cigar = cig.data(); t.qual_off = qoff.data(); t.qual = qual.data();
+        rc = cl_push_reads(ctx, &t);
+        if (rc != CL_OK) return rc;
+    }
+    cl_contig_summary sum; const cl_interval *iv = nullptr; size_t niv = 0;
+    rc = cl_contig_finish(ctx, &sum, &iv, &niv);
+    if (rc != CL_OK) return rc;
+    rc = dut_profiler_feed_contig(prof, contig_name, iv, niv, sum.state_counts);
+    if (rc != CL_OK) return rc;
+    stats->length = contig_len;
+    stats->n_covered_bases = sum.n_covered_bases;
+    stats->summed_coverage = sum.summed_coverage;
+    stats->summed_baseq = sum.summed_baseq;
+    stats->summed_mapq = sum.summed_mapq;
+    stats->quality_bases = sum.quality_bases;
+    stats->n_reads = n_names;
+    stats->reserved = 0;
+    return CL_OK;
+}
+
+void dut_contig_derive(const dut_contig_stats *s, dut_contig_derived *o)
+{
+    o->coverage_percent = s->length > 0 ? ((double)s->n_covered_bases / (double)s->length) * 100.0 : 0.0;
+    o->average_depth = s->n_covered_bases > 0 ? (double)s->summed_coverage / (double)s->n_covered_bases : 0.0;
+    o->average_mapq = s->quality_bases > 0 ? (double)s->summed_mapq / (double)s->quality_bases : 0.0;
+    o->average_baseq = s->quality_bases > 0 ? (double)s->summed_baseq / (double)s->quality_bases : 0.0;
+    if (s->quality_bases > 0) {
+        if (o->average_baseq >= 30.0) o->q30_percentage = 100.0;
+        else if (o->average_baseq < 20.0) o->q30_percentage = 0.0;
+        else o->q30_percentage = ((o->average_baseq - 20.0) / 10.0) * 100.0;
+    } else o->q30_percentage = 0.0;
+}
+
+int dut_compare_contig_names(const char *a, const char *b)
+{
+    // split at the first ASCII digit or 'X' 'Y' 'M' (report.rs:385-393)
+    auto split = [](const std::string &s) {
+        size_t i = 0;
+        for (; i < s.size(); ++i) { char c = s[i]; if ((c >= '0' && c <= '9') || c == 'X' || c == 'Y' || c == 'M') break; }
+        return i;
+    };
+    // (category, number): numeric first, then X, Y, M/MT, then the rest (report.rs:355-369)
+    auto order = [](const std::string &s, int &cat, uint32_t &num) {
+        size_t st = (!s.empty() && s[0] == '+') ? 1 : 0;     // u32::from_str accepts a leading '+'
+        bool ok = s.size() > st; uint64_t v = 0;
+        for (size_t i = st; ok && i < s.size(); ++i) {
+            if (s[i] < '0' || s[i] > '9') ok = false;
+            else { v = v * 10 + (uint64_t)(s[i] - '0'); if (v > 0xFFFFFFFFull) ok = false; }
+        }
+        num = 0;
+        if (ok) { cat = 0; num = (uint32_t)v; }
+        else if (s == "X") cat = 1;
+        else if (s == "Y") cat = 2;
+        else if (s == "M" || s == "MT") cat = 3;
+        else cat = 4;
+    };
+    const std::string sa(a), sb(b);
+    const size_t ia = split(sa), ib = split(sb);
+    const int pc = sa.compare(0, ia, sb, 0, ib);
+    if (pc != 0) return pc < 0 ? -1 : 1;
+    const std::string xa = sa.substr(ia), xb = sb.substr(ib);
+    int ca, cb; uint32_t na, nb;
+    order(xa, ca, na); order(xb, cb, nb);
+    if (ca != cb) return ca < cb ? -1 : 1;
+    if (ca == 0) return na < nb ? -1 : (na > nb ? 1 : 0);
+    const int c = xa.compare(xb);
+    return c < 0 ? -1 : (c > 0 ? 1 : 0);
+}
+
+void dut_genome_summary_build(const dut_contig_stats *stats, const uint64_t *callable, size_t n, dut_genome_summary *out)
+{
+    uint64_t total_bases = 0, callable_bases = 0, q30_bases = 0, total_quality_positions = 0, total_unique_reads = 0;
+    double total_depth = 0.0, total_mapq = 0.0, total_baseq = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        dut_contig_derived d;
+        dut_contig_derive(&stats[i], &d);
+        const double len = (double)stats[i].length;
+        total_bases += stats[i].length;
+        callable_bases += callable[i];
+        total_depth += d.average_depth * len;
+        total_mapq += d.average_mapq * len;
+        total_baseq += d.average_baseq * len;
+        const double q = d.q30_percentage / 100.0 * len;     // `as u64`: saturating, toward zero
+        q30_bases += q <= 0.0 ? 0ull : (q >= 18446744073709551615.0 ? ~0ull : (uint64_t)q);
+        total_quality_positions += stats[i].length;
+        total_unique_reads += stats[i].n_reads;
+    }
+    out->total_bases = total_bases;
+    out->callable_bases = callable_bases;
+    out->callable_percentage = total_bases > 0 ? ((double)callable_bases / (double)total_bases) * 100.0 : 0.0;
+    out->average_depth = total_bases > 0 ? total_depth / (double)total_bases : 0.0;
+    out->average_mapq = total_quality_positions > 0 ? total_mapq / (double)total_quality_positions : 0.0;
+    out->average_baseq = total_quality_positions > 0 ? total_baseq / (double)total_quality_positions : 0.0;
+    out->q30_percentage = total_quality_positions > 0 ? ((double)q30_bases / (double)total_quality_positions) * 100.0 : 0.0;
+    out->total_unique_reads = total_unique_reads;
+    out->contigs_analyzed = n;
+}
+
+} // extern "C"

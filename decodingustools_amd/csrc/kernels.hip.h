@@ -1,0 +1,721 @@
+// kernels.hip.h -- gfx950 (MI355X / CDNA4) kernels of the callable-loci engine.
+//
+// Data flow of one contig (all arrays resident in HBM, layouts in DESIGN.md section 3):
+//
+//   k_read_prep      per read: CIGAR walk -> end[r]; block partials of the per-read separable
+//                    sums (contig_profiler.rs:74,79-82 via SURVEY 8a-7), max span, max end
+//   k_window_bounds  per window of T reference positions: [lo,hi) range of reads that can touch it
+//   k_pileup<T>      one workgroup per window: the three per-position counters of
+//                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
+//                    (callable_profiler.rs:100-116) and written as one state byte per position
+//   k_finalize       run-boundary counts -> exclusive offsets; window / read partials -> summary
+//   k_rle_write      state bytes -> (start,end,state) intervals (callable_profiler.rs:122-155)
+//
+// Integer / byte work throughout: HBM-bound, no MFMA.  Wave = 64 lanes.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace clk {
+
+constexpr int kBlock = 256;          // threads per workgroup (4 waves)
+constexpr int kPrepBlocks = 1024;    // grid of k_read_prep (grid-stride)
+constexpr int kGroup = 16;           // lanes that share one read in the quality pass
+constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
+constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
+
+enum : uint32_t { kErrCigar = 1u, kErrRange = 2u };
+
+// per-block output of k_read_prep
+struct PrepPartial {
+    unsigned long long sum_reflen;       // -> summed_coverage
+    unsigned long long sum_mapq_reflen;  // -> summed_mapq
+    uint32_t max_span;
+    uint32_t max_end;
+    uint32_t err;
+    uint32_t pad;
+};
+
+// per-window output of k_pileup
+struct WinPartial {
+    unsigned long long cnt[6];       // state counts
+    unsigned long long n_cov;        // positions with raw_depth > 0
+    unsigned long long sum_qc;       // -> quality_bases
+    unsigned long long sum_q;        // -> summed_baseq
+    uint32_t n_inner;                // run boundaries strictly inside the window
+    uint32_t max_raw;
+};
+
+// mirrors cl_contig_summary (include/callable_loci.h) + engine-private tail
+struct DevSummary {
+    unsigned long long state_counts[6];
+    unsigned long long n_covered_bases;
+    unsigned long long summed_coverage;
+    unsigned long long summed_baseq;
+    unsigned long long summed_mapq;
+    unsigned long long quality_bases;
+    unsigned long long extent;
+    unsigned long long max_raw_depth;
+    unsigned long long n_intervals;
+    // private
+    unsigned long long max_end;
+    unsigned long long err;
+};
+
+struct Interval { uint32_t start, end, state; };
+
+struct Opts {
+    uint32_t min_depth;
+    uint32_t max_depth;
+    uint32_t min_mapq;
+    uint32_t min_depth_for_low_mapq;
+    uint32_t max_low_mapq;
+    double   max_low_mapq_fraction;
+    // byte-parallel "quality >= min_base_quality" constants (see qual_ge)
+    uint32_t ge_add, ge_or, ge_and;
+};
+
+struct Reads {
+    const int32_t  *pos;
+    const uint8_t  *mapq;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const unsigned long long *qual_off;
+    const uint8_t  *qual;       // points kQualPad bytes into the allocation
+    uint32_t n;
+};
+
+__device__ __forceinline__ bool op_match(uint32_t op) { return op == 0u || op == 7u || op == 8u; }
+__device__ __forceinline__ bool op_del(uint32_t op) { return op == 2u || op == 3u; }
+__device__ __forceinline__ bool op_ins(uint32_t op) { return op == 1u || op == 4u; }
+
+// ---------------------------------------------------------------------------------------------
+// wave / block reductions (wave64)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_down(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    for (int o = 32; o > 0; o >>= 1) v |= __shfl_down(v, o, 64);
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_read_prep: one thread per read (grid-stride).
+//   end[r] = pos + bam_cigar2rlen  (the pileup node span)
+//   sum_reflen       = sum over reads of reflen                 == summed_coverage
+//   sum_mapq_reflen  = sum over reads with mapq >= min_mapq of mapq*reflen == summed_mapq
+// CIGAR shapes htslib's resolve_cigar2 asserts on / indexes out of bounds for are flagged.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t *__restrict__ end_out,
+                                                       PrepPartial *__restrict__ part)
+{
+    __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
+    __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
+    unsigned long long sum_len = 0, sum_mq = 0;
+    uint32_t max_span = 0, max_end = 0, err = 0;
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < R.n; r += gridDim.x * kBlock) {
+        const uint32_t k0 = R.cigar_off[r], k1 = R.cigar_off[r + 1];
+        unsigned long long reflen = 0;
+        for (uint32_t k = k0; k < k1; ++k) {
+            const uint32_t c = R.cigar[k], op = c & 15u, l = c >> 4;
+            if (op_match(op) || op_del(op)) {
+                reflen += l;
+                if (l == 0) err |= kErrCigar;          // zero-length reference-consuming op
+            }
+        }
+        // a read that reaches a column with a single non-match op is undefined in htslib
+        if (reflen > 0 && k1 - k0 == 1 && !op_match(R.cigar[k0] & 15u)) err |= kErrCigar;
+        const unsigned long long e = (unsigned long long)(uint32_t)R.pos[r] + reflen;
+        if (e > 0xFFFF0000ull) { err |= kErrRange; }
+        const uint32_t e32 = e > 0xFFFF0000ull ? (uint32_t)R.pos[r] : (uint32_t)e;
+        end_out[r] = e32;
+        const uint32_t span = e32 - (uint32_t)R.pos[r];
+        sum_len += span;
+        const uint32_t mq = R.mapq[r];
+        if (mq >= o.min_mapq) sum_mq += (unsigned long long)mq * span;
+        max_span = span > max_span ? span : max_span;
+        max_end = e32 > max_end ? e32 : max_end;
+    }
+    sum_len = wave_sum_u64(sum_len);
+    sum_mq = wave_sum_u64(sum_mq);
+    max_span = wave_max_u32(max_span);
+    max_end = wave_max_u32(max_end);
+    err = wave_or_u32(err);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        s_a[wv] = sum_len; s_b[wv] = sum_mq; s_c[wv] = max_span; s_d[wv] = max_end; s_e[wv] = err;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PrepPartial p;
+        p.sum_reflen = 0; p.sum_mapq_reflen = 0; p.max_span = 0; p.max_end = 0; p.err = 0; p.pad = 0;
+        for (int i = 0; i < kBlock / 64; ++i) {
+            p.sum_reflen += s_a[i]; p.sum_mapq_reflen += s_b[i];
+            p.max_span = s_c[i] > p.max_span ? s_c[i] : p.max_span;
+            p.max_end = s_d[i] > p.max_end ? s_d[i] : p.max_end;
+            p.err |= s_e[i];
+        }
+        part[blockIdx.x] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_window_bounds: thread per window.  Reads are sorted by pos; a read can touch window
+// [W, W+T) only if pos < W+T and pos + max_span > W.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t n, long long key)
+{
+    uint32_t lo = 0, hi = n;                       // first r with pos[r] >= key
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPartial *__restrict__ part,
+                                                           uint32_t T, uint32_t n_win,
+                                                           uint32_t *__restrict__ win_lo,
+                                                           uint32_t *__restrict__ win_hi)
+{
+    __shared__ uint32_t s_m[kBlock / 64];
+    uint32_t m = 0;
+    for (int i = threadIdx.x; i < kPrepBlocks; i += kBlock) { uint32_t v = part[i].max_span; m = v > m ? v : m; }
+    m = wave_max_u32(m);
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    uint32_t max_span = 0;
+    for (int i = 0; i < kBlock / 64; ++i) max_span = s_m[i] > max_span ? s_m[i] : max_span;
+    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
+    if (w >= n_win) return;
+    const long long W = (long long)w * T;
+    win_lo[w] = lower_bound_pos(R.pos, R.n, W - (long long)max_span + 1);
+    win_hi[w] = lower_bound_pos(R.pos, R.n, W + (long long)T);
+}
+
+// ---------------------------------------------------------------------------------------------
+// byte-parallel threshold test.  x holds 4 quality bytes; returns 0x80 in each byte with
+// quality >= min_base_quality (mod.rs:33).  Constants from make_ge_consts():
+//   T == 0        : always                   ge_add = 0x80.., OR form
+//   1 <= T <= 128 : hi(x) | (lo7(x) >= T)    ge_add = 128 - T, OR form
+//   T >= 129      : hi(x) & (lo7(x) >= T-128) ge_add = 256 - T, AND form
+// lo7 + ge_add never carries out of its byte (both <= 127 / 128+127 < 256).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t qual_ge(uint32_t x, const Opts &o)
+{
+    const uint32_t d = (x & 0x7f7f7f7fu) + o.ge_add;
+    return ((d | (x & o.ge_or)) & (x | o.ge_and)) & 0x80808080u;
+}
+
+struct __attribute__((packed, aligned(1))) Q16 { uint32_t w[4]; };
+
+struct PileupArgs {
+    Reads R;
+    Opts o;
+    const uint32_t *end;          // per read
+    const uint32_t *win_lo, *win_hi;
+    const uint8_t  *ref;          // padded with 'N' up to n_win*T
+    const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
+    uint8_t        *state;        // n_win*T bytes
+    WinPartial     *winpart;
+    uint32_t        extent;       // positions >= extent are not classified
+    uint32_t        n_win;
+    uint32_t        n_win8;       // ceil(n_win/8): XCD-contiguous window ranges
+    // debug dumps (nullptr in production)
+    uint32_t *dbg_raw, *dbg_qc, *dbg_low;
+};
+
+// classify one position: callable_profiler.rs:100-116
+__device__ __forceinline__ uint32_t classify(uint32_t refb, uint32_t raw, uint32_t qc, uint32_t low,
+                                             const Opts &o, const uint32_t *__restrict__ lut)
+{
+    if (refb == 'N' || refb == 'n') return 0u;                  // REF_N
+    if (raw == 0) return 2u;                                    // NO_COVERAGE
+    bool is_low = false;
+    if (raw >= o.min_depth_for_low_mapq) {
+        if (raw < kLutSize) is_low = low >= lut[raw];
+        else is_low = ((double)low / (double)raw) > o.max_low_mapq_fraction;   // IEEE f64 divide
+    }
+    if (is_low) return 5u;                                      // POOR_MAPPING_QUALITY
+    if (qc < o.min_depth) return 3u;                            // LOW_COVERAGE
+    if (o.max_depth > 0 && qc > o.max_depth) return 4u;         // EXCESSIVE_COVERAGE
+    return 1u;                                                  // CALLABLE
+}
+
+constexpr int kSegPerLane = 4;                       // segments a lane may emit per round
+constexpr int kSegCap = kBlock * kSegPerLane;        // LDS segment list capacity
+constexpr int kQuads = kBlock / 4;
+
+template <int T, bool DEBUG>
+__global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
+{
+    constexpr int PER = T / kBlock;                 // positions per thread in scan / classify
+    static_assert(PER == 8 || PER == 16 || PER == 32, "T must be 2048, 4096 or 8192");
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[T];
+    __shared__ __attribute__((aligned(16))) uint32_t s_low[T];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qc[T];   // bytes [0,T) in 8-bit mode
+    __shared__ __attribute__((aligned(8))) uint2 s_seg[kSegCap];
+    __shared__ uint32_t s_nseg[2];
+    __shared__ uint32_t s_wraw[kBlock / 64], s_wlow[kBlock / 64], s_wmax[kBlock / 64];
+    __shared__ uint32_t s_last[kBlock];
+    __shared__ unsigned long long s_acc[10];        // cnt[6], n_cov, sum_qc, sum_q, n_inner
+
+    // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
+    // each XCD one contiguous range of windows so neighbouring windows share its L2.
+    const uint32_t w = (blockIdx.x & 7u) * a.n_win8 + (blockIdx.x >> 3);
+    if (w >= a.n_win) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = w * (uint32_t)T;
+    const uint32_t Wend = W + (uint32_t)T;
+
+    // ---- phase 0: clear the window's counters ----
+    {
+        uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low),
+              *q4 = reinterpret_cast<uint4 *>(s_qc);
+        for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; q4[i] = z; }
+        if (tid < 10) s_acc[tid] = 0;
+        if (tid < 2) s_nseg[tid] = 0;
+    }
+    __syncthreads();
+
+    const uint32_t lo = a.win_lo[w], hi = a.win_hi[w];
+
+    // ---- phase 1: raw_depth and low_mapq_count as +1/-1 at the clipped read span ends ----
+    // (both count every read whose [pos,end) covers the position, D/N included: mod.rs:22-28)
+    for (uint32_t r = lo + tid; r < hi; r += kBlock) {
+        const uint32_t e = a.end[r];
+        if (e <= W) continue;
+        const uint32_t b = (uint32_t)a.R.pos[r];
+        const uint32_t cb = b > W ? b - W : 0u;
+        const uint32_t ce = e - W;
+        atomicAdd(&s_raw[cb], 1u);
+        if (ce < (uint32_t)T) atomicAdd(&s_raw[ce], 0xFFFFFFFFu);
+        if ((uint32_t)a.R.mapq[r] <= a.o.max_low_mapq) {
+            atomicAdd(&s_low[cb], 1u);
+            if (ce < (uint32_t)T) atomicAdd(&s_low[ce], 0xFFFFFFFFu);
+        }
+    }
+    __syncthreads();
+
+    // ---- phase 2: prefix sums -> depths; block max of raw ----
+    uint32_t maxraw;
+    {
+        uint32_t vr[PER], vl[PER];
+        uint32_t sr = 0, sl = 0, mx = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            sr += s_raw[tid * PER + i]; vr[i] = sr;
+            sl += s_low[tid * PER + i]; vl[i] = sl;
+        }
+        // inclusive scan of thread totals across the wave
+        uint32_t ir = sr, il = sl;
+        const int lane = tid & 63;
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t tr = __shfl_up(ir, o, 64), tl = __shfl_up(il, o, 64);
+            if (lane >= o) { ir += tr; il += tl; }
+        }
+        const int wv = tid >> 6;
+        if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
+        __syncthreads();
+        uint32_t offr = ir - sr, offl = il - sl;
+        for (int i = 0; i < wv; ++i) { offr += s_wraw[i]; offl += s_wlow[i]; }
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t x = vr[i] + offr;
+            s_raw[tid * PER + i] = x;
+            s_low[tid * PER + i] = vl[i] + offl;
+            mx = x > mx ? x : mx;
+        }
+        mx = wave_max_u32(mx);
+        if (lane == 0) s_wmax[wv] = mx;
+        __syncthreads();
+        maxraw = 0;
+        for (int i = 0; i < kBlock / 64; ++i) maxraw = s_wmax[i] > maxraw ? s_wmax[i] : maxraw;
+    }
+    // qc_depth <= raw_depth at every position, so byte counters cannot overflow when the
+    // window's largest column is <= 255; otherwise use one 32-bit counter per position.
+    const bool mode8 = maxraw <= 255u;
+
+    // ---- phase 3: qc_depth -- M/=/X bases with base quality >= min (reads with mapq >= min) ----
+    // Rounds of two steps.  A: one lane per read walks its CIGAR and appends the window-clipped
+    // M/=/X segments (at most kSegPerLane per round) to an LDS list.  B: lane quads take segments
+    // from the list; each lane handles units of 16 reference positions = one unaligned 16-byte
+    // load of quality bytes, a byte-parallel threshold test and packed LDS counter adds.
+    unsigned long long sumq = 0;
+    {
+        uint32_t par = 0;
+        const uint32_t quad = tid >> 2, ql = tid & 3u;
+        for (uint32_t batch = lo; batch < hi; batch += kBlock) {
+            const uint32_t r = batch + tid;
+            bool live = false;
+            uint32_t x = 0, y = 0, k = 0, k1 = 0, qlen = 0;
+            unsigned long long q0 = 0;
+            if (r < hi && (uint32_t)a.R.mapq[r] >= a.o.min_mapq && a.end[r] > W) {
+                live = true;
+                x = (uint32_t)a.R.pos[r];
+                k = a.R.cigar_off[r];
+                k1 = a.R.cigar_off[r + 1];
+                q0 = a.R.qual_off[r];
+                const unsigned long long ql64 = a.R.qual_off[r + 1] - q0;
+                qlen = ql64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ql64;
+            }
+            for (;;) {
+                // -- A: emit segments --
+                uint32_t nemit = 0;
+                while (live && nemit < (uint32_t)kSegPerLane) {
+                    if (k >= k1 || x >= Wend) { live = false; break; }
+                    const uint32_t c = a.R.cigar[k], op = c & 15u, l = c >> 4;
+                    ++k;
+                    if (op_match(op)) {
+                        const uint32_t xe = x + l;
+                        if (xe > W && y < qlen) {
+                            const uint32_t s = x > W ? x : W;
+                            uint32_t t = xe < Wend ? xe : Wend;
+                            const uint32_t lq = (qlen - y) < l ? (qlen - y) : l;   // bases that have a quality byte
+                            t = (x + lq) < t ? (x + lq) : t;
+                            if (s < t) {
+                                const unsigned long long qi = q0 + y + (s - x);   // quality index of position s
+                                const uint32_t slot = atomicAdd(&s_nseg[par], 1u);
+                                s_seg[slot] = make_uint2((uint32_t)qi,
+                                                         (uint32_t)(qi >> 32) | ((s - W) << 6) | ((t - s - 1u) << 19));
+                                ++nemit;
+                            }
+                        }
+                        x = xe; y += l;
+                    } else if (op_del(op)) {
+                        x += l;
+                    } else if (op_ins(op)) {
+                        y += l;
+                    }
+                }
+                live = live && k < k1 && x < Wend;
+                const int more = __syncthreads_or(live ? 1 : 0);
+                // -- B: consume segments --
+                const uint32_t nseg = s_nseg[par];
+                if (tid == 0) s_nseg[par ^ 1u] = 0;
+                for (uint32_t j = quad; j < nseg; j += kQuads) {
+                    const uint2 d = s_seg[j];
+                    const uint32_t srel = (d.y >> 6) & 0x1FFFu;
+                    const uint32_t trel = srel + (d.y >> 19) + 1u;
+                    const long long qis = (long long)(((unsigned long long)(d.y & 63u) << 32) | d.x) - (long long)srel;
+                    const uint32_t u1 = (trel - 1u) >> 4;
+                    for (uint32_t u = (srel >> 4) + ql; u <= u1; u += 4u) {
+                        const uint32_t ps = u << 4;                       // unit start, window relative
+                        const uint32_t vs = srel > ps ? srel - ps : 0u;
+                        const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                        Q16 v;
+                        __builtin_memcpy(&v, a.R.qual + (qis + (long long)ps), 16);
+                        const uint32_t pm = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const uint32_t xw = v.w[jj];
+                            const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;
+                            const uint32_t inc = (qual_ge(xw, a.o) >> 7) & vm;
+                            if (inc) {
+                                if (mode8) {
+                                    atomicAdd(&s_qc[(u << 2) + jj], inc);
+                                } else {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i)
+                                        if ((inc >> (8 * i)) & 1u) atomicAdd(&s_qc[(u << 4) + 4 * jj + i], 1u);
+                                }
+                                sumq += __builtin_amdgcn_sad_u8(xw & ((inc << 8) - inc), 0u, 0u);
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                par ^= 1u;
+                if (!more) break;
+            }
+        }
+    }
+
+    // ---- phase 4: classify, count, write state bytes ----
+    {
+        uint32_t st[PER];
+        unsigned long long cntp = 0;                // six 8-bit fields (PER <= 32)
+        uint32_t ncov = 0;
+        unsigned long long sqc = 0;
+        const uint32_t p0 = W + tid * PER;
+        const uint8_t *refp = a.ref + p0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t p = p0 + i;
+            const uint32_t raw = s_raw[tid * PER + i], low = s_low[tid * PER + i];
+            const uint32_t qc = mode8 ? reinterpret_cast<const uint8_t *>(s_qc)[tid * PER + i]
+                                      : s_qc[tid * PER + i];
+            if (DEBUG) {
+                if (a.dbg_raw) a.dbg_raw[p] = raw;
+                if (a.dbg_qc) a.dbg_qc[p] = qc;
+                if (a.dbg_low) a.dbg_low[p] = low;
+            }
+            uint32_t s = 0xFFu;
+            if (p < a.extent) {
+                s = classify(refp[i], raw, qc, low, a.o, a.lut);
+                cntp += 1ull << (8u * s);
+                ncov += raw > 0 ? 1u : 0u;
+                sqc += qc;
+            }
+            st[i] = s;
+        }
+        // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
+        s_last[tid] = st[PER - 1];
+        __syncthreads();
+        uint32_t nb = 0;
+        uint32_t prev = tid > 0 ? s_last[tid - 1] : st[0];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (p0 + i < a.extent && st[i] != prev) nb += 1;
+            prev = st[i];
+        }
+        // state bytes, PER per thread
+        if (PER == 8) {
+            uint2 v;
+            v.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+            v.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+            *reinterpret_cast<uint2 *>(a.state + p0) = v;
+        } else {
+#pragma unroll
+            for (int i = 0; i + 15 < PER; i += 16) {
+                uint4 v;
+                v.x = st[i + 0] | (st[i + 1] << 8) | (st[i + 2] << 16) | (st[i + 3] << 24);
+                v.y = st[i + 4] | (st[i + 5] << 8) | (st[i + 6] << 16) | (st[i + 7] << 24);
+                v.z = st[i + 8] | (st[i + 9] << 8) | (st[i + 10] << 16) | (st[i + 11] << 24);
+                v.w = st[i + 12] | (st[i + 13] << 8) | (st[i + 14] << 16) | (st[i + 15] << 24);
+                *reinterpret_cast<uint4 *>(a.state + p0 + i) = v;
+            }
+        }
+        // block totals
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const uint32_t v = (uint32_t)(cntp >> (8 * c)) & 0xFFu;
+            if (v) atomicAdd(&s_acc[c], (unsigned long long)v);
+        }
+        if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
+        if (sqc) atomicAdd(&s_acc[7], sqc);
+        if (sumq) atomicAdd(&s_acc[8], sumq);
+        if (nb) atomicAdd(&s_acc[9], (unsigned long long)nb);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        WinPartial wp;
+        for (int c = 0; c < 6; ++c) wp.cnt[c] = s_acc[c];
+        wp.n_cov = s_acc[6]; wp.sum_qc = s_acc[7]; wp.sum_q = s_acc[8];
+        wp.n_inner = (uint32_t)s_acc[9];
+        wp.max_raw = maxraw;
+        a.winpart[w] = wp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_finalize: one workgroup.  Run starts per window = inner boundaries + the seam with the
+// previous window; exclusive scan -> win_off.  Reduces window and read partials to the summary.
+// ---------------------------------------------------------------------------------------------
+constexpr int kFinBlock = 1024;
+
+__global__ __launch_bounds__(kFinBlock) void k_finalize(const WinPartial *__restrict__ winpart,
+                                                         const PrepPartial *__restrict__ prep,
+                                                         const uint8_t *__restrict__ state, uint32_t T,
+                                                         uint32_t n_win, uint32_t extent,
+                                                         uint32_t *__restrict__ win_off,
+                                                         DevSummary *__restrict__ out)
+{
+    __shared__ uint32_t s_w[kFinBlock / 64];
+    __shared__ unsigned long long s_red[kFinBlock / 64];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t maxraw = 0;
+    for (uint32_t base = 0; base < n_win; base += kFinBlock) {
+        const uint32_t w = base + tid;
+        uint32_t c = 0;
+        if (w < n_win) {
+            const WinPartial wp = winpart[w];
+            c = wp.n_inner;
+            const uint32_t p = w * T;
+            if (p < extent) c += (w == 0) ? 1u : (state[p] != state[p - 1] ? 1u : 0u);
+            for (int i = 0; i < 6; ++i) acc[i] += wp.cnt[i];
+            acc[6] += wp.n_cov; acc[7] += wp.sum_qc; acc[8] += wp.sum_q;
+            maxraw = wp.max_raw > maxraw ? wp.max_raw : maxraw;
+        }
+        uint32_t inc = c;
+        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+        if (lane == 63) s_w[wv] = inc;
+        __syncthreads();
+        uint32_t off = s_carry + inc - c;
+        for (int i = 0; i < wv; ++i) off += s_w[i];
+        if (w < n_win) win_off[w] = off;
+        __syncthreads();
+        if (tid == kFinBlock - 1) s_carry = off + c;
+        __syncthreads();
+    }
+    // reductions
+    unsigned long long tot[11];
+    for (int i = 0; i < 9; ++i) {
+        unsigned long long v = wave_sum_u64(acc[i]);
+        if (lane == 0) s_red[wv] = v;
+        __syncthreads();
+        v = 0;
+        if (tid == 0) for (int j = 0; j < kFinBlock / 64; ++j) v += s_red[j];
+        tot[i] = v;
+        __syncthreads();
+    }
+    maxraw = wave_max_u32(maxraw);
+    if (lane == 0) s_w[wv] = maxraw;
+    __syncthreads();
+    // read partials
+    unsigned long long sl = 0, sm = 0; uint32_t me = 0, er = 0;
+    for (int i = tid; i < kPrepBlocks; i += kFinBlock) {
+        sl += prep[i].sum_reflen; sm += prep[i].sum_mapq_reflen;
+        me = prep[i].max_end > me ? prep[i].max_end : me; er |= prep[i].err;
+    }
+    sl = wave_sum_u64(sl); sm = wave_sum_u64(sm); me = wave_max_u32(me); er = wave_or_u32(er);
+    __shared__ unsigned long long s_sl[kFinBlock / 64], s_sm[kFinBlock / 64];
+    __shared__ uint32_t s_me[kFinBlock / 64], s_er[kFinBlock / 64];
+    if (lane == 0) { s_sl[wv] = sl; s_sm[wv] = sm; s_me[wv] = me; s_er[wv] = er; }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t mr = 0; sl = 0; sm = 0; me = 0; er = 0;
+        for (int j = 0; j < kFinBlock / 64; ++j) {
+            mr = s_w[j] > mr ? s_w[j] : mr;
+            sl += s_sl[j]; sm += s_sm[j]; me = s_me[j] > me ? s_me[j] : me; er |= s_er[j];
+        }
+        for (int i = 0; i < 6; ++i) out->state_counts[i] = tot[i];
+        out->n_covered_bases = tot[6];
+        out->quality_bases = tot[7];
+        out->summed_baseq = tot[8];
+        out->summed_coverage = sl;
+        out->summed_mapq = sm;
+        out->extent = extent;
+        out->max_raw_depth = mr;
+        out->n_intervals = s_carry;
+        out->max_end = me;
+        out->err = er;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_rle_write: one workgroup per window; recomputes run starts from the state bytes and writes
+// the intervals.  The thread that finds the start of run i also closes run i-1.
+// ---------------------------------------------------------------------------------------------
+template <int T>
+__global__ __launch_bounds__(kBlock) void k_rle_write(const uint8_t *__restrict__ state,
+                                                       const uint32_t *__restrict__ win_off,
+                                                       uint32_t n_win, uint32_t extent,
+                                                       Interval *__restrict__ iv, uint32_t iv_cap)
+{
+    constexpr int PER = T / kBlock;
+    __shared__ uint32_t s_w[kBlock / 64];
+    const uint32_t w = blockIdx.x;
+    if (w >= n_win) return;
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t p0 = w * (uint32_t)T + tid * PER;
+    uint8_t st[PER];
+    if (PER >= 16) {
+#pragma unroll
+        for (int i = 0; i < PER; i += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(state + p0 + i);
+            const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 16; ++j) st[i + j] = (uint8_t)(ww[j >> 2] >> (8 * (j & 3)));
+        }
+    } else {
+        const uint2 v = *reinterpret_cast<const uint2 *>(state + p0);
+        const uint32_t ww[2] = {v.x, v.y};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) st[j] = (uint8_t)(ww[j >> 2] >> (8 * (j & 3)));
+    }
+    uint32_t prev = p0 > 0 ? state[p0 - 1] : 0x100u;   // position 0 always starts a run
+    uint32_t flags = 0, c = 0;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (p0 + i < extent && st[i] != prev) { flags |= 1u << i; ++c; }
+        prev = st[i];
+    }
+    uint32_t inc = c;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wv] = inc;
+    __syncthreads();
+    uint32_t idx = win_off[w] + inc - c;
+    for (uint32_t i = 0; i < wv; ++i) idx += s_w[i];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        if (flags & (1u << i)) {
+            if (idx < iv_cap) { iv[idx].start = p0 + i; iv[idx].state = st[i]; }
+            if (idx > 0 && idx - 1 < iv_cap) iv[idx - 1].end = p0 + i;
+            ++idx;
+        }
+    }
+    // the thread that owns the last classified position closes the last run
+    if (extent > 0 && p0 <= extent - 1 && extent - 1 < p0 + PER) {
+        if (idx > 0 && idx - 1 < iv_cap) iv[idx - 1].end = extent;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// config 5: site-list pileup (src/haplogroup/caller.rs:62-152).  Thread per read; for every
+// M/=/X base whose 1-based position is a listed site, hist[site][4-bit code] += 1.
+// site_of: dense map position(0-based) -> site index or 0xFFFFFFFF, length map_len.
+// ---------------------------------------------------------------------------------------------
+struct SiteReads {
+    const int32_t  *pos;
+    const uint8_t  *mapq;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const unsigned long long *seq_off;
+    const uint8_t  *seq4;
+    uint32_t n;
+};
+
+__global__ __launch_bounds__(kBlock) void k_site_pileup(SiteReads R, uint32_t min_quality, uint32_t contig_len,
+                                                         unsigned long long ref_len,
+                                                         const uint32_t *__restrict__ sorted_pos0,
+                                                         const uint32_t *__restrict__ sorted_idx,
+                                                         uint32_t n_sites, uint32_t *__restrict__ hist)
+{
+    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < R.n; r += gridDim.x * kBlock) {
+        if ((uint32_t)R.pos[r] >= contig_len) continue;          // fetch("chr:1-len"), caller.rs:33-36
+        if ((uint32_t)R.mapq[r] < min_quality) continue;         // caller.rs:80
+        unsigned long long x = (uint32_t)R.pos[r];
+        unsigned long long y = 0;
+        const unsigned long long s0 = R.seq_off[r], slen = R.seq_off[r + 1] - s0;
+        for (uint32_t k = R.cigar_off[r]; k < R.cigar_off[r + 1]; ++k) {
+            const uint32_t c = R.cigar[k], op = c & 15u, l = c >> 4;
+            if (op_match(op)) {
+                // sites with 0-based position in [x, x+l): binary search the first one
+                uint32_t lo = 0, hi = n_sites;
+                while (lo < hi) { uint32_t m = lo + ((hi - lo) >> 1); if (sorted_pos0[m] < x) lo = m + 1; else hi = m; }
+                for (; lo < n_sites && sorted_pos0[lo] < x + l; ++lo) {
+                    const unsigned long long p = sorted_pos0[lo];
+                    const unsigned long long qi = y + (p - x);
+                    if (qi < slen && p < ref_len) {               // caller.rs:105,110-113
+                        const unsigned long long bi = s0 + qi;
+                        const uint32_t byte = R.seq4[bi >> 1];
+                        const uint32_t code = (bi & 1ull) ? (byte & 15u) : (byte >> 4);
+                        atomicAdd(&hist[(unsigned long long)sorted_idx[lo] * 16ull + code], 1u);
+                    }
+                }
+                x += l; y += l;
+            } else if (op_del(op)) {
+                x += l;
+            } else if (op_ins(op)) {
+                y += l;
+            }
+        }
+    }
+}
+
+} // namespace clk

@@ -1,0 +1,179 @@
+/*
+ * callable_loci.h -- C ABI of the MI355X (gfx950) callable-loci engine.
+ *
+ * This is the drop-in boundary for the per-contig hot path of DecodingUsTools' `coverage`
+ * subcommand.  The reference has no FFI here: the seam is the Rust function
+ *     callable_loci::process_single_contig            (src/callable_loci/mod.rs:44-52)
+ * called by process_single_contig_api                 (src/api/coverage.rs:238-252).
+ * Everything that function computes per reference position -- the htslib pileup columns
+ * (mod.rs:65-71), process_position (mod.rs:17-42), CallableProfiler::process_position /
+ * process_state (profilers/callable_profiler.rs:89-155) and ContigProfiler::process_position
+ * (profilers/contig_profiler.rs:47-83) -- is replaced by the calls below.  What stays on the
+ * caller's side (host code, above this ABI): BAM/FASTA decoding, the FUNMAP / maxcnt read
+ * admission rule, the unique-read-name count, the BED text writer with its duplicate-line
+ * behaviour (callable_profiler.rs:39-66) and the f64 summary derivation (report.rs:15-134).
+ *
+ * Plain C types only; no exceptions cross the boundary.  Every function returns CL_OK (0) or a
+ * negative cl_status; cl_last_error() returns the message of the last failure on that context.
+ * A context is bound to one HIP device and is NOT thread-safe: one host thread drives one
+ * context (the reference is single-threaded, src/main.rs:63-67).  There is no CPU fallback: if
+ * no HIP device is usable cl_create() fails.
+ */
+#ifndef CALLABLE_LOCI_H
+#define CALLABLE_LOCI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CL_ABI_VERSION 1
+
+typedef enum cl_status {
+    CL_OK = 0,
+    CL_ERR_INVALID = -1,      /* bad argument / call out of sequence                        */
+    CL_ERR_DEVICE = -2,       /* HIP runtime error (message has the hipError string)        */
+    CL_ERR_UNSORTED = -3,     /* reads not coordinate sorted (htslib: "unsorted input")     */
+    CL_ERR_CIGAR = -4,        /* malformed CIGAR (the cases htslib asserts on)              */
+    CL_ERR_NOMEM = -5,
+    CL_ERR_RANGE = -6         /* coordinate beyond what the engine addresses (2^32-1)       */
+} cl_status;
+
+/* CallableOptions, src/callable_loci/options.rs:2-9 (CLI defaults src/cli.rs:34-60:
+ * 4, 500, 10, 20, 10, 1, 0.1).  selected_contigs stays with the caller. */
+typedef struct cl_options {
+    uint32_t min_depth;
+    uint32_t max_depth;
+    uint8_t  min_mapping_quality;
+    uint8_t  min_base_quality;
+    uint32_t min_depth_for_low_mapq;
+    uint8_t  max_low_mapq;
+    double   max_low_mapq_fraction;
+} cl_options;
+
+/* CalledState discriminants, src/callable_loci/types.rs:36-43 */
+enum {
+    CL_REF_N = 0, CL_CALLABLE = 1, CL_NO_COVERAGE = 2, CL_LOW_COVERAGE = 3,
+    CL_EXCESSIVE_COVERAGE = 4, CL_POOR_MAPPING_QUALITY = 5
+};
+
+/* One tile of ACCEPTED reads of the current contig, structure-of-arrays, coordinate sorted
+ * (tiles are pushed in order; the first read of a tile must not start before the last read of
+ * the previous one).  "Accepted" = what htslib's bam_plp_push keeps: the caller has dropped
+ * BAM_FUNMAP reads and applied the maxcnt rule (the host library's dut_admit_reads does both).
+ * Fields are the ones the path consumes (mod.rs:22-37, contig_profiler.rs:54-76):
+ *   pos        0-based leftmost reference coordinate (record.pos())
+ *   mapq       record.mapq()
+ *   cigar      BAM encoding len<<4|op, op codes M0 I1 D2 N3 S4 H5 P6 =7 X8
+ *   qual       record.qual(): raw Phred bytes, l_seq per read, 0xFF when absent
+ * The caller owns the buffers; they are copied before the call returns. */
+typedef struct cl_read_tile {
+    uint64_t        n_reads;
+    const int32_t  *pos;        /* n_reads                       */
+    const uint8_t  *mapq;       /* n_reads                       */
+    const uint32_t *cigar_off;  /* n_reads + 1, cigar_off[0] may be non-zero (tile-relative base) */
+    const uint32_t *cigar;      /* indexed by cigar_off          */
+    const uint64_t *qual_off;   /* n_reads + 1                   */
+    const uint8_t  *qual;       /* indexed by qual_off           */
+} cl_read_tile;
+
+/* What the caller reads back per contig (report.rs:40-86):
+ *   state_counts      CallableProfiler::get_contig_counts, callable_profiler.rs:158-160
+ *   the next five     ContigProfiler fields, contig_profiler.rs:11-15
+ *   extent            number of positions classified: max(contig_len, largest read end)
+ *                     (a read overhanging the contig end makes the reference walk past it)
+ *   max_raw_depth     largest pileup column
+ * n_reads (distinct read names) is a host-side count and not part of this struct. */
+typedef struct cl_contig_summary {
+    uint64_t state_counts[6];
+    uint64_t n_covered_bases;
+    uint64_t summed_coverage;
+    uint64_t summed_baseq;
+    uint64_t summed_mapq;
+    uint64_t quality_bases;
+    uint64_t extent;
+    uint64_t max_raw_depth;
+    uint64_t n_intervals;
+} cl_contig_summary;
+
+/* One run of equal state: [start, end) 0-based half open, exactly one BED line of
+ * callable_profiler.rs:42-46 */
+typedef struct cl_interval {
+    uint32_t start;
+    uint32_t end;
+    uint32_t state;
+} cl_interval;
+
+typedef struct cl_ctx cl_ctx;
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+int  cl_abi_version(void);
+int  cl_device_count(void);
+/* device_id: HIP ordinal.  stream: an existing hipStream_t to enqueue on (e.g. the caller's
+ * current stream), or NULL to let the context create its own. */
+cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx **out);
+void cl_destroy(cl_ctx *ctx);
+const char *cl_last_error(const cl_ctx *ctx);
+
+/* ---- per contig: the replacement of process_single_contig ------------------------------- */
+/* Starts a contig.  ref_bases: the contig_len FASTA bytes, case preserved (mod.rs:79-80: a
+ * missing base reads as 'N'); ref_len < contig_len is allowed, the rest is 'N'. */
+cl_status cl_contig_begin(cl_ctx *ctx, int32_t tid, uint32_t contig_len,
+                          const uint8_t *ref_bases, uint64_t ref_len);
+cl_status cl_push_reads(cl_ctx *ctx, const cl_read_tile *tile);
+/* upload + run + collect in one call.  *intervals points at context-owned memory, valid until
+ * the next cl_contig_begin / cl_destroy. */
+cl_status cl_contig_finish(cl_ctx *ctx, cl_contig_summary *out,
+                           const cl_interval **intervals, size_t *n_intervals);
+
+/* ---- the same, split so that a caller can keep a contig resident in HBM and re-run it ---- */
+cl_status cl_contig_upload(cl_ctx *ctx);      /* H2D of everything pushed; synchronous     */
+cl_status cl_contig_run(cl_ctx *ctx);         /* enqueue all kernels on the stream; async  */
+cl_status cl_contig_collect(cl_ctx *ctx, cl_contig_summary *out,
+                            const cl_interval **intervals, size_t *n_intervals);
+cl_status cl_sync(cl_ctx *ctx);
+/* device pointer + byte size of the resident per-contig summary record (cl_contig_summary
+ * layout, valid after cl_contig_run completes) -- for gathering summaries across GPUs with a
+ * collective without a host round trip */
+cl_status cl_device_summary(cl_ctx *ctx, void **dev_ptr, size_t *bytes);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+enum { CL_K_PREP = 0, CL_K_BOUNDS = 1, CL_K_PILEUP = 2, CL_K_RLE = 3, CL_K_COUNT = 4 };
+/* When on, every cl_contig_run brackets each kernel group with hipEvents on the stream. */
+cl_status cl_set_profiling(cl_ctx *ctx, int on);
+/* Accumulated milliseconds per kernel group and number of runs since the last reset. */
+cl_status cl_get_kernel_ms(cl_ctx *ctx, double ms[CL_K_COUNT], uint64_t *n_runs);
+cl_status cl_reset_kernel_ms(cl_ctx *ctx);
+/* Bytes of the resident inputs the pileup kernel must read at least once and of the state
+ * array it writes (the algorithmic traffic of one cl_contig_run). */
+cl_status cl_contig_bytes(cl_ctx *ctx, uint64_t *input_bytes, uint64_t *output_bytes);
+
+/* ---- test hooks ------------------------------------------------------------------------- */
+/* Re-runs the resident contig with per-position dumps: raw_depth, qc_depth, low_mapq_count
+ * (mod.rs:17-42) and state, each `cap` entries (cap >= extent), host buffers, any may be NULL. */
+cl_status cl_debug_depths(cl_ctx *ctx, uint32_t *raw, uint32_t *qc, uint32_t *low,
+                          uint8_t *state, uint64_t cap);
+
+/* ---- config 5: site-list pileup (haplogroup::caller::process_region,
+ *      src/haplogroup/caller.rs:62-152) ---------------------------------------------------- */
+typedef struct cl_site_tile {
+    uint64_t        n_reads;    /* ALL fetched records of the contig, no flag filter (:75-80) */
+    const int32_t  *pos;
+    const uint8_t  *mapq;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const uint64_t *seq_off;    /* n_reads + 1, in BASES                                    */
+    const uint8_t  *seq4;       /* BAM 4-bit packed bases, high nibble first                */
+} cl_site_tile;
+/* hist[n_sites*16]: per site (1-based vcf_pos, caller.rs:94) the number of reads with
+ * mapq >= min_quality showing each 4-bit base code at an M/=/X position. */
+cl_status cl_site_pileup(cl_ctx *ctx, uint8_t min_quality, uint32_t contig_len,
+                         uint64_t ref_len, const cl_site_tile *tile,
+                         const uint32_t *sites, size_t n_sites, uint32_t *hist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CALLABLE_LOCI_H */

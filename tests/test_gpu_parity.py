@@ -1,0 +1,244 @@
+"""GPU parity tests (-m gpu): the HIP engine, called through the C ABI, against the CPU oracle on
+the same inputs.  Integer / byte work: everything must be bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from helpers import contig_inputs, load_kats, make_options, oracle_run
+from decodingustools_amd import (CallableOptions, CallableProfiler, ContigProfiler, Engine, admit_reads,
+                                 process_single_contig, synth)
+from decodingustools_amd.records import ContigRecords
+
+pytestmark = pytest.mark.gpu
+KATS = load_kats()
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _opts(d):
+    o = make_options(d)
+    return CallableOptions(o.min_depth, o.max_depth, o.min_mapping_quality, o.min_base_quality,
+                           o.min_depth_for_low_mapq, o.max_low_mapq, o.max_low_mapq_fraction)
+
+
+def engine_run(contigs, opt, bed_path, dump=False):
+    """The product path: process_single_contig per contig in tid order on one Engine."""
+    res = {}
+    with Engine(opt, 0) as eng:
+        counter = CallableProfiler(bed_path)
+        for name, tid, length, ref, rec in contigs:
+            st = ContigProfiler(name, length)
+            process_single_contig(eng, counter, st, opt, tid, rec, ref)
+            entry = dict(stats=st)
+            if dump:
+                # the resident contig is the accepted subset; dump its per-position counters
+                extent = eng.contig_collect().summary.extent
+                entry["dumps"] = eng.debug_depths(int(extent)) + (int(extent),)
+            res[name] = entry
+        for name in res:
+            res[name]["state_counts"] = counter.get_contig_counts(name)
+        counter.close()
+    return res, open(bed_path).read()
+
+
+def _diag(tag, name, exp, got):
+    os.makedirs(OUT, exist_ok=True)
+    bad = np.flatnonzero(exp != got)
+    with open(os.path.join(OUT, f"mismatch_{tag}.json"), "a") as f:
+        json.dump(dict(array=name, n_bad=int(bad.shape[0]), first=bad[:40].tolist(),
+                       exp=exp[bad[:40]].tolist(), got=got[bad[:40]].tolist()), f)
+        f.write("\n")
+
+
+def compare(contigs, opt_dict, tmp_path, tag, dump=True):
+    oo = make_options(opt_dict)
+    opt = _opts(opt_dict)
+    o_res, o_bed = oracle_run(contigs, oo, str(tmp_path / "o.bed"), dump=dump)
+    g_res, g_bed = engine_run(contigs, opt, str(tmp_path / "g.bed"), dump=dump)
+    ok = True
+    for name, _, length, _, _ in contigs:
+        so, sg = o_res[name]["stats"], g_res[name]["stats"]
+        if dump:
+            ro, qo, lo, sto, eo = o_res[name]["dumps"]
+            rg, qg, lg, stg, eg = g_res[name]["dumps"]
+            assert eg == max(eo, length), (eg, eo)
+            for nm, a, b in (("raw", ro, rg[:eo]), ("low", lo, lg[:eo]), ("qc", qo, qg[:eo]), ("state", sto, stg[:eo])):
+                if not np.array_equal(a, b):
+                    _diag(tag, f"{name}.{nm}", a, b)
+                    ok = False
+        for k in ("n_covered_bases", "summed_coverage", "summed_baseq", "summed_mapq", "quality_bases", "n_reads"):
+            assert so[k] == getattr(sg, k), (name, k, so[k], getattr(sg, k))
+        assert o_res[name]["state_counts"] == g_res[name]["state_counts"], name
+        for k, v in so["derived"].items():
+            assert sg.derived()[k] == v, (name, k)
+    assert ok, f"per-position mismatch, see gpurun_out/mismatch_{tag}.json"
+    if g_bed != o_bed:
+        os.makedirs(OUT, exist_ok=True)
+        open(os.path.join(OUT, f"bed_{tag}_oracle.bed"), "w").write(o_bed)
+        open(os.path.join(OUT, f"bed_{tag}_gpu.bed"), "w").write(g_bed)
+    assert g_bed == o_bed
+    return o_res, g_res
+
+
+@pytest.mark.parametrize("case", KATS["cases"], ids=[c["name"] for c in KATS["cases"]])
+def test_kats_on_gpu(case, tmp_path):
+    opt = {**KATS["default_options"], **case.get("options", {})}
+    contigs = []
+    for i, c in enumerate(case["contigs"]):
+        rec, ref = contig_inputs(c)
+        contigs.append((c["name"], c.get("tid", i), c["len"], ref, rec))
+    _, g = compare(contigs, opt, tmp_path, "kat")
+    assert open(tmp_path / "g.bed").read() == case["bed"]
+
+
+ADV_OPTS = [
+    dict(min_depth=2, min_depth_for_low_mapq=3),
+    dict(),                                                            # CLI defaults
+    dict(min_depth=1, max_depth=8, min_depth_for_low_mapq=2, max_low_mapq=2, max_low_mapq_fraction=0.25),
+    dict(min_base_quality=0, min_mapping_quality=0, max_depth=0),
+    dict(min_base_quality=128, min_depth=1),
+    dict(min_base_quality=200, min_depth=1, max_low_mapq_fraction=0.0),
+    dict(min_base_quality=255, min_mapping_quality=255, max_low_mapq=255, max_low_mapq_fraction=0.999),
+    dict(max_depth=3, min_depth=2, max_low_mapq_fraction=1.0),
+]
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_adversarial_contigs(seed, tmp_path):
+    L = [777, 2048, 2049, 4096, 5000, 6143, 1, 300][seed]
+    n = [200, 500, 500, 900, 1200, 700, 5, 2000][seed]
+    rec = synth.adversarial_contig(L, n, 1000 + seed, max_len=min(300, max(2, L)), deep=(seed in (3, 7)),
+                                   overhang=(seed in (1, 4, 6)))
+    ref = synth.make_reference(L, 50 + seed, lowercase=(seed % 2 == 0))
+    compare([("chrA", seed % 3, L, ref, rec)], ADV_OPTS[seed], tmp_path, f"adv{seed}")
+
+
+def test_multi_contig_bed_with_duplicate_lines(tmp_path):
+    contigs = []
+    for t in range(5):
+        L = [3000, 1, 2500, 4097, 100][t]
+        rec = synth.adversarial_contig(L, [300, 0, 10, 800, 40][t], 200 + t, max_len=min(200, max(2, L)))
+        ref = synth.make_reference(L, 70 + t)
+        if t == 2:
+            ref = ref[: L - 100]                 # FASTA shorter than the header length: tail reads 'N'
+        contigs.append((["chr1", "chr2", "chr3", "chrX", "chrM"][t], t, L, ref, rec))
+    compare(contigs, dict(min_depth=2, min_depth_for_low_mapq=3), tmp_path, "multi")
+    # -L style subset: only tids 1 and 3
+    compare([contigs[1], contigs[3]], dict(), tmp_path, "subset")
+
+
+def test_empty_inputs(tmp_path):
+    compare([("e1", 0, 0, None, ContigRecords.empty()), ("e2", 1, 5000, None, ContigRecords.empty()),
+             ("e3", 2, 4096, synth.make_reference(4096, 3), ContigRecords.empty())], dict(), tmp_path, "empty")
+
+
+def test_short_reads_2mb_30x(tmp_path):
+    L = 2_000_000
+    rec = synth.short_read_contig(L, 30, synth.seed_for(2, 20))
+    ref = synth.make_reference(L, synth.seed_for(2, 20))
+    compare([("chr21", 20, L, ref, rec)], dict(), tmp_path, "short2mb")
+
+
+def test_long_reads_indel_rich(tmp_path):
+    L = 300_000
+    rec = synth.long_read_contig(L, 50, synth.seed_for(3, 23))
+    ref = synth.make_reference(L, synth.seed_for(3, 23))
+    compare([("chrY", 23, L, ref, rec)], dict(), tmp_path, "long")
+
+
+def test_deep_pileup_uses_32bit_counters(tmp_path):
+    # 3000 reads stacked over a 400 bp region: columns far above 255 and above --max-depth
+    L = 6000
+    rng = np.random.default_rng(4)
+    reads = [(int(p), "120M", int(rng.choice([0, 60, 60, 60])), int(rng.choice([10, 30, 40])), 0, f"d{i}")
+             for i, p in enumerate(np.sort(rng.integers(2000, 2400, size=3000)))]
+    rec = ContigRecords.from_reads(reads)
+    ref = synth.make_reference(L, 8)
+    o, g = compare([("amp", 0, L, ref, rec)], dict(max_depth=100000, min_depth_for_low_mapq=10), tmp_path, "deep")
+    assert o["amp"]["dumps"][0].max() > 600
+    # with the CLI's cap (500) the admission rule thins the pile
+    o2, _ = compare([("amp", 0, L, ref, rec)], dict(), tmp_path, "deepcap")
+    assert o2["amp"]["state_counts"][4] >= 0
+
+
+def test_resident_rerun_is_idempotent_and_split_api_agrees(tmp_path):
+    L = 300_000
+    rec = synth.short_read_contig(L, 30, 77)
+    ref = synth.make_reference(L, 77)
+    opt = CallableOptions()
+    acc, _ = admit_reads(opt, 0, L, rec)
+    idx = np.flatnonzero(acc)
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref)
+        # push in three tiles with tile-relative offsets
+        cuts = [0, len(idx) // 3, 2 * len(idx) // 3, len(idx)]
+        for a, b in zip(cuts[:-1], cuts[1:]):
+            sel = idx[a:b]
+            lens_c = (rec.cigar_off[sel + 1] - rec.cigar_off[sel]).astype(np.int64)
+            lens_q = (rec.qual_off[sel + 1] - rec.qual_off[sel]).astype(np.int64)
+            cig = np.concatenate([rec.cigar[rec.cigar_off[i]:rec.cigar_off[i + 1]] for i in sel])
+            q = np.concatenate([rec.qual[rec.qual_off[i]:rec.qual_off[i + 1]] for i in sel])
+            coff = (np.concatenate([[0], np.cumsum(lens_c)]) + 7).astype(np.uint32)   # non-zero base
+            cig = np.concatenate([np.zeros(7, np.uint32), cig])
+            qoff = (np.concatenate([[0], np.cumsum(lens_q)]) + 5).astype(np.uint64)
+            q = np.concatenate([np.zeros(5, np.uint8), q])
+            eng.push_reads(rec.pos[sel], rec.mapq[sel], coff, cig, qoff, q)
+        eng.contig_upload()
+        eng.contig_run()
+        r1 = eng.contig_collect()
+        eng.contig_run(); eng.contig_run()
+        r2 = eng.contig_collect()
+    assert r1.as_dict() == r2.as_dict()
+    assert np.array_equal(r1.intervals, r2.intervals)
+    # same answer as the one-call path + oracle
+    o_res, o_bed = oracle_run([("c", 0, L, ref, rec)], make_options({}), str(tmp_path / "o.bed"))
+    assert r1.state_counts == o_res["c"]["state_counts"]
+    iv = r1.intervals
+    assert iv[0, 0] == 0 and iv[-1, 1] == L and np.array_equal(iv[1:, 0], iv[:-1, 1])
+    assert np.all(iv[1:, 2] != iv[:-1, 2])
+    names = np.array(oracle.STATE_NAMES)
+    bed = "".join(f"c\t{s}\t{e}\t{names[k]}\n" for s, e, k in iv.tolist())
+    assert bed == o_bed
+
+
+def test_engine_errors_are_reported():
+    from decodingustools_amd import EngineError
+    opt = CallableOptions()
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, 100, None)
+        with pytest.raises(EngineError):                     # unsorted
+            eng.push_reads([10, 5], [60, 60], [0, 1, 2], [5 << 4, 5 << 4], [0, 5, 10], np.full(10, 30, np.uint8))
+        eng.contig_begin(0, 100, None)
+        with pytest.raises(EngineError):                     # position outside the contig
+            eng.push_reads([100], [60], [0, 1], [5 << 4], [0, 5], np.full(5, 30, np.uint8))
+        eng.contig_begin(0, 100, None)
+        eng.push_reads([10], [60], [0, 1], [(5 << 4) | 2], [0, 0], np.zeros(0, np.uint8))   # a lone "5D"
+        with pytest.raises(EngineError):
+            eng.contig_finish()
+        with pytest.raises(EngineError):                     # call out of sequence
+            Engine(opt, 0).contig_run()
+
+
+@pytest.mark.parametrize("case", KATS["site_cases"], ids=[c["name"] for c in KATS["site_cases"]])
+def test_site_kats_on_gpu(case):
+    rec = ContigRecords.from_reads([tuple(r) for r in case["reads"]])
+    ref = np.frombuffer(case["ref"].encode(), dtype=np.uint8).copy()
+    exp = oracle.site_pileup(case["min_depth"], case["min_quality"], case["contig_len"], ref, rec, case["sites"])
+    with Engine(CallableOptions(), 0) as eng:
+        hist = eng.site_pileup(case["min_quality"], case["contig_len"], ref.shape[0], rec, case["sites"])
+    assert np.array_equal(hist, exp["hist"])
+
+
+def test_site_pileup_random_vs_oracle():
+    L = 400_000
+    ref = synth.make_reference(L, 5)
+    rec = synth.short_read_contig(L, 40, synth.seed_for(5, 23), with_seq=True, ref=ref)
+    rng = np.random.default_rng(9)
+    sites = rng.choice(np.arange(1, L + 50), size=5000, replace=False).astype(np.uint32)
+    exp = oracle.site_pileup(10, 20, L, ref, rec, sites)
+    with Engine(CallableOptions(), 0) as eng:
+        hist = eng.site_pileup(20, L, ref.shape[0], rec, sites)
+    assert np.array_equal(hist, exp["hist"])
+    assert exp["called"].sum() > 1000

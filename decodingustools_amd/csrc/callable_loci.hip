@@ -20,8 +20,8 @@ using namespace clk;
 
 namespace {
 
-// window size (reference positions per workgroup).  2048 -> 32 KiB of LDS per workgroup,
-// five workgroups (20 waves) per CU.
+// window size (reference positions per workgroup).  2048 -> 18.9 KiB of LDS per workgroup,
+// eight workgroups (32 waves) per CU.
 #ifndef CL_WINDOW
 #define CL_WINDOW 2048
 #endif
@@ -78,6 +78,8 @@ struct cl_ctx {
     DevBuf<uint8_t> d_state;
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
+    DevBuf<FinPartial> d_fin;
+    DevBuf<uint32_t> d_blk_off;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
     DevBuf<Interval> d_iv;
@@ -93,8 +95,10 @@ struct cl_ctx {
 
     // profiling
     bool profiling = false;
-    hipEvent_t ev[CL_K_COUNT + 1] = {};
-    bool ev_made = false, ev_pending = false;
+    static constexpr int kEvSets = 64;       // runs that can be in flight before events are read back
+    hipEvent_t ev[kEvSets][CL_K_COUNT + 1] = {};
+    bool ev_made = false;
+    int ev_pending = 0;
     double ms[CL_K_COUNT] = {};
     uint64_t n_runs = 0;
 };
@@ -145,22 +149,24 @@ void build_lut(double frac, std::vector<uint32_t> &lut)
 cl_status ensure_events(cl_ctx *c)
 {
     if (c->ev_made) return CL_OK;
-    for (int i = 0; i <= CL_K_COUNT; ++i) HIP_TRY(c, hipEventCreate(&c->ev[i]));
+    for (int s = 0; s < cl_ctx::kEvSets; ++s)
+        for (int i = 0; i <= CL_K_COUNT; ++i) HIP_TRY(c, hipEventCreate(&c->ev[s][i]));
     c->ev_made = true;
     return CL_OK;
 }
 
 cl_status harvest_events(cl_ctx *c)
 {
-    if (!c->ev_pending) return CL_OK;
-    HIP_TRY(c, hipEventSynchronize(c->ev[CL_K_COUNT]));
-    for (int i = 0; i < CL_K_COUNT; ++i) {
-        float t = 0.f;
-        HIP_TRY(c, hipEventElapsedTime(&t, c->ev[i], c->ev[i + 1]));
-        c->ms[i] += t;
+    for (int s = 0; s < c->ev_pending; ++s) {
+        HIP_TRY(c, hipEventSynchronize(c->ev[s][CL_K_COUNT]));
+        for (int i = 0; i < CL_K_COUNT; ++i) {
+            float t = 0.f;
+            HIP_TRY(c, hipEventElapsedTime(&t, c->ev[s][i], c->ev[s][i + 1]));
+            c->ms[i] += t;
+        }
+        c->n_runs += 1;
     }
-    c->n_runs += 1;
-    c->ev_pending = false;
+    c->ev_pending = 0;
     return CL_OK;
 }
 
@@ -174,6 +180,8 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_win_hi.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_off.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_fin.reserve(c->n_win / kFinBlock + 2));
+    HIP_TRY(c, c->d_blk_off.reserve(c->n_win / kFinBlock + 2));
     HIP_TRY(c, c->d_state.reserve(padded + 16));
     // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80)
     if (c->d_ref.cap < padded + 16 || c->ref_len_dev == UINT64_MAX) {
@@ -199,39 +207,44 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (prof) {
         cl_status s = ensure_events(c);
         if (s != CL_OK) return s;
-        s = harvest_events(c);
+        if (c->ev_pending == cl_ctx::kEvSets) s = harvest_events(c);   // ring full: read back (host sync)
         if (s != CL_OK) return s;
     }
+    hipEvent_t *ev = c->ev[c->ev_pending < cl_ctx::kEvSets ? c->ev_pending : 0];
     Reads R;
     R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
     R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
 
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
                        c->d_end.p, c->d_prep.p);
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     if (c->n_win) {
         hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0,
                            c->stream, R, c->d_prep.p, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p);
     }
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (prof) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     PileupArgs a;
     a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
     if (debug) launch_pileup<true>(c, a); else launch_pileup<false>(c, a);
-    if (prof) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
-    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_prep.p,
-                       c->d_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_summary.p);
+    if (prof) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
+    const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
+    if (n_fin)
+        hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_state.p,
+                           kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
+    hipLaunchKernelGGL(k_fin_summary, dim3(1), dim3(kBlock), 0, c->stream, c->d_fin.p, n_fin, c->d_prep.p,
+                       (uint32_t)kPrepBlocks, c->extent, c->d_blk_off.p, c->d_summary.p);
     if (c->n_win) {
         hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream,
-                           c->d_state.p, c->d_win_off.p, c->n_win, c->extent, c->d_iv.p,
+                           c->d_state.p, c->d_win_off.p, c->d_blk_off.p, c->n_win, c->extent, c->d_iv.p,
                            (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
     }
     if (prof) {
-        HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
-        c->ev_pending = true;
+        HIP_TRY(c, hipEventRecord(ev[4], c->stream));
+        c->ev_pending += 1;
     }
     HIP_TRY(c, hipGetLastError());
     return CL_OK;
@@ -291,8 +304,10 @@ void cl_destroy(cl_ctx *c)
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
     c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release();
-    if (c->ev_made) for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[i]);
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release();
+    if (c->ev_made)
+        for (int s = 0; s < cl_ctx::kEvSets; ++s)
+            for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -452,7 +467,7 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
             if (c->n_win)
                 hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream, c->d_state.p,
-                                   c->d_win_off.p, c->n_win, c->extent, c->d_iv.p,
+                                   c->d_win_off.p, c->d_blk_off.p, c->n_win, c->extent, c->d_iv.p,
                                    (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
             HIP_TRY(c, hipGetLastError());
         }

@@ -8,7 +8,8 @@
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
 //                    (callable_profiler.rs:100-116) and written as one state byte per position
-//   k_finalize       run-boundary counts -> exclusive offsets; window / read partials -> summary
+//   k_fin_windows /  run-boundary counts -> exclusive offsets (two-level scan); window / read
+//   k_fin_summary    partials -> contig summary
 //   k_rle_write      state bytes -> (start,end,state) intervals (callable_profiler.rs:122-155)
 //
 // Integer / byte work throughout: HBM-bound, no MFMA.  Wave = 64 lanes.
@@ -19,8 +20,7 @@
 namespace clk {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
-constexpr int kPrepBlocks = 1024;    // grid of k_read_prep (grid-stride)
-constexpr int kGroup = 16;           // lanes that share one read in the quality pass
+constexpr int kPrepBlocks = 4096;    // grid of k_read_prep (grid-stride)
 constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
 constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
 
@@ -234,39 +234,53 @@ struct PileupArgs {
     uint32_t *dbg_raw, *dbg_qc, *dbg_low;
 };
 
-// classify one position: callable_profiler.rs:100-116
-__device__ __forceinline__ uint32_t classify(uint32_t refb, uint32_t raw, uint32_t qc, uint32_t low,
-                                             const Opts &o, const uint32_t *__restrict__ lut)
+// One 16-position unit of one M/=/X segment: quality bytes v (position ps+i <-> byte i), valid
+// positions pm (bit i).  Adds the pass bits to the packed counters and returns the sum of the
+// passing qualities (contig_profiler.rs:68-70).
+//   8-bit mode : byte counter per position, 4 positions per LDS word; the word index is
+//                XOR-swizzled (word 4u+jj lives at 4u+(jj^((u>>3)&3))) so that the lanes of a
+//                wave, which all hold the same jj, spread over all 32 banks
+//   32-bit mode: one word per position (windows with a column deeper than 255)
+__device__ __forceinline__ uint32_t apply_unit(const Q16 &v, uint32_t pm, uint32_t u, bool mode8,
+                                               uint32_t *__restrict__ s_qc, const Opts &o)
 {
-    if (refb == 'N' || refb == 'n') return 0u;                  // REF_N
-    if (raw == 0) return 2u;                                    // NO_COVERAGE
-    bool is_low = false;
-    if (raw >= o.min_depth_for_low_mapq) {
-        if (raw < kLutSize) is_low = low >= lut[raw];
-        else is_low = ((double)low / (double)raw) > o.max_low_mapq_fraction;   // IEEE f64 divide
+    uint32_t sq = 0;
+    const uint32_t rot = (u >> 3) & 3u;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t xw = v.w[jj];
+        const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;
+        const uint32_t inc = (qual_ge(xw, o) >> 7) & vm;
+        if (inc) {
+            if (mode8) {
+                atomicAdd(&s_qc[(u << 2) + ((uint32_t)jj ^ rot)], inc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if ((inc >> (8 * i)) & 1u) atomicAdd(&s_qc[(u << 4) + 4 * jj + i], 1u);
+            }
+            sq = __builtin_amdgcn_sad_u8(xw & ((inc << 8) - inc), 0u, sq);
+        }
     }
-    if (is_low) return 5u;                                      // POOR_MAPPING_QUALITY
-    if (qc < o.min_depth) return 3u;                            // LOW_COVERAGE
-    if (o.max_depth > 0 && qc > o.max_depth) return 4u;         // EXCESSIVE_COVERAGE
-    return 1u;                                                  // CALLABLE
+    return sq;
 }
 
-constexpr int kSegPerLane = 4;                       // segments a lane may emit per round
-constexpr int kSegCap = kBlock * kSegPerLane;        // LDS segment list capacity
-constexpr int kQuads = kBlock / 4;
-
 template <int T, bool DEBUG>
-__global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
+__global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in scan / classify
-    static_assert(PER == 8 || PER == 16 || PER == 32, "T must be 2048, 4096 or 8192");
-    __shared__ __attribute__((aligned(16))) uint32_t s_raw[T];
-    __shared__ __attribute__((aligned(16))) uint32_t s_low[T];
-    __shared__ __attribute__((aligned(16))) uint32_t s_qc[T];   // bytes [0,T) in 8-bit mode
-    __shared__ __attribute__((aligned(8))) uint2 s_seg[kSegCap];
+    static_assert(PER == 8 || PER == 16, "T must be 2048 or 4096");
+    constexpr int kSegCap = T / 2;                  // uint2 segments that fit in s_b
+    constexpr int kSegPerLane = kSegCap / kBlock;   // segments a lane may emit per round
+    constexpr int kQuads = kBlock / 4;
+    // LDS: 2 x T words + T flag bytes.  s_a: raw depth (phases 1-2), then the qc counters
+    // (phase 3).  s_b: low-mapq depth (phases 1-2), then the segment list (phase 3).
+    __shared__ __attribute__((aligned(16))) uint32_t s_a[T];
+    __shared__ __attribute__((aligned(16))) uint32_t s_b[T];
+    __shared__ __attribute__((aligned(16))) uint8_t s_flag[T];   // bit0: raw>0, bit1: low-mapq rule fired
     __shared__ uint32_t s_nseg[2];
     __shared__ uint32_t s_wraw[kBlock / 64], s_wlow[kBlock / 64], s_wmax[kBlock / 64];
-    __shared__ uint32_t s_last[kBlock];
+    __shared__ uint8_t s_last[kBlock];
     __shared__ unsigned long long s_acc[10];        // cnt[6], n_cov, sum_qc, sum_q, n_inner
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
@@ -276,13 +290,13 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t W = w * (uint32_t)T;
     const uint32_t Wend = W + (uint32_t)T;
+    const int lane = tid & 63, wv = tid >> 6;
 
-    // ---- phase 0: clear the window's counters ----
+    // ---- phase 0: clear ----
     {
-        uint4 z = make_uint4(0, 0, 0, 0);
-        uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low),
-              *q4 = reinterpret_cast<uint4 *>(s_qc);
-        for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; q4[i] = z; }
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *r4 = reinterpret_cast<uint4 *>(s_a), *l4 = reinterpret_cast<uint4 *>(s_b);
+        for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; }
         if (tid < 10) s_acc[tid] = 0;
         if (tid < 2) s_nseg[tid] = 0;
     }
@@ -294,50 +308,70 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
     // (both count every read whose [pos,end) covers the position, D/N included: mod.rs:22-28)
     for (uint32_t r = lo + tid; r < hi; r += kBlock) {
         const uint32_t e = a.end[r];
-        if (e <= W) continue;
         const uint32_t b = (uint32_t)a.R.pos[r];
+        const uint32_t mq = a.R.mapq[r];
+        if (e <= W) continue;
         const uint32_t cb = b > W ? b - W : 0u;
         const uint32_t ce = e - W;
-        atomicAdd(&s_raw[cb], 1u);
-        if (ce < (uint32_t)T) atomicAdd(&s_raw[ce], 0xFFFFFFFFu);
-        if ((uint32_t)a.R.mapq[r] <= a.o.max_low_mapq) {
-            atomicAdd(&s_low[cb], 1u);
-            if (ce < (uint32_t)T) atomicAdd(&s_low[ce], 0xFFFFFFFFu);
+        atomicAdd(&s_a[cb], 1u);
+        if (ce < (uint32_t)T) atomicAdd(&s_a[ce], 0xFFFFFFFFu);
+        if (mq <= a.o.max_low_mapq) {
+            atomicAdd(&s_b[cb], 1u);
+            if (ce < (uint32_t)T) atomicAdd(&s_b[ce], 0xFFFFFFFFu);
         }
     }
     __syncthreads();
 
-    // ---- phase 2: prefix sums -> depths; block max of raw ----
+    // ---- phase 2: prefix sums -> depths; per position keep only (raw>0, low-mapq rule) ----
     uint32_t maxraw;
     {
         uint32_t vr[PER], vl[PER];
         uint32_t sr = 0, sl = 0, mx = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            sr += s_raw[tid * PER + i]; vr[i] = sr;
-            sl += s_low[tid * PER + i]; vl[i] = sl;
+            sr += s_a[tid * PER + i]; vr[i] = sr;
+            sl += s_b[tid * PER + i]; vl[i] = sl;
         }
-        // inclusive scan of thread totals across the wave
         uint32_t ir = sr, il = sl;
-        const int lane = tid & 63;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t tr = __shfl_up(ir, o, 64), tl = __shfl_up(il, o, 64);
             if (lane >= o) { ir += tr; il += tl; }
         }
-        const int wv = tid >> 6;
         if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
-        __syncthreads();
+        __syncthreads();                              // also: everyone has read s_a / s_b
         uint32_t offr = ir - sr, offl = il - sl;
         for (int i = 0; i < wv; ++i) { offr += s_wraw[i]; offl += s_wlow[i]; }
+        uint32_t fl[PER / 4];
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) fl[i] = 0;
+        uint32_t ncov = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const uint32_t x = vr[i] + offr;
-            s_raw[tid * PER + i] = x;
-            s_low[tid * PER + i] = vl[i] + offl;
-            mx = x > mx ? x : mx;
+            const uint32_t raw = vr[i] + offr, low = vl[i] + offl;
+            mx = raw > mx ? raw : mx;
+            // callable_profiler.rs:100-101
+            bool is_low = false;
+            if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
+                if (raw < kLutSize) is_low = low >= a.lut[raw];
+                else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
+            }
+            const uint32_t f = (raw > 0 ? 1u : 0u) | (is_low ? 2u : 0u);
+            fl[i >> 2] |= f << (8 * (i & 3));
+            if (W + tid * PER + i < a.extent) ncov += raw > 0 ? 1u : 0u;
+            if (DEBUG) {
+                if (a.dbg_raw) a.dbg_raw[W + tid * PER + i] = raw;
+                if (a.dbg_low) a.dbg_low[W + tid * PER + i] = low;
+            }
         }
+#pragma unroll
+        for (int i = 0; i < PER / 4; ++i) reinterpret_cast<uint32_t *>(s_flag)[tid * (PER / 4) + i] = fl[i];
+        if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
         mx = wave_max_u32(mx);
         if (lane == 0) s_wmax[wv] = mx;
+        // s_a becomes the qc counter array
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *q4 = reinterpret_cast<uint4 *>(s_a);
+        for (int i = tid; i < T / 4; i += kBlock) q4[i] = z;
         __syncthreads();
         maxraw = 0;
         for (int i = 0; i < kBlock / 64; ++i) maxraw = s_wmax[i] > maxraw ? s_wmax[i] : maxraw;
@@ -345,12 +379,14 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
     // qc_depth <= raw_depth at every position, so byte counters cannot overflow when the
     // window's largest column is <= 255; otherwise use one 32-bit counter per position.
     const bool mode8 = maxraw <= 255u;
+    uint32_t *s_qc = s_a;
+    uint2 *s_seg = reinterpret_cast<uint2 *>(s_b);
 
     // ---- phase 3: qc_depth -- M/=/X bases with base quality >= min (reads with mapq >= min) ----
     // Rounds of two steps.  A: one lane per read walks its CIGAR and appends the window-clipped
-    // M/=/X segments (at most kSegPerLane per round) to an LDS list.  B: lane quads take segments
-    // from the list; each lane handles units of 16 reference positions = one unaligned 16-byte
-    // load of quality bytes, a byte-parallel threshold test and packed LDS counter adds.
+    // M/=/X segments (at most kSegPerLane per round) to the LDS list.  B: lane quads take segments
+    // from the list; a lane handles units of 16 reference positions = one unaligned 16-byte load
+    // of quality bytes (three in flight), a byte-parallel threshold test, packed LDS counter adds.
     unsigned long long sumq = 0;
     {
         uint32_t par = 0;
@@ -360,14 +396,15 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
             bool live = false;
             uint32_t x = 0, y = 0, k = 0, k1 = 0, qlen = 0;
             unsigned long long q0 = 0;
-            if (r < hi && (uint32_t)a.R.mapq[r] >= a.o.min_mapq && a.end[r] > W) {
-                live = true;
+            if (r < hi) {
+                const uint32_t mq = a.R.mapq[r], e = a.end[r];
                 x = (uint32_t)a.R.pos[r];
                 k = a.R.cigar_off[r];
                 k1 = a.R.cigar_off[r + 1];
                 q0 = a.R.qual_off[r];
                 const unsigned long long ql64 = a.R.qual_off[r + 1] - q0;
                 qlen = ql64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ql64;
+                live = mq >= a.o.min_mapq && e > W;
             }
             for (;;) {
                 // -- A: emit segments --
@@ -407,31 +444,27 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
                     const uint2 d = s_seg[j];
                     const uint32_t srel = (d.y >> 6) & 0x1FFFu;
                     const uint32_t trel = srel + (d.y >> 19) + 1u;
-                    const long long qis = (long long)(((unsigned long long)(d.y & 63u) << 32) | d.x) - (long long)srel;
+                    const uint8_t *qp = a.R.qual + ((long long)(((unsigned long long)(d.y & 63u) << 32) | d.x) - (long long)srel);
                     const uint32_t u1 = (trel - 1u) >> 4;
-                    for (uint32_t u = (srel >> 4) + ql; u <= u1; u += 4u) {
-                        const uint32_t ps = u << 4;                       // unit start, window relative
-                        const uint32_t vs = srel > ps ? srel - ps : 0u;
-                        const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
-                        Q16 v;
-                        __builtin_memcpy(&v, a.R.qual + (qis + (long long)ps), 16);
-                        const uint32_t pm = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
+                    for (uint32_t ub = (srel >> 4) + ql; ub <= u1; ub += 12u) {
+                        // three units per lane and trip: u, u+4, u+8 (clamped; a clamped unit has an empty mask)
+                        uint32_t uu[3], pm[3];
+                        Q16 v[3];
 #pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const uint32_t xw = v.w[jj];
-                            const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;
-                            const uint32_t inc = (qual_ge(xw, a.o) >> 7) & vm;
-                            if (inc) {
-                                if (mode8) {
-                                    atomicAdd(&s_qc[(u << 2) + jj], inc);
-                                } else {
-#pragma unroll
-                                    for (int i = 0; i < 4; ++i)
-                                        if ((inc >> (8 * i)) & 1u) atomicAdd(&s_qc[(u << 4) + 4 * jj + i], 1u);
-                                }
-                                sumq += __builtin_amdgcn_sad_u8(xw & ((inc << 8) - inc), 0u, 0u);
-                            }
+                        for (int i = 0; i < 3; ++i) {
+                            const uint32_t u = ub + 4u * i;
+                            uu[i] = u <= u1 ? u : u1;
+                            __builtin_memcpy(&v[i], qp + (uu[i] << 4), 16);
                         }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) {
+                            const uint32_t ps = uu[i] << 4;
+                            const uint32_t vs = srel > ps ? srel - ps : 0u;
+                            const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                            pm[i] = (ub + 4u * i <= u1) ? (((1u << ve) - 1u) & ~((1u << vs) - 1u)) : 0u;
+                        }
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) sumq += apply_unit(v[i], pm[i], uu[i], mode8, s_qc, a.o);
                     }
                 }
                 __syncthreads();
@@ -441,36 +474,43 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
         }
     }
 
-    // ---- phase 4: classify, count, write state bytes ----
+    // ---- phase 4: classify (callable_profiler.rs:104-116), count, write state bytes ----
     {
         uint32_t st[PER];
-        unsigned long long cntp = 0;                // six 8-bit fields (PER <= 32)
-        uint32_t ncov = 0;
+        unsigned long long cntp = 0;                // six 8-bit fields (PER <= 16)
         unsigned long long sqc = 0;
         const uint32_t p0 = W + tid * PER;
         const uint8_t *refp = a.ref + p0;
+        uint32_t qcw[PER / 4];
+        if (mode8) {
+#pragma unroll
+            for (int i = 0; i < PER / 4; ++i) {
+                const uint32_t wi = tid * (PER / 4) + i;          // word 4u+jj with u = wi>>2, jj = wi&3
+                qcw[i] = s_qc[(wi & ~3u) | ((wi & 3u) ^ ((wi >> 5) & 3u))];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const uint32_t p = p0 + i;
-            const uint32_t raw = s_raw[tid * PER + i], low = s_low[tid * PER + i];
-            const uint32_t qc = mode8 ? reinterpret_cast<const uint8_t *>(s_qc)[tid * PER + i]
-                                      : s_qc[tid * PER + i];
-            if (DEBUG) {
-                if (a.dbg_raw) a.dbg_raw[p] = raw;
-                if (a.dbg_qc) a.dbg_qc[p] = qc;
-                if (a.dbg_low) a.dbg_low[p] = low;
-            }
+            const uint32_t f = s_flag[tid * PER + i];
+            const uint32_t qc = mode8 ? ((qcw[i >> 2] >> (8 * (i & 3))) & 0xFFu) : s_qc[tid * PER + i];
+            if (DEBUG) { if (a.dbg_qc) a.dbg_qc[p] = qc; }
             uint32_t s = 0xFFu;
             if (p < a.extent) {
-                s = classify(refp[i], raw, qc, low, a.o, a.lut);
+                const uint32_t rb = refp[i];
+                if (rb == 'N' || rb == 'n') s = 0u;                                  // REF_N
+                else if (!(f & 1u)) s = 2u;                                          // NO_COVERAGE
+                else if (f & 2u) s = 5u;                                             // POOR_MAPPING_QUALITY
+                else if (qc < a.o.min_depth) s = 3u;                                 // LOW_COVERAGE
+                else if (a.o.max_depth > 0 && qc > a.o.max_depth) s = 4u;            // EXCESSIVE_COVERAGE
+                else s = 1u;                                                         // CALLABLE
                 cntp += 1ull << (8u * s);
-                ncov += raw > 0 ? 1u : 0u;
                 sqc += qc;
             }
             st[i] = s;
         }
         // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
-        s_last[tid] = st[PER - 1];
+        s_last[tid] = (uint8_t)st[PER - 1];
         __syncthreads();
         uint32_t nb = 0;
         uint32_t prev = tid > 0 ? s_last[tid - 1] : st[0];
@@ -479,30 +519,24 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
             if (p0 + i < a.extent && st[i] != prev) nb += 1;
             prev = st[i];
         }
-        // state bytes, PER per thread
         if (PER == 8) {
             uint2 v;
             v.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
             v.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
             *reinterpret_cast<uint2 *>(a.state + p0) = v;
         } else {
-#pragma unroll
-            for (int i = 0; i + 15 < PER; i += 16) {
-                uint4 v;
-                v.x = st[i + 0] | (st[i + 1] << 8) | (st[i + 2] << 16) | (st[i + 3] << 24);
-                v.y = st[i + 4] | (st[i + 5] << 8) | (st[i + 6] << 16) | (st[i + 7] << 24);
-                v.z = st[i + 8] | (st[i + 9] << 8) | (st[i + 10] << 16) | (st[i + 11] << 24);
-                v.w = st[i + 12] | (st[i + 13] << 8) | (st[i + 14] << 16) | (st[i + 15] << 24);
-                *reinterpret_cast<uint4 *>(a.state + p0 + i) = v;
-            }
+            uint4 v;
+            v.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+            v.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+            v.z = st[8 % PER] | (st[9 % PER] << 8) | (st[10 % PER] << 16) | (st[11 % PER] << 24);
+            v.w = st[12 % PER] | (st[13 % PER] << 8) | (st[14 % PER] << 16) | (st[15 % PER] << 24);
+            *reinterpret_cast<uint4 *>(a.state + p0) = v;
         }
-        // block totals
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const uint32_t v = (uint32_t)(cntp >> (8 * c)) & 0xFFu;
             if (v) atomicAdd(&s_acc[c], (unsigned long long)v);
         }
-        if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
         if (sqc) atomicAdd(&s_acc[7], sqc);
         if (sumq) atomicAdd(&s_acc[8], sumq);
         if (nb) atomicAdd(&s_acc[9], (unsigned long long)nb);
@@ -519,37 +553,84 @@ __global__ __launch_bounds__(kBlock) void k_pileup(PileupArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_finalize: one workgroup.  Run starts per window = inner boundaries + the seam with the
-// previous window; exclusive scan -> win_off.  Reduces window and read partials to the summary.
+// k_fin_windows / k_fin_summary: two-level exclusive scan of the run starts per window (inner
+// boundaries + the seam with the previous window) and reduction of the window / read partials
+// to the contig summary.
 // ---------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
 
-__global__ __launch_bounds__(kFinBlock) void k_finalize(const WinPartial *__restrict__ winpart,
-                                                         const PrepPartial *__restrict__ prep,
-                                                         const uint8_t *__restrict__ state, uint32_t T,
-                                                         uint32_t n_win, uint32_t extent,
-                                                         uint32_t *__restrict__ win_off,
+struct FinPartial {
+    unsigned long long acc[9];       // cnt[6], n_cov, sum_qc, sum_q
+    uint32_t n_runs;
+    uint32_t max_raw;
+};
+
+__global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__restrict__ winpart,
+                                                            const uint8_t *__restrict__ state, uint32_t T,
+                                                            uint32_t n_win, uint32_t extent,
+                                                            uint32_t *__restrict__ win_off,
+                                                            FinPartial *__restrict__ fin)
+{
+    __shared__ uint32_t s_w[kFinBlock / 64], s_m[kFinBlock / 64];
+    __shared__ unsigned long long s_red[9][kFinBlock / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint32_t w = blockIdx.x * kFinBlock + tid;
+    unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t c = 0, maxraw = 0;
+    if (w < n_win) {
+        const WinPartial wp = winpart[w];
+        c = wp.n_inner;
+        const uint32_t p = w * T;
+        if (p < extent) c += (w == 0) ? 1u : (state[p] != state[p - 1] ? 1u : 0u);
+        for (int i = 0; i < 6; ++i) acc[i] = wp.cnt[i];
+        acc[6] = wp.n_cov; acc[7] = wp.sum_qc; acc[8] = wp.sum_q;
+        maxraw = wp.max_raw;
+    }
+    uint32_t inc = c;
+    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    if (lane == 63) s_w[wv] = inc;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const unsigned long long v = wave_sum_u64(acc[i]);
+        if (lane == 0) s_red[i][wv] = v;
+    }
+    maxraw = wave_max_u32(maxraw);
+    if (lane == 0) s_m[wv] = maxraw;
+    __syncthreads();
+    uint32_t off = inc - c;
+    for (int i = 0; i < wv; ++i) off += s_w[i];
+    if (w < n_win) win_off[w] = off;                 // relative to this block's first window
+    if (tid == 0) {
+        FinPartial fp;
+        fp.n_runs = 0; fp.max_raw = 0;
+        for (int j = 0; j < kFinBlock / 64; ++j) { fp.n_runs += s_w[j]; fp.max_raw = s_m[j] > fp.max_raw ? s_m[j] : fp.max_raw; }
+        for (int i = 0; i < 9; ++i) { unsigned long long v = 0; for (int j = 0; j < kFinBlock / 64; ++j) v += s_red[i][j]; fp.acc[i] = v; }
+        fin[blockIdx.x] = fp;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
+                                                         const PrepPartial *__restrict__ prep, uint32_t n_prep,
+                                                         uint32_t extent, uint32_t *__restrict__ blk_off,
                                                          DevSummary *__restrict__ out)
 {
-    __shared__ uint32_t s_w[kFinBlock / 64];
-    __shared__ unsigned long long s_red[kFinBlock / 64];
+    __shared__ unsigned long long s_red[11][kBlock / 64];
+    __shared__ uint32_t s_u[3][kBlock / 64];
+    __shared__ uint32_t s_w[kBlock / 64];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_carry = 0;
     __syncthreads();
-    unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint32_t maxraw = 0;
-    for (uint32_t base = 0; base < n_win; base += kFinBlock) {
-        const uint32_t w = base + tid;
+    unsigned long long acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t maxraw = 0, maxend = 0, err = 0;
+    for (uint32_t base = 0; base < n_fin; base += kBlock) {
+        const uint32_t b = base + tid;
         uint32_t c = 0;
-        if (w < n_win) {
-            const WinPartial wp = winpart[w];
-            c = wp.n_inner;
-            const uint32_t p = w * T;
-            if (p < extent) c += (w == 0) ? 1u : (state[p] != state[p - 1] ? 1u : 0u);
-            for (int i = 0; i < 6; ++i) acc[i] += wp.cnt[i];
-            acc[6] += wp.n_cov; acc[7] += wp.sum_qc; acc[8] += wp.sum_q;
-            maxraw = wp.max_raw > maxraw ? wp.max_raw : maxraw;
+        if (b < n_fin) {
+            const FinPartial fp = fin[b];
+            c = fp.n_runs;
+            for (int i = 0; i < 9; ++i) acc[i] += fp.acc[i];
+            maxraw = fp.max_raw > maxraw ? fp.max_raw : maxraw;
         }
         uint32_t inc = c;
         for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
@@ -557,48 +638,34 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const WinPartial *__rest
         __syncthreads();
         uint32_t off = s_carry + inc - c;
         for (int i = 0; i < wv; ++i) off += s_w[i];
-        if (w < n_win) win_off[w] = off;
+        if (b < n_fin) blk_off[b] = off;
         __syncthreads();
-        if (tid == kFinBlock - 1) s_carry = off + c;
-        __syncthreads();
-    }
-    // reductions
-    unsigned long long tot[11];
-    for (int i = 0; i < 9; ++i) {
-        unsigned long long v = wave_sum_u64(acc[i]);
-        if (lane == 0) s_red[wv] = v;
-        __syncthreads();
-        v = 0;
-        if (tid == 0) for (int j = 0; j < kFinBlock / 64; ++j) v += s_red[j];
-        tot[i] = v;
+        if (tid == kBlock - 1) s_carry = off + c;
         __syncthreads();
     }
-    maxraw = wave_max_u32(maxraw);
-    if (lane == 0) s_w[wv] = maxraw;
-    __syncthreads();
-    // read partials
-    unsigned long long sl = 0, sm = 0; uint32_t me = 0, er = 0;
-    for (int i = tid; i < kPrepBlocks; i += kFinBlock) {
-        sl += prep[i].sum_reflen; sm += prep[i].sum_mapq_reflen;
-        me = prep[i].max_end > me ? prep[i].max_end : me; er |= prep[i].err;
+    for (uint32_t i = tid; i < n_prep; i += kBlock) {
+        acc[9] += prep[i].sum_reflen; acc[10] += prep[i].sum_mapq_reflen;
+        maxend = prep[i].max_end > maxend ? prep[i].max_end : maxend; err |= prep[i].err;
     }
-    sl = wave_sum_u64(sl); sm = wave_sum_u64(sm); me = wave_max_u32(me); er = wave_or_u32(er);
-    __shared__ unsigned long long s_sl[kFinBlock / 64], s_sm[kFinBlock / 64];
-    __shared__ uint32_t s_me[kFinBlock / 64], s_er[kFinBlock / 64];
-    if (lane == 0) { s_sl[wv] = sl; s_sm[wv] = sm; s_me[wv] = me; s_er[wv] = er; }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        const unsigned long long v = wave_sum_u64(acc[i]);
+        if (lane == 0) s_red[i][wv] = v;
+    }
+    maxraw = wave_max_u32(maxraw); maxend = wave_max_u32(maxend); err = wave_or_u32(err);
+    if (lane == 0) { s_u[0][wv] = maxraw; s_u[1][wv] = maxend; s_u[2][wv] = err; }
     __syncthreads();
     if (tid == 0) {
-        uint32_t mr = 0; sl = 0; sm = 0; me = 0; er = 0;
-        for (int j = 0; j < kFinBlock / 64; ++j) {
-            mr = s_w[j] > mr ? s_w[j] : mr;
-            sl += s_sl[j]; sm += s_sm[j]; me = s_me[j] > me ? s_me[j] : me; er |= s_er[j];
-        }
+        unsigned long long tot[11];
+        for (int i = 0; i < 11; ++i) { tot[i] = 0; for (int j = 0; j < kBlock / 64; ++j) tot[i] += s_red[i][j]; }
+        uint32_t mr = 0, me = 0, er = 0;
+        for (int j = 0; j < kBlock / 64; ++j) { mr = s_u[0][j] > mr ? s_u[0][j] : mr; me = s_u[1][j] > me ? s_u[1][j] : me; er |= s_u[2][j]; }
         for (int i = 0; i < 6; ++i) out->state_counts[i] = tot[i];
         out->n_covered_bases = tot[6];
         out->quality_bases = tot[7];
         out->summed_baseq = tot[8];
-        out->summed_coverage = sl;
-        out->summed_mapq = sm;
+        out->summed_coverage = tot[9];
+        out->summed_mapq = tot[10];
         out->extent = extent;
         out->max_raw_depth = mr;
         out->n_intervals = s_carry;
@@ -614,6 +681,7 @@ __global__ __launch_bounds__(kFinBlock) void k_finalize(const WinPartial *__rest
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_rle_write(const uint8_t *__restrict__ state,
                                                        const uint32_t *__restrict__ win_off,
+                                                       const uint32_t *__restrict__ blk_off,
                                                        uint32_t n_win, uint32_t extent,
                                                        Interval *__restrict__ iv, uint32_t iv_cap)
 {
@@ -649,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint8_t *__restrict_
     for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
     if (lane == 63) s_w[wv] = inc;
     __syncthreads();
-    uint32_t idx = win_off[w] + inc - c;
+    uint32_t idx = blk_off[w / kFinBlock] + win_off[w] + inc - c;
     for (uint32_t i = 0; i < wv; ++i) idx += s_w[i];
 #pragma unroll
     for (int i = 0; i < PER; ++i) {

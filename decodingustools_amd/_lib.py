@@ -115,7 +115,8 @@ SYMBOLS = [
 
 
 def lib_path():
-    return _build.LIB
+    # DUT_CALLABLE_LIB: tooling override to time a differently built variant of the same library
+    return os.environ.get("DUT_CALLABLE_LIB") or _build.LIB
 
 
 def load():

@@ -75,11 +75,13 @@ struct cl_ctx {
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
     DevBuf<uint32_t> d_win_lo, d_win_hi, d_win_off;
+    DevBuf<unsigned long long> d_win_q0;
     DevBuf<uint8_t> d_state;
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
     DevBuf<uint32_t> d_blk_off;
+    DevBuf<uint32_t> d_errflag;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
     DevBuf<Interval> d_iv;
@@ -179,6 +181,7 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_win_lo.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_hi.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_off.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win_q0.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_fin.reserve(c->n_win / kFinBlock + 2));
     HIP_TRY(c, c->d_blk_off.reserve(c->n_win / kFinBlock + 2));
@@ -198,7 +201,11 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
 {
     const uint32_t grid = a.n_win8 * 8u;
     if (grid == 0) return;
-    hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+    // the byte-parallel threshold test has a shorter form when min_base_quality <= 128
+    if (c->opt.min_base_quality <= 128)
+        hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+    else
+        hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, false>), dim3(grid), dim3(kBlock), 0, c->stream, a);
 }
 
 cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, uint32_t *dbg_low)
@@ -215,20 +222,25 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
     R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
 
+    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, sizeof(uint32_t), c->stream));
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
                        c->d_end.p, c->d_prep.p);
     if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     if (c->n_win) {
         hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                           c->stream, R, c->d_prep.p, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p);
+                           c->stream, R, c->d_prep.p, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p, c->d_win_q0.p, c->d_errflag.p);
     }
     if (prof) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     PileupArgs a;
-    a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p;
+    a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p; a.win_q0 = c->d_win_q0.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
+    {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
+        const char *ab = getenv("CL_ABLATE");
+        a.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u;
+    }
     if (debug) launch_pileup<true>(c, a); else launch_pileup<false>(c, a);
     if (prof) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
@@ -236,7 +248,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
         hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_state.p,
                            kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
     hipLaunchKernelGGL(k_fin_summary, dim3(1), dim3(kBlock), 0, c->stream, c->d_fin.p, n_fin, c->d_prep.p,
-                       (uint32_t)kPrepBlocks, c->extent, c->d_blk_off.p, c->d_summary.p);
+                       (uint32_t)kPrepBlocks, c->extent, c->d_errflag.p, c->d_blk_off.p, c->d_summary.p);
     if (c->n_win) {
         hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream,
                            c->d_state.p, c->d_win_off.p, c->d_blk_off.p, c->n_win, c->extent, c->d_iv.p,
@@ -288,7 +300,7 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     std::vector<uint32_t> lut;
     build_lut(opt->max_low_mapq_fraction, lut);
     bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepBlocks) == hipSuccess &&
-              c->d_summary.reserve(1) == hipSuccess &&
+              c->d_summary.reserve(1) == hipSuccess && c->d_errflag.reserve(1) == hipSuccess &&
               hipMemcpy(c->d_lut.p, lut.data(), kLutSize * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { cl_destroy(c); return CL_ERR_DEVICE; }
     *out = c;
@@ -302,9 +314,9 @@ void cl_destroy(cl_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
-    c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
+    c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release(); c->d_errflag.release();
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);

@@ -185,7 +185,9 @@ __device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t
 __global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPartial *__restrict__ part,
                                                            uint32_t T, uint32_t n_win,
                                                            uint32_t *__restrict__ win_lo,
-                                                           uint32_t *__restrict__ win_hi)
+                                                           uint32_t *__restrict__ win_hi,
+                                                           unsigned long long *__restrict__ win_q0,
+                                                           uint32_t *__restrict__ err_flag)
 {
     __shared__ uint32_t s_m[kBlock / 64];
     uint32_t m = 0;
@@ -198,8 +200,13 @@ __global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPar
     const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
     if (w >= n_win) return;
     const long long W = (long long)w * T;
-    win_lo[w] = lower_bound_pos(R.pos, R.n, W - (long long)max_span + 1);
-    win_hi[w] = lower_bound_pos(R.pos, R.n, W + (long long)T);
+    const uint32_t lo = lower_bound_pos(R.pos, R.n, W - (long long)max_span + 1);
+    const uint32_t hi = lower_bound_pos(R.pos, R.n, W + (long long)T);
+    win_lo[w] = lo;
+    win_hi[w] = hi;
+    win_q0[w] = R.qual_off[lo];                    // lo <= n: the offsets array has n+1 entries
+    // k_pileup addresses the quality bytes of a window with 32-bit offsets
+    if (hi > lo && R.qual_off[hi] - R.qual_off[lo] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -223,6 +230,7 @@ struct PileupArgs {
     Opts o;
     const uint32_t *end;          // per read
     const uint32_t *win_lo, *win_hi;
+    const unsigned long long *win_q0;   // qual_off[win_lo[w]]
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     uint8_t        *state;        // n_win*T bytes
@@ -232,53 +240,140 @@ struct PileupArgs {
     uint32_t        n_win8;       // ceil(n_win/8): XCD-contiguous window ranges
     // debug dumps (nullptr in production)
     uint32_t *dbg_raw, *dbg_qc, *dbg_low;
+    uint32_t ablate;              // timing experiments only (env CL_ABLATE); 0 in production
 };
 
-// One 16-position unit of one M/=/X segment: quality bytes v (position ps+i <-> byte i), valid
-// positions pm (bit i).  Adds the pass bits to the packed counters and returns the sum of the
-// passing qualities (contig_profiler.rs:68-70).
+// One 16-position unit of one M/=/X segment: quality bytes v (unit position i <-> byte i), valid
+// positions pm (bit i).  Adds the pass bits to the counters and returns the sum of the passing
+// qualities (contig_profiler.rs:68-70).  Branch-free: an invalid position simply adds 0.
 //   8-bit mode : byte counter per position, 4 positions per LDS word; the word index is
 //                XOR-swizzled (word 4u+jj lives at 4u+(jj^((u>>3)&3))) so that the lanes of a
 //                wave, which all hold the same jj, spread over all 32 banks
 //   32-bit mode: one word per position (windows with a column deeper than 255)
-__device__ __forceinline__ uint32_t apply_unit(const Q16 &v, uint32_t pm, uint32_t u, bool mode8,
-                                               uint32_t *__restrict__ s_qc, const Opts &o)
+// ORF: min_base_quality <= 128, the test is hi(x) | (lo7(x) + (128-T) >= 128) (see qual_ge).
+// 0x01 in every byte of xw that is a valid position (pm nibble jj) and passes the threshold
+template <bool ORF>
+__device__ __forceinline__ uint32_t pass_bytes(uint32_t xw, uint32_t pm, int jj, const Opts &o)
+{
+    const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;   // nibble -> 0x01 per valid byte
+    if (ORF) return ((((xw & 0x7f7f7f7fu) + o.ge_add) | xw) >> 7) & vm;
+    return (qual_ge(xw, o) >> 7) & vm;
+}
+
+template <bool ORF>
+__device__ __forceinline__ uint32_t apply_unit8(const Q16 &v, uint32_t pm, uint32_t u,
+                                                uint32_t *__restrict__ s_qc, const Opts &o)
 {
     uint32_t sq = 0;
-    const uint32_t rot = (u >> 3) & 3u;
+    // byte address of word 4u + (jj ^ rot) == (16u | 4rot) ^ 4jj   (rot = (u>>3)&3)
+    const uint32_t a0 = (u << 4) | ((u >> 1) & 12u);
+    uint8_t *qc8 = reinterpret_cast<uint8_t *>(s_qc);
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const uint32_t xw = v.w[jj];
-        const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;
-        const uint32_t inc = (qual_ge(xw, o) >> 7) & vm;
-        if (inc) {
-            if (mode8) {
-                atomicAdd(&s_qc[(u << 2) + ((uint32_t)jj ^ rot)], inc);
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
-                    if ((inc >> (8 * i)) & 1u) atomicAdd(&s_qc[(u << 4) + 4 * jj + i], 1u);
-            }
-            sq = __builtin_amdgcn_sad_u8(xw & ((inc << 8) - inc), 0u, sq);
-        }
+        const uint32_t inc = pass_bytes<ORF>(xw, pm, jj, o);
+        atomicAdd(reinterpret_cast<uint32_t *>(qc8 + (a0 ^ (4u * jj))), inc);
+        sq = __builtin_amdgcn_udot4(xw, inc, sq, false);      // += quality of every passing byte
     }
     return sq;
 }
 
-template <int T, bool DEBUG>
-__global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
+template <bool ORF>
+__device__ __forceinline__ uint32_t apply_unit32(const Q16 &v, uint32_t pm, uint32_t u,
+                                                 uint32_t *__restrict__ s_qc, const Opts &o)
+{
+    uint32_t sq = 0;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        const uint32_t xw = v.w[jj];
+        const uint32_t inc = pass_bytes<ORF>(xw, pm, jj, o);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if ((inc >> (8 * i)) & 1u) atomicAdd(&s_qc[(u << 4) + 4 * jj + i], 1u);
+        sq = __builtin_amdgcn_udot4(xw, inc, sq, false);
+    }
+    return sq;
+}
+
+// per-lane view of one read while the window is processed
+struct ReadCur {
+    uint32_t x;        // reference position of the next CIGAR op
+    uint32_t y;        // query position of the next CIGAR op
+    uint32_t k, k1;    // next / end CIGAR index
+    uint32_t qrel;     // offset of the read's first quality byte from the window's quality base
+    uint32_t qlen;     // l_seq
+    uint32_t end, mq;
+    uint32_t c0;       // prefetched first CIGAR word
+    bool     live;
+};
+
+// a segment of the LDS list as a lane quad sees it
+struct SegView {
+    uint32_t srel, trel, qoff, u1, ub;
+};
+__device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
+{
+    SegView s;
+    s.srel = d.y & 0xFFFFu;
+    s.trel = s.srel + (d.y >> 16) + 1u;
+    s.qoff = d.x + (uint32_t)kQualPad - s.srel;      // + 16*u = byte offset of unit u from the padded base
+    s.u1 = (s.trel - 1u) >> 4;
+    s.ub = (s.srel >> 4) + ql;
+    return s;
+}
+// loads of one trip: units ub, ub+4, ub+8 (a unit past the end is clamped onto the last one)
+__device__ __forceinline__ void seg_load3(const SegView &s, uint32_t ub, const uint8_t *__restrict__ qbase,
+                                          Q16 v[3], uint32_t uu[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t u = ub + 4u * i;
+        uu[i] = u < s.u1 ? u : s.u1;
+        __builtin_memcpy(&v[i], qbase + (s.qoff + (uu[i] << 4)), 16);
+    }
+}
+template <bool ORF>
+__device__ __forceinline__ uint32_t seg_apply3(const SegView &s, uint32_t ub, bool on, const Q16 v[3],
+                                               const uint32_t uu[3], bool mode8, uint32_t *__restrict__ s_qc,
+                                               const Opts &o)
+{
+    uint32_t sq = 0;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t ps = uu[i] << 4;
+        const uint32_t vs = s.srel > ps ? s.srel - ps : 0u;
+        const uint32_t ve = (s.trel - ps) < 16u ? (s.trel - ps) : 16u;
+        const uint32_t m = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
+        const uint32_t pm = (on && ub + 4u * i <= s.u1) ? m : 0u;
+        if (mode8) sq += apply_unit8<ORF>(v[i], pm, uu[i], s_qc, o);
+        else sq += apply_unit32<ORF>(v[i], pm, uu[i], s_qc, o);
+    }
+    return sq;
+}
+
+#ifndef CL_MINWAVES
+#define CL_MINWAVES 8
+#endif
+#ifndef CL_RPL
+#define CL_RPL 1
+#endif
+template <int T, bool DEBUG, bool ORF>
+__global__ __launch_bounds__(kBlock, CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in scan / classify
     static_assert(PER == 8 || PER == 16, "T must be 2048 or 4096");
     constexpr int kSegCap = T / 2;                  // uint2 segments that fit in s_b
     constexpr int kSegPerLane = kSegCap / kBlock;   // segments a lane may emit per round
-    constexpr int kQuads = kBlock / 4;
+    constexpr int kRegCap = kSegCap / (kBlock / 64);   // list entries per wave region
+    constexpr int kRPL = CL_RPL;                    // reads per lane and pass
+    constexpr uint32_t kLutLds = 256;
     // LDS: 2 x T words + T flag bytes.  s_a: raw depth (phases 1-2), then the qc counters
     // (phase 3).  s_b: low-mapq depth (phases 1-2), then the segment list (phase 3).
     __shared__ __attribute__((aligned(16))) uint32_t s_a[T];
     __shared__ __attribute__((aligned(16))) uint32_t s_b[T];
     __shared__ __attribute__((aligned(16))) uint8_t s_flag[T];   // bit0: raw>0, bit1: low-mapq rule fired
-    __shared__ uint32_t s_nseg[2];
+    __shared__ uint16_t s_lut[kLutLds];             // low-mapq thresholds for raw < 256 (0xFFFF = never)
+    __shared__ uint32_t s_nseg[2][kBlock / 64];   // per round parity and wave: entries in the wave's region
     __shared__ uint32_t s_wraw[kBlock / 64], s_wlow[kBlock / 64], s_wmax[kBlock / 64];
     __shared__ uint8_t s_last[kBlock];
     __shared__ unsigned long long s_acc[10];        // cnt[6], n_cov, sum_qc, sum_q, n_inner
@@ -291,6 +386,19 @@ __global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
     const uint32_t W = w * (uint32_t)T;
     const uint32_t Wend = W + (uint32_t)T;
     const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t p0 = W + tid * PER;
+
+    const uint32_t lo = a.win_lo[w], hi = a.win_hi[w];
+    // all quality bytes of the reads [lo,hi) lie within 2^32 of qual_off[lo] (checked by
+    // k_window_bounds), so they are addressed by 32-bit offsets from a uniform base.  The base
+    // sits kQualPad bytes low so that the offset of a unit start never goes negative.
+    const unsigned long long qwin = a.win_q0[w];
+    const uint8_t *qbase = a.R.qual + qwin - kQualPad;
+
+    // reference bytes of this thread's positions: needed last, requested first
+    uint32_t refw[PER / 4];
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
 
     // ---- phase 0: clear ----
     {
@@ -298,28 +406,62 @@ __global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
         uint4 *r4 = reinterpret_cast<uint4 *>(s_a), *l4 = reinterpret_cast<uint4 *>(s_b);
         for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; }
         if (tid < 10) s_acc[tid] = 0;
-        if (tid < 2) s_nseg[tid] = 0;
+        if (tid < 2 * (kBlock / 64)) (&s_nseg[0][0])[tid] = 0;
+        if (tid < kLutLds) { const uint32_t v = a.lut[tid]; s_lut[tid] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v; }
     }
     __syncthreads();
 
-    const uint32_t lo = a.win_lo[w], hi = a.win_hi[w];
+    // reads of the window are taken kRPL per lane; all their metadata loads are issued together
+    const uint32_t n_pass = (hi - lo + kRPL * kBlock - 1) / (kRPL * kBlock);
+    ReadCur rc[kRPL];
+    auto load_reads = [&](uint32_t pass) {
+#pragma unroll
+        for (int i = 0; i < kRPL; ++i) {
+            const uint32_t r = lo + (pass * kRPL + i) * kBlock + tid;
+            rc[i].live = r < hi;
+            rc[i].x = 0; rc[i].y = 0; rc[i].k = 0; rc[i].k1 = 0; rc[i].qrel = 0; rc[i].qlen = 0;
+            rc[i].end = 0; rc[i].mq = 0; rc[i].c0 = 0;
+            if (r < hi) {
+                rc[i].x = (uint32_t)a.R.pos[r];
+                rc[i].end = a.end[r];
+                rc[i].mq = a.R.mapq[r];
+                rc[i].k = a.R.cigar_off[r];
+                rc[i].k1 = a.R.cigar_off[r + 1];
+                const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
+                rc[i].qrel = (uint32_t)(q0 - qwin);
+                rc[i].qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
+            }
+        }
+    };
 
     // ---- phase 1: raw_depth and low_mapq_count as +1/-1 at the clipped read span ends ----
     // (both count every read whose [pos,end) covers the position, D/N included: mod.rs:22-28)
-    for (uint32_t r = lo + tid; r < hi; r += kBlock) {
-        const uint32_t e = a.end[r];
-        const uint32_t b = (uint32_t)a.R.pos[r];
-        const uint32_t mq = a.R.mapq[r];
-        if (e <= W) continue;
-        const uint32_t cb = b > W ? b - W : 0u;
-        const uint32_t ce = e - W;
-        atomicAdd(&s_a[cb], 1u);
-        if (ce < (uint32_t)T) atomicAdd(&s_a[ce], 0xFFFFFFFFu);
-        if (mq <= a.o.max_low_mapq) {
-            atomicAdd(&s_b[cb], 1u);
-            if (ce < (uint32_t)T) atomicAdd(&s_b[ce], 0xFFFFFFFFu);
+    for (uint32_t pass = 0; pass < ((a.ablate & 4u) ? 0u : n_pass); ++pass) {
+        load_reads(pass);
+#pragma unroll
+        for (int i = 0; i < kRPL; ++i) {
+            if (rc[i].live && rc[i].end > W) {
+                const uint32_t cb = rc[i].x > W ? rc[i].x - W : 0u;
+                const uint32_t ce = rc[i].end - W;
+                atomicAdd(&s_a[cb], 1u);
+                if (ce < (uint32_t)T) atomicAdd(&s_a[ce], 0xFFFFFFFFu);
+                if (rc[i].mq <= a.o.max_low_mapq) {
+                    atomicAdd(&s_b[cb], 1u);
+                    if (ce < (uint32_t)T) atomicAdd(&s_b[ce], 0xFFFFFFFFu);
+                }
+            }
         }
     }
+    // with a single pass the reads stay in registers for phase 3; their first CIGAR word is
+    // requested now and arrives behind the scan
+    auto prefetch_c0 = [&]() {
+#pragma unroll
+        for (int i = 0; i < kRPL; ++i) {
+            rc[i].live = rc[i].live && rc[i].mq >= a.o.min_mapq && rc[i].end > W && rc[i].k < rc[i].k1;
+            if (rc[i].live) rc[i].c0 = a.R.cigar[rc[i].k];
+        }
+    };
+    if (n_pass == 1) prefetch_c0();
     __syncthreads();
 
     // ---- phase 2: prefix sums -> depths; per position keep only (raw>0, low-mapq rule) ----
@@ -352,15 +494,16 @@ __global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
             // callable_profiler.rs:100-101
             bool is_low = false;
             if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
-                if (raw < kLutSize) is_low = low >= a.lut[raw];
+                if (raw < kLutLds) { const uint32_t th = s_lut[raw]; is_low = th != 0xFFFFu && low >= th; }
+                else if (raw < kLutSize) is_low = low >= a.lut[raw];
                 else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
             }
             const uint32_t f = (raw > 0 ? 1u : 0u) | (is_low ? 2u : 0u);
             fl[i >> 2] |= f << (8 * (i & 3));
-            if (W + tid * PER + i < a.extent) ncov += raw > 0 ? 1u : 0u;
+            if (p0 + i < a.extent) ncov += raw > 0 ? 1u : 0u;
             if (DEBUG) {
-                if (a.dbg_raw) a.dbg_raw[W + tid * PER + i] = raw;
-                if (a.dbg_low) a.dbg_low[W + tid * PER + i] = low;
+                if (a.dbg_raw) a.dbg_raw[p0 + i] = raw;
+                if (a.dbg_low) a.dbg_low[p0 + i] = low;
             }
         }
 #pragma unroll
@@ -380,93 +523,86 @@ __global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
     // window's largest column is <= 255; otherwise use one 32-bit counter per position.
     const bool mode8 = maxraw <= 255u;
     uint32_t *s_qc = s_a;
-    uint2 *s_seg = reinterpret_cast<uint2 *>(s_b);
+    uint2 *s_seg = reinterpret_cast<uint2 *>(s_b);   // {quality offset, srel | (len-1)<<16}
 
     // ---- phase 3: qc_depth -- M/=/X bases with base quality >= min (reads with mapq >= min) ----
-    // Rounds of two steps.  A: one lane per read walks its CIGAR and appends the window-clipped
-    // M/=/X segments (at most kSegPerLane per round) to the LDS list.  B: lane quads take segments
-    // from the list; a lane handles units of 16 reference positions = one unaligned 16-byte load
-    // of quality bytes (three in flight), a byte-parallel threshold test, packed LDS counter adds.
+    // Rounds of two steps.  A: each lane walks the CIGARs of its reads and appends the
+    // window-clipped M/=/X segments (at most kSegPerLane per round) to the LDS list.  B: lane quads
+    // take segments from the list, two at a time; a lane handles units of 16 reference positions
+    // = one unaligned 16-byte load of quality bytes (six in flight), a byte-parallel threshold
+    // test and packed LDS counter adds.
     unsigned long long sumq = 0;
     {
         uint32_t par = 0;
-        const uint32_t quad = tid >> 2, ql = tid & 3u;
-        for (uint32_t batch = lo; batch < hi; batch += kBlock) {
-            const uint32_t r = batch + tid;
-            bool live = false;
-            uint32_t x = 0, y = 0, k = 0, k1 = 0, qlen = 0;
-            unsigned long long q0 = 0;
-            if (r < hi) {
-                const uint32_t mq = a.R.mapq[r], e = a.end[r];
-                x = (uint32_t)a.R.pos[r];
-                k = a.R.cigar_off[r];
-                k1 = a.R.cigar_off[r + 1];
-                q0 = a.R.qual_off[r];
-                const unsigned long long ql64 = a.R.qual_off[r + 1] - q0;
-                qlen = ql64 > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ql64;
-                live = mq >= a.o.min_mapq && e > W;
-            }
+        const uint32_t ql = tid & 3u;
+        for (uint32_t pass = 0; pass < ((a.ablate & 2u) ? 0u : n_pass); ++pass) {
+            if (n_pass > 1) { load_reads(pass); prefetch_c0(); }
+            bool first[kRPL];
+#pragma unroll
+            for (int i = 0; i < kRPL; ++i) first[i] = true;
             for (;;) {
                 // -- A: emit segments --
                 uint32_t nemit = 0;
-                while (live && nemit < (uint32_t)kSegPerLane) {
-                    if (k >= k1 || x >= Wend) { live = false; break; }
-                    const uint32_t c = a.R.cigar[k], op = c & 15u, l = c >> 4;
-                    ++k;
-                    if (op_match(op)) {
-                        const uint32_t xe = x + l;
-                        if (xe > W && y < qlen) {
-                            const uint32_t s = x > W ? x : W;
-                            uint32_t t = xe < Wend ? xe : Wend;
-                            const uint32_t lq = (qlen - y) < l ? (qlen - y) : l;   // bases that have a quality byte
-                            t = (x + lq) < t ? (x + lq) : t;
-                            if (s < t) {
-                                const unsigned long long qi = q0 + y + (s - x);   // quality index of position s
-                                const uint32_t slot = atomicAdd(&s_nseg[par], 1u);
-                                s_seg[slot] = make_uint2((uint32_t)qi,
-                                                         (uint32_t)(qi >> 32) | ((s - W) << 6) | ((t - s - 1u) << 19));
-                                ++nemit;
+#pragma unroll
+                for (int i = 0; i < kRPL; ++i) {
+                    ReadCur &c = rc[i];
+                    while (c.live && nemit < (uint32_t)kSegPerLane) {
+                        if (c.k >= c.k1 || c.x >= Wend) { c.live = false; break; }
+                        const uint32_t cw = first[i] ? c.c0 : a.R.cigar[c.k];
+                        first[i] = false;
+                        const uint32_t op = cw & 15u, l = cw >> 4;
+                        ++c.k;
+                        if (op_match(op)) {
+                            const uint32_t xe = c.x + l;
+                            if (xe > W && c.y < c.qlen) {
+                                const uint32_t s = c.x > W ? c.x : W;
+                                uint32_t t = xe < Wend ? xe : Wend;
+                                const uint32_t lq = (c.qlen - c.y) < l ? (c.qlen - c.y) : l;   // bases that have a quality byte
+                                t = (c.x + lq) < t ? (c.x + lq) : t;
+                                if (s < t) {
+                                    const uint32_t slot = wv * kRegCap + atomicAdd(&s_nseg[par][wv], 1u);
+                                    s_seg[slot] = make_uint2(c.qrel + c.y + (s - c.x), (s - W) | ((t - s - 1u) << 16));
+                                    ++nemit;
+                                }
+                            }
+                            c.x = xe; c.y += l;
+                        } else if (op_del(op)) {
+                            c.x += l;
+                        } else if (op_ins(op)) {
+                            c.y += l;
+                        }
+                    }
+                    c.live = c.live && c.k < c.k1 && c.x < Wend;
+                }
+                bool any_live = false;
+#pragma unroll
+                for (int i = 0; i < kRPL; ++i) any_live = any_live || rc[i].live;
+                const int more = __syncthreads_or(any_live ? 1 : 0);
+                // -- B: consume segments --
+                // Each wave's region of the list is in read (= position) order.  The 16 quads of a
+                // wave take entries that are far apart (4 regions x 4 strided sub-ranges), so that one
+                // wave instruction never adds to the same counter word from several lanes.
+                if (tid < kBlock / 64) s_nseg[par ^ 1u][tid] = 0;
+                uint32_t sq32 = 0;
+                {
+                    const uint32_t qw = (tid >> 2) & 15u, region = qw & 3u, sub = qw >> 2;
+                    const uint32_t nr = (a.ablate & 1u) ? 0u : s_nseg[par][region];
+                    const uint32_t Q = (nr + 3u) >> 2;
+                    const uint2 *reg = s_seg + region * kRegCap;
+                    for (uint32_t rr = wv; rr < Q; rr += kBlock / 64) {
+                        const uint32_t idx = sub * Q + rr;
+                        if (idx < nr) {
+                            const SegView sa = seg_view(reg[idx], ql);
+                            for (uint32_t u = sa.ub; u <= sa.u1; u += 12u) {
+                                Q16 va[3];
+                                uint32_t ua[3];
+                                seg_load3(sa, u, qbase, va, ua);
+                                sq32 += seg_apply3<ORF>(sa, u, true, va, ua, mode8, s_qc, a.o);
                             }
                         }
-                        x = xe; y += l;
-                    } else if (op_del(op)) {
-                        x += l;
-                    } else if (op_ins(op)) {
-                        y += l;
                     }
                 }
-                live = live && k < k1 && x < Wend;
-                const int more = __syncthreads_or(live ? 1 : 0);
-                // -- B: consume segments --
-                const uint32_t nseg = s_nseg[par];
-                if (tid == 0) s_nseg[par ^ 1u] = 0;
-                for (uint32_t j = quad; j < nseg; j += kQuads) {
-                    const uint2 d = s_seg[j];
-                    const uint32_t srel = (d.y >> 6) & 0x1FFFu;
-                    const uint32_t trel = srel + (d.y >> 19) + 1u;
-                    const uint8_t *qp = a.R.qual + ((long long)(((unsigned long long)(d.y & 63u) << 32) | d.x) - (long long)srel);
-                    const uint32_t u1 = (trel - 1u) >> 4;
-                    for (uint32_t ub = (srel >> 4) + ql; ub <= u1; ub += 12u) {
-                        // three units per lane and trip: u, u+4, u+8 (clamped; a clamped unit has an empty mask)
-                        uint32_t uu[3], pm[3];
-                        Q16 v[3];
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const uint32_t u = ub + 4u * i;
-                            uu[i] = u <= u1 ? u : u1;
-                            __builtin_memcpy(&v[i], qp + (uu[i] << 4), 16);
-                        }
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) {
-                            const uint32_t ps = uu[i] << 4;
-                            const uint32_t vs = srel > ps ? srel - ps : 0u;
-                            const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
-                            pm[i] = (ub + 4u * i <= u1) ? (((1u << ve) - 1u) & ~((1u << vs) - 1u)) : 0u;
-                        }
-#pragma unroll
-                        for (int i = 0; i < 3; ++i) sumq += apply_unit(v[i], pm[i], uu[i], mode8, s_qc, a.o);
-                    }
-                }
+                sumq += sq32;
                 __syncthreads();
                 par ^= 1u;
                 if (!more) break;
@@ -479,25 +615,22 @@ __global__ __launch_bounds__(kBlock, 8) void k_pileup(PileupArgs a)
         uint32_t st[PER];
         unsigned long long cntp = 0;                // six 8-bit fields (PER <= 16)
         unsigned long long sqc = 0;
-        const uint32_t p0 = W + tid * PER;
-        const uint8_t *refp = a.ref + p0;
-        uint32_t qcw[PER / 4];
-        if (mode8) {
+        uint32_t qcw[PER / 4], flw[PER / 4];
 #pragma unroll
-            for (int i = 0; i < PER / 4; ++i) {
-                const uint32_t wi = tid * (PER / 4) + i;          // word 4u+jj with u = wi>>2, jj = wi&3
-                qcw[i] = s_qc[(wi & ~3u) | ((wi & 3u) ^ ((wi >> 5) & 3u))];
-            }
+        for (int i = 0; i < PER / 4; ++i) {
+            const uint32_t wi = tid * (PER / 4) + i;          // word 4u+jj with u = wi>>2, jj = wi&3
+            flw[i] = reinterpret_cast<const uint32_t *>(s_flag)[wi];
+            qcw[i] = mode8 ? s_qc[(wi & ~3u) | ((wi & 3u) ^ ((wi >> 5) & 3u))] : 0u;
         }
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
             const uint32_t p = p0 + i;
-            const uint32_t f = s_flag[tid * PER + i];
+            const uint32_t f = (flw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
             const uint32_t qc = mode8 ? ((qcw[i >> 2] >> (8 * (i & 3))) & 0xFFu) : s_qc[tid * PER + i];
             if (DEBUG) { if (a.dbg_qc) a.dbg_qc[p] = qc; }
             uint32_t s = 0xFFu;
             if (p < a.extent) {
-                const uint32_t rb = refp[i];
+                const uint32_t rb = (refw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
                 if (rb == 'N' || rb == 'n') s = 0u;                                  // REF_N
                 else if (!(f & 1u)) s = 2u;                                          // NO_COVERAGE
                 else if (f & 2u) s = 5u;                                             // POOR_MAPPING_QUALITY
@@ -611,7 +744,8 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
 
 __global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
                                                          const PrepPartial *__restrict__ prep, uint32_t n_prep,
-                                                         uint32_t extent, uint32_t *__restrict__ blk_off,
+                                                         uint32_t extent, const uint32_t *__restrict__ err_flag,
+                                                         uint32_t *__restrict__ blk_off,
                                                          DevSummary *__restrict__ out)
 {
     __shared__ unsigned long long s_red[11][kBlock / 64];
@@ -670,7 +804,7 @@ __global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__rest
         out->max_raw_depth = mr;
         out->n_intervals = s_carry;
         out->max_end = me;
-        out->err = er;
+        out->err = er | *err_flag;
     }
 }
 

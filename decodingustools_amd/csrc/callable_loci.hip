@@ -20,8 +20,8 @@ using namespace clk;
 
 namespace {
 
-// window size (reference positions per workgroup).  2048 -> 18.9 KiB of LDS per workgroup,
-// eight workgroups (32 waves) per CU.
+// window size (reference positions per workgroup).  2048 -> 24.9 KiB of LDS per workgroup,
+// six workgroups (24 waves) per CU.
 #ifndef CL_WINDOW
 #define CL_WINDOW 2048
 #endif
@@ -55,6 +55,7 @@ struct cl_ctx {
 
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
+    bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
     int32_t tid = 0;
     uint32_t contig_len = 0;
     std::vector<uint8_t> h_ref;
@@ -201,11 +202,16 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
 {
     const uint32_t grid = a.n_win8 * 8u;
     if (grid == 0) return;
-    // the byte-parallel threshold test has a shorter form when min_base_quality <= 128
-    if (c->opt.min_base_quality <= 128)
-        hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true>), dim3(grid), dim3(kBlock), 0, c->stream, a);
-    else
-        hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, false>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+    // the byte-parallel threshold test has a shorter form when min_base_quality <= 128;
+    // the 32-bit counter variant is used only after k_window_bounds asked for it (kNeedDeep)
+    const bool orf = c->opt.min_base_quality <= 128;
+    if (!c->deep) {
+        if (orf) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, false>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, false, false>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+    } else {
+        if (orf) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+        else hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, false, true>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+    }
 }
 
 cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, uint32_t *dbg_low)
@@ -426,7 +432,7 @@ cl_status cl_contig_upload(cl_ctx *c)
     std::vector<uint8_t>().swap(c->h_qual);
     std::vector<uint32_t>().swap(c->h_cigar_off);
     std::vector<unsigned long long>().swap(c->h_qual_off);
-    c->uploaded = true; c->ran = false;
+    c->uploaded = true; c->ran = false; c->deep = false;
     return CL_OK;
 }
 
@@ -459,13 +465,20 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
 {
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
     HIP_TRY(c, hipSetDevice(c->device));
-    for (int attempt = 0; attempt < 3; ++attempt) {
+    for (int attempt = 0; attempt < 4; ++attempt) {
         HIP_TRY(c, hipMemcpyAsync(&c->h_sum, c->d_summary.p, sizeof(DevSummary), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         cl_status s = harvest_events(c);
         if (s != CL_OK) return s;
         s = check_summary(c);
         if (s != CL_OK) return s;
+        // a window touched by more reads than the 16-bit counters hold: redo with 32-bit counters
+        if ((c->h_sum.err & kNeedDeep) && !c->deep) {
+            c->deep = true;
+            s = enqueue(c, false, nullptr, nullptr, nullptr);
+            if (s != CL_OK) return s;
+            continue;
+        }
         // a read that overhangs the contig end makes the reference walk (and classify as REF_N,
         // mod.rs:100-101) positions up to its end: redo the contig with the larger extent
         if (c->h_sum.max_end > c->extent) {

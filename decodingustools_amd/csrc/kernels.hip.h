@@ -24,7 +24,7 @@ constexpr int kPrepBlocks = 4096;    // grid of k_read_prep (grid-stride)
 constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
 constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
 
-enum : uint32_t { kErrCigar = 1u, kErrRange = 2u };
+enum : uint32_t { kErrCigar = 1u, kErrRange = 2u, kNeedDeep = 4u };
 
 // per-block output of k_read_prep
 struct PrepPartial {
@@ -207,6 +207,8 @@ __global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPar
     win_q0[w] = R.qual_off[lo];                    // lo <= n: the offsets array has n+1 entries
     // k_pileup addresses the quality bytes of a window with 32-bit offsets
     if (hi > lo && R.qual_off[hi] - R.qual_off[lo] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
+    // more reads than the 16-bit qc_depth counters of k_pileup can hold: the 32-bit variant is needed
+    if (hi - lo > 65535u) atomicOr(err_flag, kNeedDeep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -243,36 +245,53 @@ struct PileupArgs {
     uint32_t ablate;              // timing experiments only (env CL_ABLATE); 0 in production
 };
 
-// One 16-position unit of one M/=/X segment: quality bytes v (unit position i <-> byte i), valid
-// positions pm (bit i).  Adds the pass bits to the counters and returns the sum of the passing
-// qualities (contig_profiler.rs:68-70).  Branch-free: an invalid position simply adds 0.
-//   8-bit mode : byte counter per position, 4 positions per LDS word; the word index is
-//                XOR-swizzled (word 4u+jj lives at 4u+(jj^((u>>3)&3))) so that the lanes of a
-//                wave, which all hold the same jj, spread over all 32 banks
-//   32-bit mode: one word per position (windows with a column deeper than 255)
-// ORF: min_base_quality <= 128, the test is hi(x) | (lo7(x) + (128-T) >= 128) (see qual_ge).
-// 0x01 in every byte of xw that is a valid position (pm nibble jj) and passes the threshold
+// ---------------------------------------------------------------------------------------------
+// k_pileup: one workgroup per window of T reference positions.
+//
+// Pass over the window's reads, 256 at a time, one lane per read, waves never synchronising:
+//   * +1/-1 at the clipped span ends into raw / low-mapq difference arrays (mod.rs:22-28: every
+//     read covering a position counts, D/N included)
+//   * the lane walks its CIGAR and writes the window-clipped M/=/X segments of reads with
+//     mapq >= min_mapq into its wave's private LDS list (in lane = position order)
+//   * lane quads consume the list: a lane handles units of 16 reference positions = one unaligned
+//     16-byte load of quality bytes, a byte-parallel "quality >= min" test (mod.rs:30-37) and
+//     adds into packed 16-bit LDS counters (qc_depth); the sum of the passing qualities feeds
+//     summed_baseq (contig_profiler.rs:68-70)
+// then one barrier and a final phase per position: prefix sums -> raw_depth / low_mapq_count,
+// the low-MAPQ rule and the state (callable_profiler.rs:100-116), run-boundary count, state byte.
+// None of the per-position counters ever exists in HBM.
+//
+// Reads are dealt to waves round-robin (read = base + 4*lane + wave) so that the segments a
+// wave's 16 quads work on at the same time are ~16 reads apart and never share a counter word.
+//
+// DEEP = false: 16-bit counters; valid while the window is touched by <= 65535 reads (otherwise
+// k_window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one 32-bit
+// counter per position).
+// ---------------------------------------------------------------------------------------------
 template <bool ORF>
 __device__ __forceinline__ uint32_t pass_bytes(uint32_t xw, uint32_t pm, int jj, const Opts &o)
 {
-    const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;   // nibble -> 0x01 per valid byte
+    // 0x01 in every byte of xw that is a valid position (nibble jj of pm) and passes the threshold
+    const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;
     if (ORF) return ((((xw & 0x7f7f7f7fu) + o.ge_add) | xw) >> 7) & vm;
     return (qual_ge(xw, o) >> 7) & vm;
 }
 
+// 16-bit counters: positions 4e..4e+3 are one 8-byte entry e = 4u + jj, stored at
+// 4u + (jj ^ ((u>>2)&3)) so that lanes holding the same jj spread over all banks.
 template <bool ORF>
-__device__ __forceinline__ uint32_t apply_unit8(const Q16 &v, uint32_t pm, uint32_t u,
-                                                uint32_t *__restrict__ s_qc, const Opts &o)
+__device__ __forceinline__ uint32_t apply_unit16(const Q16 &v, uint32_t pm, uint32_t u,
+                                                 unsigned long long *__restrict__ s_qc, const Opts &o)
 {
     uint32_t sq = 0;
-    // byte address of word 4u + (jj ^ rot) == (16u | 4rot) ^ 4jj   (rot = (u>>3)&3)
-    const uint32_t a0 = (u << 4) | ((u >> 1) & 12u);
-    uint8_t *qc8 = reinterpret_cast<uint8_t *>(s_qc);
+    const uint32_t e0 = (u << 2) | ((u >> 2) & 3u);       // entry index for jj = 0, xor jj for the others
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const uint32_t xw = v.w[jj];
         const uint32_t inc = pass_bytes<ORF>(xw, pm, jj, o);
-        atomicAdd(reinterpret_cast<uint32_t *>(qc8 + (a0 ^ (4u * jj))), inc);
+        const uint32_t lo = __builtin_amdgcn_perm(0u, inc, 0x0c010c00u);   // bytes 0,1 -> 16-bit fields
+        const uint32_t hi = __builtin_amdgcn_perm(0u, inc, 0x0c030c02u);   // bytes 2,3
+        atomicAdd(&s_qc[e0 ^ (uint32_t)jj], ((unsigned long long)hi << 32) | lo);
         sq = __builtin_amdgcn_udot4(xw, inc, sq, false);      // += quality of every passing byte
     }
     return sq;
@@ -295,86 +314,41 @@ __device__ __forceinline__ uint32_t apply_unit32(const Q16 &v, uint32_t pm, uint
     return sq;
 }
 
-// per-lane view of one read while the window is processed
-struct ReadCur {
-    uint32_t x;        // reference position of the next CIGAR op
-    uint32_t y;        // query position of the next CIGAR op
-    uint32_t k, k1;    // next / end CIGAR index
-    uint32_t qrel;     // offset of the read's first quality byte from the window's quality base
-    uint32_t qlen;     // l_seq
-    uint32_t end, mq;
-    uint32_t c0;       // prefetched first CIGAR word
-    bool     live;
-};
-
-// a segment of the LDS list as a lane quad sees it
+// a list entry {quality offset, srel | (len-1)<<16 | valid<<31} as a lane quad sees it
 struct SegView {
     uint32_t srel, trel, qoff, u1, ub;
+    bool on;
 };
 __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 {
     SegView s;
+    s.on = (d.y >> 31) != 0u;
     s.srel = d.y & 0xFFFFu;
-    s.trel = s.srel + (d.y >> 16) + 1u;
+    s.trel = s.srel + ((d.y >> 16) & 0x7FFFu) + 1u;
     s.qoff = d.x + (uint32_t)kQualPad - s.srel;      // + 16*u = byte offset of unit u from the padded base
     s.u1 = (s.trel - 1u) >> 4;
     s.ub = (s.srel >> 4) + ql;
     return s;
 }
-// loads of one trip: units ub, ub+4, ub+8 (a unit past the end is clamped onto the last one)
-__device__ __forceinline__ void seg_load3(const SegView &s, uint32_t ub, const uint8_t *__restrict__ qbase,
-                                          Q16 v[3], uint32_t uu[3])
-{
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const uint32_t u = ub + 4u * i;
-        uu[i] = u < s.u1 ? u : s.u1;
-        __builtin_memcpy(&v[i], qbase + (s.qoff + (uu[i] << 4)), 16);
-    }
-}
-template <bool ORF>
-__device__ __forceinline__ uint32_t seg_apply3(const SegView &s, uint32_t ub, bool on, const Q16 v[3],
-                                               const uint32_t uu[3], bool mode8, uint32_t *__restrict__ s_qc,
-                                               const Opts &o)
-{
-    uint32_t sq = 0;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const uint32_t ps = uu[i] << 4;
-        const uint32_t vs = s.srel > ps ? s.srel - ps : 0u;
-        const uint32_t ve = (s.trel - ps) < 16u ? (s.trel - ps) : 16u;
-        const uint32_t m = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
-        const uint32_t pm = (on && ub + 4u * i <= s.u1) ? m : 0u;
-        if (mode8) sq += apply_unit8<ORF>(v[i], pm, uu[i], s_qc, o);
-        else sq += apply_unit32<ORF>(v[i], pm, uu[i], s_qc, o);
-    }
-    return sq;
-}
 
 #ifndef CL_MINWAVES
-#define CL_MINWAVES 8
+#define CL_MINWAVES 6
 #endif
-#ifndef CL_RPL
-#define CL_RPL 1
-#endif
-template <int T, bool DEBUG, bool ORF>
-__global__ __launch_bounds__(kBlock, CL_MINWAVES) void k_pileup(PileupArgs a)
+template <int T, bool DEBUG, bool ORF, bool DEEP>
+__global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
-    constexpr int PER = T / kBlock;                 // positions per thread in scan / classify
-    static_assert(PER == 8 || PER == 16, "T must be 2048 or 4096");
-    constexpr int kSegCap = T / 2;                  // uint2 segments that fit in s_b
-    constexpr int kSegPerLane = kSegCap / kBlock;   // segments a lane may emit per round
-    constexpr int kRegCap = kSegCap / (kBlock / 64);   // list entries per wave region
-    constexpr int kRPL = CL_RPL;                    // reads per lane and pass
+    constexpr int PER = T / kBlock;                 // positions per thread in the final phase
+    static_assert(PER == 8, "T must be 2048");
+    constexpr int kWaves = kBlock / 64;
+    constexpr int kSegRound = 2;                    // segments a lane may emit per round
+    constexpr int kListCap = 64 * kSegRound;        // entries of one wave's list
     constexpr uint32_t kLutLds = 256;
-    // LDS: 2 x T words + T flag bytes.  s_a: raw depth (phases 1-2), then the qc counters
-    // (phase 3).  s_b: low-mapq depth (phases 1-2), then the segment list (phase 3).
-    __shared__ __attribute__((aligned(16))) uint32_t s_a[T];
-    __shared__ __attribute__((aligned(16))) uint32_t s_b[T];
-    __shared__ __attribute__((aligned(16))) uint8_t s_flag[T];   // bit0: raw>0, bit1: low-mapq rule fired
-    __shared__ uint16_t s_lut[kLutLds];             // low-mapq thresholds for raw < 256 (0xFFFF = never)
-    __shared__ uint32_t s_nseg[2][kBlock / 64];   // per round parity and wave: entries in the wave's region
-    __shared__ uint32_t s_wraw[kBlock / 64], s_wlow[kBlock / 64], s_wmax[kBlock / 64];
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[T];     // +-1 differences, then unused
+    __shared__ __attribute__((aligned(16))) uint32_t s_low[T];
+    __shared__ __attribute__((aligned(16))) uint32_t s_qcw[DEEP ? T : T / 2];   // qc_depth counters
+    __shared__ __attribute__((aligned(8))) uint2 s_list[kWaves][kListCap];
+    __shared__ uint16_t s_lut[kLutLds];             // low-mapq threshold for raw < 256 (0xFFFF = never)
+    __shared__ uint32_t s_wraw[kWaves], s_wlow[kWaves], s_wmax[kWaves];
     __shared__ uint8_t s_last[kBlock];
     __shared__ unsigned long long s_acc[10];        // cnt[6], n_cov, sum_qc, sum_q, n_inner
 
@@ -385,7 +359,7 @@ __global__ __launch_bounds__(kBlock, CL_MINWAVES) void k_pileup(PileupArgs a)
     const uint32_t tid = threadIdx.x;
     const uint32_t W = w * (uint32_t)T;
     const uint32_t Wend = W + (uint32_t)T;
-    const int lane = tid & 63, wv = tid >> 6;
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
     const uint32_t p0 = W + tid * PER;
 
     const uint32_t lo = a.win_lo[w], hi = a.win_hi[w];
@@ -396,280 +370,242 @@ __global__ __launch_bounds__(kBlock, CL_MINWAVES) void k_pileup(PileupArgs a)
     const uint8_t *qbase = a.R.qual + qwin - kQualPad;
 
     // reference bytes of this thread's positions: needed last, requested first
-    uint32_t refw[PER / 4];
-#pragma unroll
-    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
+    const uint2 refv = *reinterpret_cast<const uint2 *>(a.ref + p0);
 
-    // ---- phase 0: clear ----
+    // ---- clear ----
     {
         const uint4 z = make_uint4(0, 0, 0, 0);
-        uint4 *r4 = reinterpret_cast<uint4 *>(s_a), *l4 = reinterpret_cast<uint4 *>(s_b);
+        uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low),
+              *q4 = reinterpret_cast<uint4 *>(s_qcw);
         for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; }
+        for (int i = tid; i < (DEEP ? T : T / 2) / 4; i += kBlock) q4[i] = z;
         if (tid < 10) s_acc[tid] = 0;
-        if (tid < 2 * (kBlock / 64)) (&s_nseg[0][0])[tid] = 0;
-        if (tid < kLutLds) { const uint32_t v = a.lut[tid]; s_lut[tid] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v; }
+        if (tid < kLutLds) {
+            // fold "raw >= min_depth_for_low_mapq" into the table: below it the rule never fires
+            const uint32_t v = (tid >= a.o.min_depth_for_low_mapq && tid > 0) ? a.lut[tid] : 0xFFFFFFFFu;
+            s_lut[tid] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v;
+        }
     }
     __syncthreads();
 
-    // reads of the window are taken kRPL per lane; all their metadata loads are issued together
-    const uint32_t n_pass = (hi - lo + kRPL * kBlock - 1) / (kRPL * kBlock);
-    ReadCur rc[kRPL];
-    auto load_reads = [&](uint32_t pass) {
-#pragma unroll
-        for (int i = 0; i < kRPL; ++i) {
-            const uint32_t r = lo + (pass * kRPL + i) * kBlock + tid;
-            rc[i].live = r < hi;
-            rc[i].x = 0; rc[i].y = 0; rc[i].k = 0; rc[i].k1 = 0; rc[i].qrel = 0; rc[i].qlen = 0;
-            rc[i].end = 0; rc[i].mq = 0; rc[i].c0 = 0;
-            if (r < hi) {
-                rc[i].x = (uint32_t)a.R.pos[r];
-                rc[i].end = a.end[r];
-                rc[i].mq = a.R.mapq[r];
-                rc[i].k = a.R.cigar_off[r];
-                rc[i].k1 = a.R.cigar_off[r + 1];
-                const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
-                rc[i].qrel = (uint32_t)(q0 - qwin);
-                rc[i].qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
+    // ---- the pass over the reads ----
+    uint32_t sq32 = 0;                              // sum of passing qualities handled by this lane
+    unsigned long long sumq = 0;
+    const uint32_t ql = lane & 3u, quad = lane >> 2;
+    uint2 *list = s_list[wv];
+    for (uint32_t base = lo; base < ((a.ablate & 2u) ? lo : hi); base += kBlock) {
+        const uint32_t r = base + 4u * lane + wv;
+        bool live = false;
+        uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
+        if (r < hi) {
+            x = (uint32_t)a.R.pos[r];
+            const uint32_t e = a.end[r], mq = a.R.mapq[r];
+            k = a.R.cigar_off[r];
+            k1 = a.R.cigar_off[r + 1];
+            const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
+            qrel = (uint32_t)(q0 - qwin);
+            qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
+            if (e > W) {
+                const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
+                atomicAdd(&s_raw[cb], 1u);
+                if (ce < (uint32_t)T) atomicAdd(&s_raw[ce], 0xFFFFFFFFu);
+                if (mq <= a.o.max_low_mapq) {
+                    atomicAdd(&s_low[cb], 1u);
+                    if (ce < (uint32_t)T) atomicAdd(&s_low[ce], 0xFFFFFFFFu);
+                }
+                live = mq >= a.o.min_mapq && k < k1;
             }
+            if (live) cw = a.R.cigar[k];
         }
-    };
-
-    // ---- phase 1: raw_depth and low_mapq_count as +1/-1 at the clipped read span ends ----
-    // (both count every read whose [pos,end) covers the position, D/N included: mod.rs:22-28)
-    for (uint32_t pass = 0; pass < ((a.ablate & 4u) ? 0u : n_pass); ++pass) {
-        load_reads(pass);
+        bool have_cw = true;
+        for (;;) {                                   // rounds: wave-uniform loop
+            // -- each lane: next (at most kSegRound) segments of its read --
+            uint2 seg[kSegRound];
+            uint32_t nemit = 0;
 #pragma unroll
-        for (int i = 0; i < kRPL; ++i) {
-            if (rc[i].live && rc[i].end > W) {
-                const uint32_t cb = rc[i].x > W ? rc[i].x - W : 0u;
-                const uint32_t ce = rc[i].end - W;
-                atomicAdd(&s_a[cb], 1u);
-                if (ce < (uint32_t)T) atomicAdd(&s_a[ce], 0xFFFFFFFFu);
-                if (rc[i].mq <= a.o.max_low_mapq) {
-                    atomicAdd(&s_b[cb], 1u);
-                    if (ce < (uint32_t)T) atomicAdd(&s_b[ce], 0xFFFFFFFFu);
+            for (int i = 0; i < kSegRound; ++i) seg[i] = make_uint2(0u, 0u);
+            while (live && nemit < (uint32_t)kSegRound) {
+                if (k >= k1 || x >= Wend) { live = false; break; }
+                const uint32_t c = have_cw ? cw : a.R.cigar[k];
+                have_cw = false;
+                const uint32_t op = c & 15u, l = c >> 4;
+                ++k;
+                if (op_match(op)) {
+                    const uint32_t xe = x + l;
+                    if (xe > W && y < qlen) {
+                        const uint32_t s = x > W ? x : W;
+                        uint32_t t = xe < Wend ? xe : Wend;
+                        const uint32_t lq = (qlen - y) < l ? (qlen - y) : l;   // bases that have a quality byte
+                        t = (x + lq) < t ? (x + lq) : t;
+                        if (s < t) {
+                            const uint2 d = make_uint2(qrel + y + (s - x), (s - W) | ((t - s - 1u) << 16) | 0x80000000u);
+                            if (nemit == 0) seg[0] = d; else seg[1] = d;
+                            ++nemit;
+                        }
+                    }
+                    x = xe; y += l;
+                } else if (op_del(op)) {
+                    x += l;
+                } else if (op_ins(op)) {
+                    y += l;
                 }
             }
-        }
-    }
-    // with a single pass the reads stay in registers for phase 3; their first CIGAR word is
-    // requested now and arrives behind the scan
-    auto prefetch_c0 = [&]() {
+            live = live && k < k1 && x < Wend;
+            // -- wave-private list in lane (= position) order: first segments, then second ones --
+            uint32_t n_list = 0;
 #pragma unroll
-        for (int i = 0; i < kRPL; ++i) {
-            rc[i].live = rc[i].live && rc[i].mq >= a.o.min_mapq && rc[i].end > W && rc[i].k < rc[i].k1;
-            if (rc[i].live) rc[i].c0 = a.R.cigar[rc[i].k];
+            for (int i = 0; i < kSegRound; ++i) {
+                const bool has = (seg[i].y >> 31) != 0u;
+                const unsigned long long m = __ballot(has);
+                if (has) {
+                    const uint32_t idx = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    list[idx] = seg[i];
+                }
+                n_list += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // -- quads consume: quad q takes entries q*Q .. q*Q+Q-1, i.e. concurrently active
+            //    quads are Q list entries (~4Q reads) apart --
+            if (!(a.ablate & 1u)) {
+                const uint32_t Q = (n_list + 15u) >> 4;
+                for (uint32_t i = 0; i < Q; ++i) {
+                    const uint32_t idx = quad * Q + i;
+                    uint2 d = make_uint2(0u, 0u);
+                    if (idx < n_list) d = list[idx];
+                    const SegView sv = seg_view(d, ql);
+                    for (uint32_t u = sv.ub; u <= sv.u1; u += 12u) {
+                        // three units per lane and trip: u, u+4, u+8 (a unit past the end is clamped
+                        // onto the last one and gets an empty mask)
+                        Q16 v[3];
+                        uint32_t uu[3];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const uint32_t un = u + 4u * j;
+                            uu[j] = un < sv.u1 ? un : sv.u1;
+                            __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
+                        }
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            const uint32_t ps = uu[j] << 4;
+                            const uint32_t vs = sv.srel > ps ? sv.srel - ps : 0u;
+                            const uint32_t ve = (sv.trel - ps) < 16u ? (sv.trel - ps) : 16u;
+                            const uint32_t m = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
+                            const uint32_t pm = (sv.on && u + 4u * j <= sv.u1) ? m : 0u;
+                            if (DEEP) sq32 += apply_unit32<ORF>(v[j], pm, uu[j], s_qcw, a.o);
+                            else sq32 += apply_unit16<ORF>(v[j], pm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();       // the list is rewritten in the next round
+            if (!__any(live)) break;
         }
-    };
-    if (n_pass == 1) prefetch_c0();
+        sumq += sq32; sq32 = 0;
+    }
     __syncthreads();
 
-    // ---- phase 2: prefix sums -> depths; per position keep only (raw>0, low-mapq rule) ----
-    uint32_t maxraw;
+    // ---- final phase: depths, low-MAPQ rule, state, counts (8 positions per thread) ----
     {
         uint32_t vr[PER], vl[PER];
-        uint32_t sr = 0, sl = 0, mx = 0;
+        uint32_t sr = 0, sl = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            sr += s_a[tid * PER + i]; vr[i] = sr;
-            sl += s_b[tid * PER + i]; vl[i] = sl;
+            sr += s_raw[tid * PER + i]; vr[i] = sr;
+            sl += s_low[tid * PER + i]; vl[i] = sl;
         }
         uint32_t ir = sr, il = sl;
         for (int o = 1; o < 64; o <<= 1) {
             uint32_t tr = __shfl_up(ir, o, 64), tl = __shfl_up(il, o, 64);
-            if (lane >= o) { ir += tr; il += tl; }
+            if (lane >= (uint32_t)o) { ir += tr; il += tl; }
         }
         if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
-        __syncthreads();                              // also: everyone has read s_a / s_b
-        uint32_t offr = ir - sr, offl = il - sl;
-        for (int i = 0; i < wv; ++i) { offr += s_wraw[i]; offl += s_wlow[i]; }
-        uint32_t fl[PER / 4];
+        // qc_depth of the thread's positions
+        uint32_t qc[PER];
+        if (DEEP) {
 #pragma unroll
-        for (int i = 0; i < PER / 4; ++i) fl[i] = 0;
-        uint32_t ncov = 0;
+            for (int i = 0; i < PER; ++i) qc[i] = s_qcw[tid * PER + i];
+        } else {
+            const uint2 *q2 = reinterpret_cast<const uint2 *>(s_qcw);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const uint32_t raw = vr[i] + offr, low = vl[i] + offl;
-            mx = raw > mx ? raw : mx;
-            // callable_profiler.rs:100-101
-            bool is_low = false;
-            if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
-                if (raw < kLutLds) { const uint32_t th = s_lut[raw]; is_low = th != 0xFFFFu && low >= th; }
-                else if (raw < kLutSize) is_low = low >= a.lut[raw];
-                else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
-            }
-            const uint32_t f = (raw > 0 ? 1u : 0u) | (is_low ? 2u : 0u);
-            fl[i >> 2] |= f << (8 * (i & 3));
-            if (p0 + i < a.extent) ncov += raw > 0 ? 1u : 0u;
-            if (DEBUG) {
-                if (a.dbg_raw) a.dbg_raw[p0 + i] = raw;
-                if (a.dbg_low) a.dbg_low[p0 + i] = low;
+            for (int h = 0; h < PER / 4; ++h) {
+                const uint32_t e = tid * (PER / 4) + h;                 // entry 4u+jj: u = e>>2, jj = e&3
+                const uint2 c = q2[(e & ~3u) | ((e & 3u) ^ ((e >> 4) & 3u))];
+                qc[4 * h + 0] = c.x & 0xFFFFu; qc[4 * h + 1] = c.x >> 16;
+                qc[4 * h + 2] = c.y & 0xFFFFu; qc[4 * h + 3] = c.y >> 16;
             }
         }
-#pragma unroll
-        for (int i = 0; i < PER / 4; ++i) reinterpret_cast<uint32_t *>(s_flag)[tid * (PER / 4) + i] = fl[i];
-        if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
-        mx = wave_max_u32(mx);
-        if (lane == 0) s_wmax[wv] = mx;
-        // s_a becomes the qc counter array
-        const uint4 z = make_uint4(0, 0, 0, 0);
-        uint4 *q4 = reinterpret_cast<uint4 *>(s_a);
-        for (int i = tid; i < T / 4; i += kBlock) q4[i] = z;
         __syncthreads();
-        maxraw = 0;
-        for (int i = 0; i < kBlock / 64; ++i) maxraw = s_wmax[i] > maxraw ? s_wmax[i] : maxraw;
-    }
-    // qc_depth <= raw_depth at every position, so byte counters cannot overflow when the
-    // window's largest column is <= 255; otherwise use one 32-bit counter per position.
-    const bool mode8 = maxraw <= 255u;
-    uint32_t *s_qc = s_a;
-    uint2 *s_seg = reinterpret_cast<uint2 *>(s_b);   // {quality offset, srel | (len-1)<<16}
-
-    // ---- phase 3: qc_depth -- M/=/X bases with base quality >= min (reads with mapq >= min) ----
-    // Rounds of two steps.  A: each lane walks the CIGARs of its reads and appends the
-    // window-clipped M/=/X segments (at most kSegPerLane per round) to the LDS list.  B: lane quads
-    // take segments from the list, two at a time; a lane handles units of 16 reference positions
-    // = one unaligned 16-byte load of quality bytes (six in flight), a byte-parallel threshold
-    // test and packed LDS counter adds.
-    unsigned long long sumq = 0;
-    {
-        uint32_t par = 0;
-        const uint32_t ql = tid & 3u;
-        for (uint32_t pass = 0; pass < ((a.ablate & 2u) ? 0u : n_pass); ++pass) {
-            if (n_pass > 1) { load_reads(pass); prefetch_c0(); }
-            bool first[kRPL];
+        uint32_t offr = ir - sr, offl = il - sl;
+        for (uint32_t i = 0; i < wv; ++i) { offr += s_wraw[i]; offl += s_wlow[i]; }
+        uint32_t mx = 0;
 #pragma unroll
-            for (int i = 0; i < kRPL; ++i) first[i] = true;
-            for (;;) {
-                // -- A: emit segments --
-                uint32_t nemit = 0;
+        for (int i = 0; i < PER; ++i) { vr[i] += offr; vl[i] += offl; mx = vr[i] > mx ? vr[i] : mx; }
+        // low-MAPQ rule, callable_profiler.rs:100-101
+        uint32_t lowbits = 0;
+        if (mx < kLutLds) {
 #pragma unroll
-                for (int i = 0; i < kRPL; ++i) {
-                    ReadCur &c = rc[i];
-                    while (c.live && nemit < (uint32_t)kSegPerLane) {
-                        if (c.k >= c.k1 || c.x >= Wend) { c.live = false; break; }
-                        const uint32_t cw = first[i] ? c.c0 : a.R.cigar[c.k];
-                        first[i] = false;
-                        const uint32_t op = cw & 15u, l = cw >> 4;
-                        ++c.k;
-                        if (op_match(op)) {
-                            const uint32_t xe = c.x + l;
-                            if (xe > W && c.y < c.qlen) {
-                                const uint32_t s = c.x > W ? c.x : W;
-                                uint32_t t = xe < Wend ? xe : Wend;
-                                const uint32_t lq = (c.qlen - c.y) < l ? (c.qlen - c.y) : l;   // bases that have a quality byte
-                                t = (c.x + lq) < t ? (c.x + lq) : t;
-                                if (s < t) {
-                                    const uint32_t slot = wv * kRegCap + atomicAdd(&s_nseg[par][wv], 1u);
-                                    s_seg[slot] = make_uint2(c.qrel + c.y + (s - c.x), (s - W) | ((t - s - 1u) << 16));
-                                    ++nemit;
-                                }
-                            }
-                            c.x = xe; c.y += l;
-                        } else if (op_del(op)) {
-                            c.x += l;
-                        } else if (op_ins(op)) {
-                            c.y += l;
-                        }
-                    }
-                    c.live = c.live && c.k < c.k1 && c.x < Wend;
+            for (int i = 0; i < PER; ++i) lowbits |= (vl[i] >= (uint32_t)s_lut[vr[i]] ? 1u : 0u) << i;
+        } else {
+            for (int i = 0; i < PER; ++i) {
+                const uint32_t raw = vr[i], low = vl[i];
+                bool is_low = false;
+                if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
+                    if (raw < kLutSize) is_low = low >= a.lut[raw];
+                    else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
                 }
-                bool any_live = false;
-#pragma unroll
-                for (int i = 0; i < kRPL; ++i) any_live = any_live || rc[i].live;
-                const int more = __syncthreads_or(any_live ? 1 : 0);
-                // -- B: consume segments --
-                // Each wave's region of the list is in read (= position) order.  The 16 quads of a
-                // wave take entries that are far apart (4 regions x 4 strided sub-ranges), so that one
-                // wave instruction never adds to the same counter word from several lanes.
-                if (tid < kBlock / 64) s_nseg[par ^ 1u][tid] = 0;
-                uint32_t sq32 = 0;
-                {
-                    const uint32_t qw = (tid >> 2) & 15u, region = qw & 3u, sub = qw >> 2;
-                    const uint32_t nr = (a.ablate & 1u) ? 0u : s_nseg[par][region];
-                    const uint32_t Q = (nr + 3u) >> 2;
-                    const uint2 *reg = s_seg + region * kRegCap;
-                    for (uint32_t rr = wv; rr < Q; rr += kBlock / 64) {
-                        const uint32_t idx = sub * Q + rr;
-                        if (idx < nr) {
-                            const SegView sa = seg_view(reg[idx], ql);
-                            for (uint32_t u = sa.ub; u <= sa.u1; u += 12u) {
-                                Q16 va[3];
-                                uint32_t ua[3];
-                                seg_load3(sa, u, qbase, va, ua);
-                                sq32 += seg_apply3<ORF>(sa, u, true, va, ua, mode8, s_qc, a.o);
-                            }
-                        }
-                    }
-                }
-                sumq += sq32;
-                __syncthreads();
-                par ^= 1u;
-                if (!more) break;
+                lowbits |= (is_low ? 1u : 0u) << i;
             }
         }
-    }
-
-    // ---- phase 4: classify (callable_profiler.rs:104-116), count, write state bytes ----
-    {
+        // state, callable_profiler.rs:104-116 (later tests have priority, so apply them last)
         uint32_t st[PER];
-        unsigned long long cntp = 0;                // six 8-bit fields (PER <= 16)
+        uint32_t cnt4 = 0, ncov = 0;                // six 4-bit fields (at most 8 each)
         unsigned long long sqc = 0;
-        uint32_t qcw[PER / 4], flw[PER / 4];
-#pragma unroll
-        for (int i = 0; i < PER / 4; ++i) {
-            const uint32_t wi = tid * (PER / 4) + i;          // word 4u+jj with u = wi>>2, jj = wi&3
-            flw[i] = reinterpret_cast<const uint32_t *>(s_flag)[wi];
-            qcw[i] = mode8 ? s_qc[(wi & ~3u) | ((wi & 3u) ^ ((wi >> 5) & 3u))] : 0u;
-        }
+        const uint32_t n_ok = p0 >= a.extent ? 0u : (a.extent - p0 < (uint32_t)PER ? a.extent - p0 : (uint32_t)PER);
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            const uint32_t p = p0 + i;
-            const uint32_t f = (flw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-            const uint32_t qc = mode8 ? ((qcw[i >> 2] >> (8 * (i & 3))) & 0xFFu) : s_qc[tid * PER + i];
-            if (DEBUG) { if (a.dbg_qc) a.dbg_qc[p] = qc; }
-            uint32_t s = 0xFFu;
-            if (p < a.extent) {
-                const uint32_t rb = (refw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                if (rb == 'N' || rb == 'n') s = 0u;                                  // REF_N
-                else if (!(f & 1u)) s = 2u;                                          // NO_COVERAGE
-                else if (f & 2u) s = 5u;                                             // POOR_MAPPING_QUALITY
-                else if (qc < a.o.min_depth) s = 3u;                                 // LOW_COVERAGE
-                else if (a.o.max_depth > 0 && qc > a.o.max_depth) s = 4u;            // EXCESSIVE_COVERAGE
-                else s = 1u;                                                         // CALLABLE
-                cntp += 1ull << (8u * s);
-                sqc += qc;
+            const uint32_t rb = ((i < 4 ? refv.x : refv.y) >> (8 * (i & 3))) & 0xFFu;
+            uint32_t s = 1u;                                                      // CALLABLE
+            s = (a.o.max_depth > 0 && qc[i] > a.o.max_depth) ? 4u : s;            // EXCESSIVE_COVERAGE
+            s = qc[i] < a.o.min_depth ? 3u : s;                                   // LOW_COVERAGE
+            s = ((lowbits >> i) & 1u) ? 5u : s;                                   // POOR_MAPPING_QUALITY
+            s = vr[i] == 0 ? 2u : s;                                              // NO_COVERAGE
+            s = ((rb | 0x20u) == 'n') ? 0u : s;                                   // REF_N
+            const bool ok = (uint32_t)i < n_ok;
+            cnt4 += ok ? (1u << (4u * s)) : 0u;
+            ncov += (ok && vr[i] > 0) ? 1u : 0u;
+            sqc += ok ? qc[i] : 0u;
+            st[i] = ok ? s : 0xFFu;
+            if (DEBUG) {
+                if (a.dbg_raw) a.dbg_raw[p0 + i] = vr[i];
+                if (a.dbg_low) a.dbg_low[p0 + i] = vl[i];
+                if (a.dbg_qc) a.dbg_qc[p0 + i] = qc[i];
             }
-            st[i] = s;
         }
         // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
         s_last[tid] = (uint8_t)st[PER - 1];
+        mx = wave_max_u32(mx);
+        if (lane == 0) s_wmax[wv] = mx;
         __syncthreads();
         uint32_t nb = 0;
         uint32_t prev = tid > 0 ? s_last[tid - 1] : st[0];
 #pragma unroll
         for (int i = 0; i < PER; ++i) {
-            if (p0 + i < a.extent && st[i] != prev) nb += 1;
+            nb += ((uint32_t)i < n_ok && st[i] != prev) ? 1u : 0u;
             prev = st[i];
         }
-        if (PER == 8) {
-            uint2 v;
-            v.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
-            v.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
-            *reinterpret_cast<uint2 *>(a.state + p0) = v;
-        } else {
-            uint4 v;
-            v.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
-            v.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
-            v.z = st[8 % PER] | (st[9 % PER] << 8) | (st[10 % PER] << 16) | (st[11 % PER] << 24);
-            v.w = st[12 % PER] | (st[13 % PER] << 8) | (st[14 % PER] << 16) | (st[15 % PER] << 24);
-            *reinterpret_cast<uint4 *>(a.state + p0) = v;
-        }
+        uint2 sv;
+        sv.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
+        sv.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
+        *reinterpret_cast<uint2 *>(a.state + p0) = sv;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const uint32_t v = (uint32_t)(cntp >> (8 * c)) & 0xFFu;
+            const uint32_t v = (cnt4 >> (4 * c)) & 15u;
             if (v) atomicAdd(&s_acc[c], (unsigned long long)v);
         }
+        if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
         if (sqc) atomicAdd(&s_acc[7], sqc);
         if (sumq) atomicAdd(&s_acc[8], sumq);
         if (nb) atomicAdd(&s_acc[9], (unsigned long long)nb);
@@ -680,7 +616,9 @@ __global__ __launch_bounds__(kBlock, CL_MINWAVES) void k_pileup(PileupArgs a)
         for (int c = 0; c < 6; ++c) wp.cnt[c] = s_acc[c];
         wp.n_cov = s_acc[6]; wp.sum_qc = s_acc[7]; wp.sum_q = s_acc[8];
         wp.n_inner = (uint32_t)s_acc[9];
-        wp.max_raw = maxraw;
+        uint32_t m = 0;
+        for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
+        wp.max_raw = m;
         a.winpart[w] = wp;
     }
 }

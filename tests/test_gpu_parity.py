@@ -163,6 +163,26 @@ def test_deep_pileup_uses_32bit_counters(tmp_path):
     assert o2["amp"]["state_counts"][4] >= 0
 
 
+def test_window_with_more_than_65535_reads_uses_the_32bit_variant(tmp_path):
+    # 70 000 reads on 1 500 start positions: the 16-bit qc counters cannot hold a window like this,
+    # k_window_bounds flags it and the engine re-runs the contig with 32-bit counters
+    L = 5000
+    rng = np.random.default_rng(11)
+    n = 70_000
+    pos = np.sort(rng.integers(1000, 2500, size=n)).astype(np.int32)
+    rl = 40
+    rec = ContigRecords(
+        pos=pos, flag=np.zeros(n, np.uint16), mapq=rng.choice([0, 20, 60, 60], size=n).astype(np.uint8),
+        cigar_off=np.arange(n + 1, dtype=np.uint32), cigar=np.full(n, (rl << 4) | 0, np.uint32),
+        qual_off=(np.arange(n + 1, dtype=np.uint64) * np.uint64(rl)),
+        qual=rng.choice([5, 25, 40], size=n * rl).astype(np.uint8),
+        qname_off=(np.arange(n + 1, dtype=np.uint32) * np.uint32(10)), qname=synth._names_fixed(np.arange(n)).reshape(-1))
+    ref = synth.make_reference(L, 12)
+    o, g = compare([("deep", 0, L, ref, rec.validate())], dict(max_depth=1_000_000, min_depth_for_low_mapq=10),
+                   tmp_path, "deep65k")
+    assert o["deep"]["dumps"][0].max() > 1500
+
+
 def test_resident_rerun_is_idempotent_and_split_api_agrees(tmp_path):
     L = 300_000
     rec = synth.short_read_contig(L, 30, 77)

@@ -355,7 +355,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     const uint64_t n = t->n_reads;
     if (n == 0) return CL_OK;
     if (!t->pos || !t->mapq || !t->cigar_off || !t->qual_off) return fail(c, CL_ERR_INVALID, "null tile array");
-    if (c->h_pos.size() + n > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 reads in one contig");
+    if (c->h_pos.size() + n >= (1ull << 29)) return fail(c, CL_ERR_RANGE, "more than 2^29 reads in one contig");
     // validation that protects the kernels' indexing
     int32_t last = c->h_pos.empty() ? 0 : c->h_pos.back();
     for (uint64_t i = 0; i < n; ++i) {

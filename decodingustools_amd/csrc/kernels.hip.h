@@ -297,6 +297,25 @@ __device__ __forceinline__ uint32_t apply_unit16(const Q16 &v, uint32_t pm, uint
     return sq;
 }
 
+// 8-bit counters, two sets (reads alternate between the sets, a window handled this way is
+// touched by <= 510 reads, so no byte exceeds 255): positions 8e..8e+7 are one 8-byte entry
+// e = 2u + h of set `set`, stored at 2u + (h ^ ((u>>3)&1)); one ds_add_u64 covers 8 positions.
+template <bool ORF>
+__device__ __forceinline__ uint32_t apply_unit8(const Q16 &v, uint32_t pm, uint32_t u, uint32_t set_off,
+                                                unsigned long long *__restrict__ s_qc, const Opts &o)
+{
+    uint32_t inc[4], sq = 0;
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+        inc[jj] = pass_bytes<ORF>(v.w[jj], pm, jj, o);
+        sq = __builtin_amdgcn_udot4(v.w[jj], inc[jj], sq, false);      // += quality of every passing byte
+    }
+    const uint32_t e0 = set_off + ((u << 1) | ((u >> 3) & 1u));
+    atomicAdd(&s_qc[e0], ((unsigned long long)inc[1] << 32) | inc[0]);
+    atomicAdd(&s_qc[e0 ^ 1u], ((unsigned long long)inc[3] << 32) | inc[2]);
+    return sq;
+}
+
 template <bool ORF>
 __device__ __forceinline__ uint32_t apply_unit32(const Q16 &v, uint32_t pm, uint32_t u,
                                                  uint32_t *__restrict__ s_qc, const Opts &o)
@@ -314,17 +333,18 @@ __device__ __forceinline__ uint32_t apply_unit32(const Q16 &v, uint32_t pm, uint
     return sq;
 }
 
-// a list entry {quality offset, srel | (len-1)<<16 | valid<<31} as a lane quad sees it
+// a list entry {quality offset, srel | (len-1)<<16 | set<<30 | valid<<31} as a lane quad sees it
 struct SegView {
-    uint32_t srel, trel, qoff, u1, ub;
+    uint32_t srel, trel, qoff, u1, ub, set;
     bool on;
 };
 __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 {
     SegView s;
     s.on = (d.y >> 31) != 0u;
+    s.set = (d.y >> 30) & 1u;
     s.srel = d.y & 0xFFFFu;
-    s.trel = s.srel + ((d.y >> 16) & 0x7FFFu) + 1u;
+    s.trel = s.srel + ((d.y >> 16) & 0x3FFFu) + 1u;
     s.qoff = d.x + (uint32_t)kQualPad - s.srel;      // + 16*u = byte offset of unit u from the padded base
     s.u1 = (s.trel - 1u) >> 4;
     s.ub = (s.srel >> 4) + ql;
@@ -388,6 +408,10 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
     }
     __syncthreads();
 
+    // qc_depth counters: two sets of bytes when the window is touched by <= 510 reads (the reads
+    // alternate between the sets, so no byte can pass 255), else 16-bit fields (DEEP: 32-bit words)
+    const bool mode8 = !DEEP && (hi - lo) <= 510u;
+
     // ---- the pass over the reads ----
     uint32_t sq32 = 0;                              // sum of passing qualities handled by this lane
     unsigned long long sumq = 0;
@@ -395,6 +419,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
     uint2 *list = s_list[wv];
     for (uint32_t base = lo; base < ((a.ablate & 2u) ? lo : hi); base += kBlock) {
         const uint32_t r = base + 4u * lane + wv;
+        __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
         bool live = false;
         uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
         if (r < hi) {
@@ -415,42 +440,40 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
                 }
                 live = mq >= a.o.min_mapq && k < k1;
             }
-            if (live) cw = a.R.cigar[k];
+            if (live) cw = a.R.cigar[k];             // invariant: cw == cigar[k] while live
         }
-        bool have_cw = true;
+        const uint32_t setbit = (r & 1u) << 30;      // which 8-bit counter set this read adds to
         for (;;) {                                   // rounds: wave-uniform loop
-            // -- each lane: next (at most kSegRound) segments of its read --
+            // -- each lane: next (at most kSegRound) segments of its read.  Wave-uniform loop,
+            //    per-lane predication, one CIGAR op per iteration; invariant: cw == cigar[k] while live --
             uint2 seg[kSegRound];
+            seg[0] = make_uint2(0u, 0u); seg[1] = make_uint2(0u, 0u);
             uint32_t nemit = 0;
-#pragma unroll
-            for (int i = 0; i < kSegRound; ++i) seg[i] = make_uint2(0u, 0u);
-            while (live && nemit < (uint32_t)kSegRound) {
-                if (k >= k1 || x >= Wend) { live = false; break; }
-                const uint32_t c = have_cw ? cw : a.R.cigar[k];
-                have_cw = false;
-                const uint32_t op = c & 15u, l = c >> 4;
-                ++k;
-                if (op_match(op)) {
-                    const uint32_t xe = x + l;
-                    if (xe > W && y < qlen) {
-                        const uint32_t s = x > W ? x : W;
-                        uint32_t t = xe < Wend ? xe : Wend;
-                        const uint32_t lq = (qlen - y) < l ? (qlen - y) : l;   // bases that have a quality byte
-                        t = (x + lq) < t ? (x + lq) : t;
-                        if (s < t) {
-                            const uint2 d = make_uint2(qrel + y + (s - x), (s - W) | ((t - s - 1u) << 16) | 0x80000000u);
-                            if (nemit == 0) seg[0] = d; else seg[1] = d;
-                            ++nemit;
-                        }
-                    }
-                    x = xe; y += l;
-                } else if (op_del(op)) {
-                    x += l;
-                } else if (op_ins(op)) {
-                    y += l;
+            for (;;) {
+                const bool act = live && nemit < (uint32_t)kSegRound;
+                if (!__any(act)) break;
+                const uint32_t op = cw & 15u, l = cw >> 4;
+                const bool ism = ((0x181u >> op) & 1u) != 0u;        // M = X
+                const bool radv = ((0x18Du >> op) & 1u) != 0u;       // M D N = X consume reference
+                const bool qadv = ((0x193u >> op) & 1u) != 0u;       // M I S = X consume query
+                const uint32_t xe = x + (radv ? l : 0u);
+                const uint32_t sp = x > W ? x : W;
+                const uint32_t lq = y < qlen ? ((qlen - y) < l ? (qlen - y) : l) : 0u;   // bases that have a quality byte
+                uint32_t tp = xe < Wend ? xe : Wend;
+                tp = (x + lq) < tp ? (x + lq) : tp;
+                const bool valid = act && ism && sp < tp;
+                const uint2 d = make_uint2(qrel + y + (sp - x), (sp - W) | ((tp - sp - 1u) << 16) | setbit | 0x80000000u);
+                if (valid && nemit == 0u) seg[0] = d;
+                if (valid && nemit == 1u) seg[1] = d;
+                nemit += valid ? 1u : 0u;
+                if (act) {
+                    x = xe;
+                    y += qadv ? l : 0u;
+                    k += 1u;
+                    live = k < k1 && x < Wend;
+                    if (live) cw = a.R.cigar[k];
                 }
             }
-            live = live && k < k1 && x < Wend;
             // -- wave-private list in lane (= position) order: first segments, then second ones --
             uint32_t n_list = 0;
 #pragma unroll
@@ -494,6 +517,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
                             const uint32_t m = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
                             const uint32_t pm = (sv.on && u + 4u * j <= sv.u1) ? m : 0u;
                             if (DEEP) sq32 += apply_unit32<ORF>(v[j], pm, uu[j], s_qcw, a.o);
+                            else if (mode8) sq32 += apply_unit8<ORF>(v[j], pm, uu[j], sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
                             else sq32 += apply_unit16<ORF>(v[j], pm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
                         }
                     }
@@ -527,6 +551,15 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
         if (DEEP) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) qc[i] = s_qcw[tid * PER + i];
+        } else if (mode8) {
+            const uint2 *q2 = reinterpret_cast<const uint2 *>(s_qcw);
+            const uint32_t u = tid >> 1, e = (u << 1) | ((tid & 1u) ^ ((u >> 3) & 1u));   // entry 2u+h of the thread's 8 positions
+            const uint2 ca = q2[e], cb = q2[T / 8 + e];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qc[i] = ((ca.x >> (8 * i)) & 0xFFu) + ((cb.x >> (8 * i)) & 0xFFu);
+                qc[4 + i] = ((ca.y >> (8 * i)) & 0xFFu) + ((cb.y >> (8 * i)) & 0xFFu);
+            }
         } else {
             const uint2 *q2 = reinterpret_cast<const uint2 *>(s_qcw);
 #pragma unroll

@@ -1,0 +1,269 @@
+"""Host-side mirror of the reference's coverage driver (src/api/coverage.rs) over decoded,
+in-memory contigs, plus the multi-GPU form of it.
+
+    CoverageInput / CoverageOutput / CoverageAnalyzer.analyze     api/coverage.rs:22-145
+    initialize_contig_stats / validate_contig_selection           api/coverage.rs:149-204
+    process_contigs_api (ascending tid, serial)                   api/coverage.rs:221-236
+    build_coverage_export numbers                                 callable_loci/report.rs:15-134
+
+Multi-GPU (`analyze_sharded`): contigs are independent (the only cross-contig state of the
+reference is the BED writer's pending line, an output-formatting matter reproduced on rank 0), so
+they are dealt to ranks by longest-processing-time-first on their aligned bases; every rank runs
+its contigs on its own GPU with no data-path collective; per-contig summaries are exchanged with
+one all_gather (RCCL over xGMI when the backend is "nccl") and the run lists are sent to rank 0,
+which writes the BED in tid order.
+"""
+from dataclasses import dataclass, field
+from typing import Callable, Dict, List, Optional
+
+import numpy as np
+
+from .callable_loci import (CallableOptions, CallableProfiler, ContigProfiler, ContigResult, Engine,
+                            admit_reads, genome_summary)
+from .records import ContigRecords
+
+
+class ApiError(RuntimeError):
+    """ApiError::Analysis(String), api/mod.rs:24-41."""
+
+
+@dataclass
+class ContigInput:
+    name: str
+    length: int
+    records: ContigRecords
+    ref: Optional[np.ndarray] = None       # FASTA bytes of the contig, case preserved
+
+
+@dataclass
+class CoverageInput:
+    contigs: List[ContigInput]             # header (@SQ) order; index in this list = tid
+    options: CallableOptions = field(default_factory=CallableOptions)
+    selected: Optional[List[str]] = None   # -L / --contig
+    output_bed: str = "callable_regions.bed"
+
+
+@dataclass
+class CoverageOutput:
+    export: Dict
+    bed_file: str
+
+
+@dataclass
+class ContigOutcome:
+    """What one process_single_contig leaves behind (ContigProfiler + counts + runs)."""
+    tid: int
+    stats: ContigProfiler
+    state_counts: List[int]
+    intervals: np.ndarray                  # (n,3) uint32
+
+
+SUMMARY_FIELDS = 14   # 6 counts, covered, sum_cov, sum_baseq, sum_mapq, quality_bases, n_reads, length, n_intervals
+
+
+def initialize_contig_stats(inp: CoverageInput):
+    """api/coverage.rs:149-185: one ContigProfiler per header contig, filtered by -L."""
+    sel = set(inp.selected) if inp.selected is not None else None
+    out = {}
+    for tid, c in enumerate(inp.contigs):
+        if sel is not None and c.name not in sel:
+            continue
+        out[tid] = ContigProfiler(c.name, c.length)
+    return out
+
+
+def validate_contig_selection(stats, inp: CoverageInput):
+    """api/coverage.rs:187-204."""
+    if inp.selected is not None and not stats:
+        raise ApiError("None of the specified contigs ({}) were found in the BAM file".format(
+            ", ".join(inp.selected)))
+
+
+def engine_process_contig(engine: Engine, options: CallableOptions, tid: int, c: ContigInput) -> ContigOutcome:
+    """process_single_contig (mod.rs:44-147) on the device engine, returning the runs instead of
+    writing them (the caller owns the BED writer)."""
+    acc, n_names = admit_reads(options, tid, c.length, c.records)
+    rec = c.records
+    idx = np.flatnonzero(acc)
+    engine.contig_begin(tid, c.length, c.ref)
+    if idx.shape[0]:
+        if idx.shape[0] == rec.n:
+            engine.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        else:
+            clen = (rec.cigar_off[1:] - rec.cigar_off[:-1]).astype(np.int64)
+            qlen = (rec.qual_off[1:] - rec.qual_off[:-1]).astype(np.int64)
+            cig = rec.cigar[np.repeat(acc, clen)]
+            qual = rec.qual[np.repeat(acc, qlen)]
+            coff = np.concatenate([[0], np.cumsum(clen[idx])]).astype(np.uint32)
+            qoff = np.concatenate([[0], np.cumsum(qlen[idx])]).astype(np.uint64)
+            engine.push_reads(rec.pos[idx], rec.mapq[idx], coff, cig, qoff, qual)
+    res: ContigResult = engine.contig_finish()
+    st = ContigProfiler(c.name, c.length)
+    s = res.summary
+    st.n_covered_bases = int(s.n_covered_bases); st.summed_coverage = int(s.summed_coverage)
+    st.summed_baseq = int(s.summed_baseq); st.summed_mapq = int(s.summed_mapq)
+    st.quality_bases = int(s.quality_bases); st.n_reads = int(n_names)
+    return ContigOutcome(tid=tid, stats=st, state_counts=res.state_counts, intervals=res.intervals)
+
+
+def build_coverage_export(outcomes: List[ContigOutcome]) -> Dict:
+    """The numeric part of report.rs:15-134 (BamStats-derived strings are out of scope)."""
+    stats = [o.stats for o in outcomes]
+    callable_counts = [o.state_counts[1] for o in outcomes]
+    g = genome_summary(stats, callable_counts)
+    by_name = {o.stats.name: o for o in outcomes}
+    contigs = []
+    for name in g["order"]:
+        o = by_name[name]
+        d = o.stats.derived()
+        c = o.state_counts
+        contigs.append(dict(
+            name=name, length=o.stats.length, unique_reads=o.stats.n_reads,
+            coverage_percent=d["coverage_percent"], average_depth=d["average_depth"],
+            covered_bases=o.stats.n_covered_bases, total_bases=o.stats.length,
+            quality_stats=dict(average_mapq=d["average_mapq"], average_baseq=d["average_baseq"],
+                               q30_percentage=d["q30_percentage"]),
+            state_distribution=dict(ref_n=c[0], callable=c[1], no_coverage=c[2], low_coverage=c[3],
+                                    excessive_coverage=c[4], poor_mapping_quality=c[5])))
+    return dict(
+        summary=dict(total_bases=g["total_bases"], callable_bases=g["callable_bases"],
+                     callable_percentage=g["callable_percentage"], average_depth=g["average_depth"],
+                     contigs_analyzed=g["contigs_analyzed"]),
+        contigs=contigs,
+        quality_metrics=dict(average_mapq=g["average_mapq"], average_baseq=g["average_baseq"],
+                             q30_percentage=g["q30_percentage"]),
+        total_unique_reads=g["total_unique_reads"])
+
+
+def write_bed(outcomes: List[ContigOutcome], bed_path: str):
+    """One CallableProfiler over all contigs in ascending tid (api/coverage.rs:229-234), which
+    reproduces the duplicated last line of every contig but the last (callable_profiler.rs:64-66)."""
+    counter = CallableProfiler(bed_path)
+    try:
+        for o in sorted(outcomes, key=lambda o: o.tid):
+            class _S:                      # feed_contig only needs .state_counts and .intervals
+                pass
+            r = _S(); r.state_counts = o.state_counts; r.intervals = o.intervals
+            counter.feed_contig(o.stats.name, r)
+    finally:
+        counter.close()
+
+
+class CoverageAnalyzer:
+    """CoverageAnalyzer (api/coverage.rs:22-122) for decoded inputs on one GPU."""
+
+    def __init__(self, device_id: int = 0):
+        self.device_id = device_id
+        self._progress = None
+
+    def with_progress(self, callback: Callable):
+        self._progress = callback
+        return self
+
+    def _emit(self, kind, task):
+        if self._progress:
+            self._progress(dict(event=kind, task=task))
+
+    def analyze(self, inp: CoverageInput) -> CoverageOutput:
+        self._emit("Started", "Coverage Analysis")
+        stats = initialize_contig_stats(inp)
+        validate_contig_selection(stats, inp)
+        outcomes = []
+        with Engine(inp.options, self.device_id) as eng:
+            for tid in sorted(stats):
+                try:
+                    outcomes.append(engine_process_contig(eng, inp.options, tid, inp.contigs[tid]))
+                except Exception as e:       # api/coverage.rs:251
+                    raise ApiError(f"Error processing contig: {e}") from e
+        write_bed(outcomes, inp.output_bed)
+        out = CoverageOutput(export=build_coverage_export(outcomes), bed_file=inp.output_bed)
+        self._emit("Completed", "Coverage Analysis")
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU: one process per GPU, contigs dealt by LPT, one all_gather of summaries
+# ------------------------------------------------------------------------------------------------
+def lpt_assignment(weights: List[int], world: int) -> List[int]:
+    """Longest-processing-time-first: returns the rank of every item (deterministic)."""
+    load = [0] * world
+    rank_of = [0] * len(weights)
+    for i in sorted(range(len(weights)), key=lambda i: (-weights[i], i)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        rank_of[i] = r
+        load[r] += weights[i]
+    return rank_of
+
+
+def _outcome_row(o: ContigOutcome) -> List[int]:
+    s = o.stats
+    return list(o.state_counts) + [s.n_covered_bases, s.summed_coverage, s.summed_baseq, s.summed_mapq,
+                                   s.quality_bases, s.n_reads, s.length, int(o.intervals.shape[0])]
+
+
+def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: Callable[[int, ContigInput], ContigOutcome],
+                    device="cpu", group=None) -> Optional[CoverageOutput]:
+    """Every rank calls this with the same `inp` description (it only touches the contigs it is
+    assigned).  `process_contig(tid, contig)` runs one contig on this rank's GPU
+    (engine_process_contig bound to the rank's Engine).  Returns the output on rank 0, None elsewhere.
+    The only exchanges are the summary all_gather and the run lists sent to rank 0."""
+    import torch
+    import torch.distributed as dist
+    stats = initialize_contig_stats(inp)
+    validate_contig_selection(stats, inp)
+    tids = sorted(stats)
+    weights = [int(inp.contigs[t].records.qual.shape[0]) + inp.contigs[t].length for t in tids]
+    rank_of = lpt_assignment(weights, world)
+    mine = [t for t, r in zip(tids, rank_of) if r == rank]
+    local = {t: process_contig(t, inp.contigs[t]) for t in mine}
+
+    # --- summaries: fixed-size rows, one all_gather ---
+    per_rank = max(1, max(rank_of.count(r) for r in range(world)) if tids else 1)
+    rows = torch.zeros((per_rank, SUMMARY_FIELDS + 1), dtype=torch.int64)
+    rows[:, 0] = -1
+    for i, t in enumerate(mine):
+        rows[i, 0] = t
+        rows[i, 1:] = torch.tensor(_outcome_row(local[t]), dtype=torch.int64)
+    rows = rows.to(device)
+    gathered = [torch.zeros_like(rows) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(gathered, rows, group=group)
+    else:
+        gathered = [rows]
+    table = {}
+    for g in gathered:
+        for row in g.cpu().tolist():
+            if row[0] >= 0:
+                table[int(row[0])] = row[1:]
+
+    # --- run lists to rank 0 (padded to the largest list of any rank) ---
+    n_iv_rank = [sum(table[t][13] for t, r in zip(tids, rank_of) if r == rr) for rr in range(world)]
+    cap = max(1, max(n_iv_rank) if n_iv_rank else 1)
+    buf = torch.zeros((cap, 3), dtype=torch.int64)
+    off = 0
+    for t in mine:
+        iv = local[t].intervals
+        buf[off:off + iv.shape[0]] = torch.from_numpy(iv.astype(np.int64))
+        off += iv.shape[0]
+    buf = buf.to(device)
+    if world > 1:
+        bufs = [torch.zeros_like(buf) for _ in range(world)] if rank == 0 else None
+        dist.gather(buf, bufs, dst=0, group=group)
+    else:
+        bufs = [buf]
+    if rank != 0:
+        return None
+    outcomes = []
+    offs = [0] * world
+    for t, r in zip(tids, rank_of):
+        row = table[t]
+        n_iv = int(row[13])
+        iv = bufs[r][offs[r]:offs[r] + n_iv].cpu().numpy().astype(np.uint32)
+        offs[r] += n_iv
+        c = inp.contigs[t]
+        st = ContigProfiler(c.name, c.length, n_covered_bases=int(row[6]), summed_coverage=int(row[7]),
+                            summed_baseq=int(row[8]), summed_mapq=int(row[9]), quality_bases=int(row[10]),
+                            n_reads=int(row[11]))
+        outcomes.append(ContigOutcome(tid=t, stats=st, state_counts=[int(x) for x in row[:6]], intervals=iv))
+    write_bed(outcomes, inp.output_bed)
+    return CoverageOutput(export=build_coverage_export(outcomes), bed_file=inp.output_bed)

@@ -262,3 +262,35 @@ def test_site_pileup_random_vs_oracle():
         hist = eng.site_pileup(20, L, ref.shape[0], rec, sites)
     assert np.array_equal(hist, exp["hist"])
     assert exp["called"].sum() > 1000
+
+
+def test_coverage_analyzer_and_sharded_driver_on_gpu(tmp_path):
+    from decodingustools_amd.coverage import (ContigInput, CoverageAnalyzer, CoverageInput, analyze_sharded,
+                                              engine_process_contig)
+    names = ["chr1", "chr2", "chr10", "chrX", "chrM"]
+    lens = [60_000, 31_000, 42_000, 20_480, 7_000]
+    contigs = []
+    for t, (nm, L) in enumerate(zip(names, lens)):
+        rec = synth.short_read_contig(L, 30, 4000 + t) if t != 4 else synth.adversarial_contig(L, 900, 4100, deep=True)
+        contigs.append(ContigInput(nm, L, rec, synth.make_reference(L, 60 + t, lowercase=(t == 4))))
+    opt = CallableOptions()
+    events = []
+    inp = CoverageInput(contigs=contigs, options=opt, selected=["chr1", "chr10", "chrM", "chrZZ"],
+                        output_bed=str(tmp_path / "a.bed"))
+    out = CoverageAnalyzer(0).with_progress(events.append).analyze(inp)
+    assert [e["event"] for e in events] == ["Started", "Completed"]
+    keep = [(c.name, t, c.length, c.ref, c.records) for t, c in enumerate(contigs) if c.name in inp.selected]
+    o_res, o_bed = oracle_run(keep, make_options({}), str(tmp_path / "o.bed"))
+    assert open(out.bed_file).read() == o_bed
+    assert [c["name"] for c in out.export["contigs"]] == ["chr1", "chr10", "chrM"]
+    for c in out.export["contigs"]:
+        st = o_res[c["name"]]["stats"]
+        assert c["unique_reads"] == st["n_reads"] and c["covered_bases"] == st["n_covered_bases"]
+        assert c["average_depth"] == st["derived"]["average_depth"]
+        assert c["quality_stats"]["average_mapq"] == st["derived"]["average_mapq"]
+        assert c["state_distribution"]["callable"] == o_res[c["name"]]["state_counts"][1]
+    # the sharded driver with one rank is the same computation
+    inp2 = CoverageInput(contigs=contigs, options=opt, selected=inp.selected, output_bed=str(tmp_path / "b.bed"))
+    with Engine(opt, 0) as eng:
+        out2 = analyze_sharded(inp2, 0, 1, lambda tid, c: engine_process_contig(eng, opt, tid, c))
+    assert open(out2.bed_file).read() == o_bed and out2.export == out.export

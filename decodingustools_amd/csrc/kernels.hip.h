@@ -16,6 +16,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 
 namespace clk {
 
@@ -269,62 +270,63 @@ struct PileupArgs {
 // counter per position).
 // ---------------------------------------------------------------------------------------------
 template <bool ORF>
-__device__ __forceinline__ uint32_t pass_bytes(uint32_t xw, uint32_t pm, int jj, const Opts &o)
+__device__ __forceinline__ uint32_t pass_bytes(uint32_t xw, uint32_t vm, const Opts &o)
 {
-    // 0x01 in every byte of xw that is a valid position (nibble jj of pm) and passes the threshold
-    const uint32_t vm = __umul24((pm >> (4 * jj)) & 15u, 0x204081u) & 0x01010101u;
+    // 0x01 in every byte of xw that is a valid position (vm) and passes the threshold
     if (ORF) return ((((xw & 0x7f7f7f7fu) + o.ge_add) | xw) >> 7) & vm;
     return (qual_ge(xw, o) >> 7) & vm;
-}
-
-// 16-bit counters: positions 4e..4e+3 are one 8-byte entry e = 4u + jj, stored at
-// 4u + (jj ^ ((u>>2)&3)) so that lanes holding the same jj spread over all banks.
-template <bool ORF>
-__device__ __forceinline__ uint32_t apply_unit16(const Q16 &v, uint32_t pm, uint32_t u,
-                                                 unsigned long long *__restrict__ s_qc, const Opts &o)
-{
-    uint32_t sq = 0;
-    const uint32_t e0 = (u << 2) | ((u >> 2) & 3u);       // entry index for jj = 0, xor jj for the others
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-        const uint32_t xw = v.w[jj];
-        const uint32_t inc = pass_bytes<ORF>(xw, pm, jj, o);
-        const uint32_t lo = __builtin_amdgcn_perm(0u, inc, 0x0c010c00u);   // bytes 0,1 -> 16-bit fields
-        const uint32_t hi = __builtin_amdgcn_perm(0u, inc, 0x0c030c02u);   // bytes 2,3
-        atomicAdd(&s_qc[e0 ^ (uint32_t)jj], ((unsigned long long)hi << 32) | lo);
-        sq = __builtin_amdgcn_udot4(xw, inc, sq, false);      // += quality of every passing byte
-    }
-    return sq;
 }
 
 // 8-bit counters, two sets (reads alternate between the sets, a window handled this way is
 // touched by <= 510 reads, so no byte exceeds 255): positions 8e..8e+7 are one 8-byte entry
 // e = 2u + h of set `set`, stored at 2u + (h ^ ((u>>3)&1)); one ds_add_u64 covers 8 positions.
 template <bool ORF>
-__device__ __forceinline__ uint32_t apply_unit8(const Q16 &v, uint32_t pm, uint32_t u, uint32_t set_off,
+__device__ __forceinline__ uint32_t apply_unit8(const Q16 &v, const uint4 vm, uint32_t u, uint32_t set_off,
                                                 unsigned long long *__restrict__ s_qc, const Opts &o)
 {
-    uint32_t inc[4], sq = 0;
+    const uint32_t i0 = pass_bytes<ORF>(v.w[0], vm.x, o), i1 = pass_bytes<ORF>(v.w[1], vm.y, o);
+    const uint32_t i2 = pass_bytes<ORF>(v.w[2], vm.z, o), i3 = pass_bytes<ORF>(v.w[3], vm.w, o);
+    uint32_t sq = __builtin_amdgcn_udot4(v.w[0], i0, 0u, false);      // += quality of every passing byte
+    sq = __builtin_amdgcn_udot4(v.w[1], i1, sq, false);
+    sq = __builtin_amdgcn_udot4(v.w[2], i2, sq, false);
+    sq = __builtin_amdgcn_udot4(v.w[3], i3, sq, false);
+    const uint32_t e0 = set_off + ((u << 1) | ((u >> 3) & 1u));
+    atomicAdd(&s_qc[e0], ((unsigned long long)i1 << 32) | i0);
+    atomicAdd(&s_qc[e0 ^ 1u], ((unsigned long long)i3 << 32) | i2);
+    return sq;
+}
+
+// 16-bit counters: positions 4e..4e+3 are one 8-byte entry e = 4u + jj, stored at
+// 4u + (jj ^ ((u>>2)&3)) so that lanes holding the same jj spread over all banks.
+template <bool ORF>
+__device__ __forceinline__ uint32_t apply_unit16(const Q16 &v, const uint4 vm, uint32_t u,
+                                                 unsigned long long *__restrict__ s_qc, const Opts &o)
+{
+    uint32_t sq = 0;
+    const uint32_t e0 = (u << 2) | ((u >> 2) & 3u);       // entry index for jj = 0, xor jj for the others
+    const uint32_t vmw[4] = {vm.x, vm.y, vm.z, vm.w};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
-        inc[jj] = pass_bytes<ORF>(v.w[jj], pm, jj, o);
-        sq = __builtin_amdgcn_udot4(v.w[jj], inc[jj], sq, false);      // += quality of every passing byte
+        const uint32_t xw = v.w[jj];
+        const uint32_t inc = pass_bytes<ORF>(xw, vmw[jj], o);
+        const uint32_t lo = __builtin_amdgcn_perm(0u, inc, 0x0c010c00u);   // bytes 0,1 -> 16-bit fields
+        const uint32_t hi = __builtin_amdgcn_perm(0u, inc, 0x0c030c02u);   // bytes 2,3
+        atomicAdd(&s_qc[e0 ^ (uint32_t)jj], ((unsigned long long)hi << 32) | lo);
+        sq = __builtin_amdgcn_udot4(xw, inc, sq, false);
     }
-    const uint32_t e0 = set_off + ((u << 1) | ((u >> 3) & 1u));
-    atomicAdd(&s_qc[e0], ((unsigned long long)inc[1] << 32) | inc[0]);
-    atomicAdd(&s_qc[e0 ^ 1u], ((unsigned long long)inc[3] << 32) | inc[2]);
     return sq;
 }
 
 template <bool ORF>
-__device__ __forceinline__ uint32_t apply_unit32(const Q16 &v, uint32_t pm, uint32_t u,
+__device__ __forceinline__ uint32_t apply_unit32(const Q16 &v, const uint4 vm, uint32_t u,
                                                  uint32_t *__restrict__ s_qc, const Opts &o)
 {
     uint32_t sq = 0;
+    const uint32_t vmw[4] = {vm.x, vm.y, vm.z, vm.w};
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
         const uint32_t xw = v.w[jj];
-        const uint32_t inc = pass_bytes<ORF>(xw, pm, jj, o);
+        const uint32_t inc = pass_bytes<ORF>(xw, vmw[jj], o);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             if ((inc >> (8 * i)) & 1u) atomicAdd(&s_qc[(u << 4) + 4 * jj + i], 1u);
@@ -368,6 +370,9 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
     __shared__ __attribute__((aligned(16))) uint32_t s_qcw[DEEP ? T : T / 2];   // qc_depth counters
     __shared__ __attribute__((aligned(8))) uint2 s_list[kWaves][kListCap];
     __shared__ uint16_t s_lut[kLutLds];             // low-mapq threshold for raw < 256 (0xFFFF = never)
+    // validity masks of a 16-position unit: byte i of s_mstart[vs] is 0x01 iff i >= vs,
+    // byte i of s_mend[ve] is 0x01 iff i < ve (vs, ve in 0..16)
+    __shared__ __attribute__((aligned(16))) uint4 s_mstart[17], s_mend[17];
     __shared__ uint32_t s_wraw[kWaves], s_wlow[kWaves], s_wmax[kWaves];
     __shared__ uint8_t s_last[kBlock];
     __shared__ unsigned long long s_acc[10];        // cnt[6], n_cov, sum_qc, sum_q, n_inner
@@ -400,6 +405,16 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
         for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; }
         for (int i = tid; i < (DEEP ? T : T / 2) / 4; i += kBlock) q4[i] = z;
         if (tid < 10) s_acc[tid] = 0;
+        if (tid < 34) {
+            const uint32_t e = tid < 17 ? tid : tid - 17;                       // vs or ve
+            const uint32_t bits = tid < 17 ? (0xFFFFu & ~((1u << e) - 1u)) : ((1u << e) - 1u);
+            uint4 m;
+            m.x = __umul24(bits & 15u, 0x204081u) & 0x01010101u;
+            m.y = __umul24((bits >> 4) & 15u, 0x204081u) & 0x01010101u;
+            m.z = __umul24((bits >> 8) & 15u, 0x204081u) & 0x01010101u;
+            m.w = __umul24((bits >> 12) & 15u, 0x204081u) & 0x01010101u;
+            if (tid < 17) s_mstart[e] = m; else s_mend[e] = m;
+        }
         if (tid < kLutLds) {
             // fold "raw >= min_depth_for_low_mapq" into the table: below it the rule never fires
             const uint32_t v = (tid >= a.o.min_depth_for_low_mapq && tid > 0) ? a.lut[tid] : 0xFFFFFFFFu;
@@ -493,35 +508,43 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
             //    quads are Q list entries (~4Q reads) apart --
             if (!(a.ablate & 1u)) {
                 const uint32_t Q = (n_list + 15u) >> 4;
-                for (uint32_t i = 0; i < Q; ++i) {
-                    const uint32_t idx = quad * Q + i;
-                    uint2 d = make_uint2(0u, 0u);
-                    if (idx < n_list) d = list[idx];
-                    const SegView sv = seg_view(d, ql);
-                    for (uint32_t u = sv.ub; u <= sv.u1; u += 12u) {
-                        // three units per lane and trip: u, u+4, u+8 (a unit past the end is clamped
-                        // onto the last one and gets an empty mask)
-                        Q16 v[3];
-                        uint32_t uu[3];
+                // MODE 0: 8-bit two-set counters, 1: 16-bit fields, 2: 32-bit words (DEEP)
+                auto consume = [&](auto mode_tag) {
+                    constexpr int MODE = decltype(mode_tag)::value;
+                    for (uint32_t i = 0; i < Q; ++i) {
+                        const uint32_t idx = quad * Q + i;
+                        uint2 d = make_uint2(0u, 0u);
+                        if (idx < n_list) d = list[idx];
+                        const SegView sv = seg_view(d, ql);
+                        // three units per lane and trip: u, u+4, u+8; a unit past the end is clamped
+                        // onto the last one and gets an empty mask
+                        for (uint32_t u = sv.ub; u <= sv.u1; u += 12u) {
+                            Q16 v[3];
+                            uint32_t uu[3];
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const uint32_t un = u + 4u * j;
-                            uu[j] = un < sv.u1 ? un : sv.u1;
-                            __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
-                        }
+                            for (int j = 0; j < 3; ++j) {
+                                const uint32_t un = u + 4u * j;
+                                uu[j] = un < sv.u1 ? un : sv.u1;
+                                __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
+                            }
 #pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            const uint32_t ps = uu[j] << 4;
-                            const uint32_t vs = sv.srel > ps ? sv.srel - ps : 0u;
-                            const uint32_t ve = (sv.trel - ps) < 16u ? (sv.trel - ps) : 16u;
-                            const uint32_t m = ((1u << ve) - 1u) & ~((1u << vs) - 1u);
-                            const uint32_t pm = (sv.on && u + 4u * j <= sv.u1) ? m : 0u;
-                            if (DEEP) sq32 += apply_unit32<ORF>(v[j], pm, uu[j], s_qcw, a.o);
-                            else if (mode8) sq32 += apply_unit8<ORF>(v[j], pm, uu[j], sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                            else sq32 += apply_unit16<ORF>(v[j], pm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                            for (int j = 0; j < 3; ++j) {
+                                const uint32_t ps = uu[j] << 4;
+                                const uint32_t vs = sv.srel > ps ? sv.srel - ps : 0u;
+                                uint32_t ve = (sv.trel - ps) < 16u ? (sv.trel - ps) : 16u;
+                                ve = (sv.on && u + 4u * j <= sv.u1) ? ve : 0u;
+                                const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                                const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                                if (MODE == 2) sq32 += apply_unit32<ORF>(v[j], vm, uu[j], s_qcw, a.o);
+                                else if (MODE == 0) sq32 += apply_unit8<ORF>(v[j], vm, uu[j], sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                                else sq32 += apply_unit16<ORF>(v[j], vm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                            }
                         }
                     }
-                }
+                };
+                if (DEEP) consume(std::integral_constant<int, 2>{});
+                else if (mode8) consume(std::integral_constant<int, 0>{});
+                else consume(std::integral_constant<int, 1>{});
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();       // the list is rewritten in the next round

@@ -123,13 +123,13 @@ cl_status fail(cl_ctx *c, cl_status s, const std::string &m)
     } while (0)
 
 // constants of the byte-parallel quality threshold (kernels.hip.h qual_ge)
-void make_ge_consts(uint8_t T, Opts &o)
+void make_ge_consts(uint8_t T, uint32_t &ge_add, uint32_t &ge_or, uint32_t &ge_and)
 {
     uint32_t add;
-    if (T == 0) { add = 0x80u; o.ge_or = 0xFFFFFFFFu; o.ge_and = 0xFFFFFFFFu; }
-    else if (T <= 128) { add = 128u - T; o.ge_or = 0xFFFFFFFFu; o.ge_and = 0xFFFFFFFFu; }
-    else { add = 256u - T; o.ge_or = 0u; o.ge_and = 0u; }
-    o.ge_add = add * 0x01010101u;
+    if (T == 0) { add = 0x80u; ge_or = 0xFFFFFFFFu; ge_and = 0xFFFFFFFFu; }
+    else if (T <= 128) { add = 128u - T; ge_or = 0xFFFFFFFFu; ge_and = 0xFFFFFFFFu; }
+    else { add = 256u - T; ge_or = 0u; ge_and = 0u; }
+    ge_add = add * 0x01010101u;
 }
 
 // lut[raw] = smallest low_mapq_count with (low as f64 / raw as f64) > max_low_mapq_fraction
@@ -302,7 +302,11 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     o.min_depth = opt->min_depth; o.max_depth = opt->max_depth; o.min_mapq = opt->min_mapping_quality;
     o.min_depth_for_low_mapq = opt->min_depth_for_low_mapq; o.max_low_mapq = opt->max_low_mapq;
     o.max_low_mapq_fraction = opt->max_low_mapq_fraction;
-    make_ge_consts(opt->min_base_quality, o);
+    make_ge_consts(opt->min_base_quality, o.ge_add, o.ge_or, o.ge_and);
+    o.md_all = opt->min_depth > 255 ? 1u : 0u;
+    make_ge_consts((uint8_t)(opt->min_depth > 255 ? 255 : opt->min_depth), o.md_add, o.md_or, o.md_and);
+    o.xd_on = (opt->max_depth >= 1 && opt->max_depth <= 254) ? 1u : 0u;
+    make_ge_consts((uint8_t)(o.xd_on ? opt->max_depth + 1 : 255), o.xd_add, o.xd_or, o.xd_and);
     std::vector<uint32_t> lut;
     build_lut(opt->max_low_mapq_fraction, lut);
     bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepBlocks) == hipSuccess &&

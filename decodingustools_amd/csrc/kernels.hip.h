@@ -74,6 +74,10 @@ struct Opts {
     double   max_low_mapq_fraction;
     // byte-parallel "quality >= min_base_quality" constants (see qual_ge)
     uint32_t ge_add, ge_or, ge_and;
+    // the same for "qc_depth >= min_depth" (md_all: min_depth > 255, every byte-sized count is below)
+    // and "qc_depth >= max_depth + 1" (xd_on: max_depth in 1..254), used by the byte-parallel final phase
+    uint32_t md_add, md_or, md_and, md_all;
+    uint32_t xd_add, xd_or, xd_and, xd_on;
 };
 
 struct Reads {
@@ -226,6 +230,13 @@ __device__ __forceinline__ uint32_t qual_ge(uint32_t x, const Opts &o)
     return ((d | (x & o.ge_or)) & (x | o.ge_and)) & 0x80808080u;
 }
 
+// the same test for any byte threshold given its three constants: 0x80 per byte >= threshold
+__device__ __forceinline__ uint32_t swar_ge7(uint32_t q, uint32_t add, uint32_t orm, uint32_t andm)
+{
+    const uint32_t d = (q & 0x7f7f7f7fu) + add;
+    return ((d | (q & orm)) & (q | andm)) & 0x80808080u;
+}
+
 struct __attribute__((packed, aligned(1))) Q16 { uint32_t w[4]; };
 
 struct PileupArgs {
@@ -360,7 +371,7 @@ template <int T, bool DEBUG, bool ORF, bool DEEP>
 __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
-    static_assert(PER == 8, "T must be 2048");
+    static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
     constexpr int kWaves = kBlock / 64;
     constexpr int kSegRound = 2;                    // segments a lane may emit per round
     constexpr int kListCap = 64 * kSegRound;        // entries of one wave's list
@@ -395,7 +406,9 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
     const uint8_t *qbase = a.R.qual + qwin - kQualPad;
 
     // reference bytes of this thread's positions: needed last, requested first
-    const uint2 refv = *reinterpret_cast<const uint2 *>(a.ref + p0);
+    uint32_t refw[PER / 4];
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
 
     // ---- clear ----
     {
@@ -569,28 +582,19 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
             if (lane >= (uint32_t)o) { ir += tr; il += tl; }
         }
         if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
-        // qc_depth of the thread's positions
-        uint32_t qc[PER];
-        if (DEEP) {
+        // 8-bit mode: the thread's PER positions are PER consecutive bytes of entry 2u+h (8 positions
+        // each) of the two counter sets
+        uint32_t qc8a[PER / 4], qc8b[PER / 4];
 #pragma unroll
-            for (int i = 0; i < PER; ++i) qc[i] = s_qcw[tid * PER + i];
-        } else if (mode8) {
-            const uint2 *q2 = reinterpret_cast<const uint2 *>(s_qcw);
-            const uint32_t u = tid >> 1, e = (u << 1) | ((tid & 1u) ^ ((u >> 3) & 1u));   // entry 2u+h of the thread's 8 positions
-            const uint2 ca = q2[e], cb = q2[T / 8 + e];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                qc[i] = ((ca.x >> (8 * i)) & 0xFFu) + ((cb.x >> (8 * i)) & 0xFFu);
-                qc[4 + i] = ((ca.y >> (8 * i)) & 0xFFu) + ((cb.y >> (8 * i)) & 0xFFu);
-            }
-        } else {
-            const uint2 *q2 = reinterpret_cast<const uint2 *>(s_qcw);
+        for (int h = 0; h < PER / 4; ++h) { qc8a[h] = 0; qc8b[h] = 0; }
+        if (!DEEP && mode8) {
+            const uint32_t ent = (tid * PER) >> 3, u = ent >> 1;
+            const uint32_t e = (u << 1) | ((ent & 1u) ^ ((u >> 3) & 1u));
 #pragma unroll
             for (int h = 0; h < PER / 4; ++h) {
-                const uint32_t e = tid * (PER / 4) + h;                 // entry 4u+jj: u = e>>2, jj = e&3
-                const uint2 c = q2[(e & ~3u) | ((e & 3u) ^ ((e >> 4) & 3u))];
-                qc[4 * h + 0] = c.x & 0xFFFFu; qc[4 * h + 1] = c.x >> 16;
-                qc[4 * h + 2] = c.y & 0xFFFFu; qc[4 * h + 3] = c.y >> 16;
+                const uint32_t wsel = PER == 8 ? (uint32_t)h : (tid & 1u);          // which half of the entry
+                qc8a[h] = s_qcw[2u * e + wsel];
+                qc8b[h] = s_qcw[2u * (T / 8 + e) + wsel];
             }
         }
         __syncthreads();
@@ -599,68 +603,124 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
         uint32_t mx = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) { vr[i] += offr; vl[i] += offl; mx = vr[i] > mx ? vr[i] : mx; }
-        // low-MAPQ rule, callable_profiler.rs:100-101
-        uint32_t lowbits = 0;
-        if (mx < kLutLds) {
+        const uint32_t n_ok = p0 >= a.extent ? 0u : (a.extent - p0 < (uint32_t)PER ? a.extent - p0 : (uint32_t)PER);
+
+        uint32_t S[PER / 4];                        // state bytes of the thread's positions
+        uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, ncov = 0;
+        unsigned long long sqc = 0;
+        if (!DEEP && mode8 && mx < kLutLds && n_ok == (uint32_t)PER) {
+            // ---- byte-parallel path: every column is shallower than 256, so qc_depth (<= raw_depth)
+            //      fits a byte and four positions are classified per 32-bit word ----
+            const uint32_t ONES = 0x01010101u;
 #pragma unroll
-            for (int i = 0; i < PER; ++i) lowbits |= (vl[i] >= (uint32_t)s_lut[vr[i]] ? 1u : 0u) << i;
+            for (int h = 0; h < PER / 4; ++h) {
+                const uint32_t q4 = qc8a[h] + qc8b[h];                       // no byte can carry
+                uint32_t cov = 0, low = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t raw = vr[4 * h + i];
+                    cov |= (raw < 1u ? raw : 1u) << (8 * i);
+                    // low-MAPQ rule through the table (callable_profiler.rs:100-101)
+                    low |= (vl[4 * h + i] >= (uint32_t)s_lut[raw] ? 1u : 0u) << (8 * i);
+                }
+                const uint32_t x = (refw[h] | 0x20202020u) ^ 0x6e6e6e6eu;   // zero byte <=> 'N' or 'n'
+                const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7;
+                const uint32_t N = ~nz & ONES;
+                uint32_t lt = ONES;                                          // qc < min_depth
+                if (!a.o.md_all) lt = ~(swar_ge7(q4, a.o.md_add, a.o.md_or, a.o.md_and) >> 7) & ONES;
+                uint32_t gt = 0;                                             // qc > max_depth (max_depth in 1..254)
+                if (a.o.xd_on) gt = swar_ge7(q4, a.o.xd_add, a.o.xd_or, a.o.xd_and) >> 7;
+                // priorities of callable_profiler.rs:104-116, resolved into disjoint flags
+                const uint32_t t0 = ~N & cov;
+                const uint32_t rLow = t0 & low, t1 = t0 & ~low;
+                const uint32_t rLT = t1 & lt, t2 = t1 & ~lt;
+                const uint32_t rGT = t2 & gt, rC = t2 & ~gt;
+                const uint32_t rNC = ~N & ~cov & ONES;
+                S[h] = rC + (rNC << 1) + rLT + (rLT << 1) + (rGT << 2) + rLow + (rLow << 2);
+                cnt[0] += __popc(N); cnt[1] += __popc(rC); cnt[2] += __popc(rNC);
+                cnt[3] += __popc(rLT); cnt[4] += __popc(rGT); cnt[5] += __popc(rLow);
+                ncov += __popc(cov);
+                sqc += __builtin_amdgcn_udot4(q4, ONES, 0u, false);
+                if (DEBUG) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        if (a.dbg_raw) a.dbg_raw[p0 + 4 * h + i] = vr[4 * h + i];
+                        if (a.dbg_low) a.dbg_low[p0 + 4 * h + i] = vl[4 * h + i];
+                        if (a.dbg_qc) a.dbg_qc[p0 + 4 * h + i] = (q4 >> (8 * i)) & 0xFFu;
+                    }
+                }
+            }
         } else {
+            // ---- general path, one position at a time ----
+            uint32_t qc[PER];
+            if (DEEP) {
+#pragma unroll
+                for (int i = 0; i < PER; ++i) qc[i] = s_qcw[tid * PER + i];
+            } else if (mode8) {
+#pragma unroll
+                for (int i = 0; i < PER; ++i)
+                    qc[i] = ((qc8a[i >> 2] >> (8 * (i & 3))) & 0xFFu) + ((qc8b[i >> 2] >> (8 * (i & 3))) & 0xFFu);
+            } else {
+                const uint2 *q2 = reinterpret_cast<const uint2 *>(s_qcw);
+#pragma unroll
+                for (int h = 0; h < PER / 4; ++h) {
+                    const uint32_t e = tid * (PER / 4) + h;                 // entry 4u+jj: u = e>>2, jj = e&3
+                    const uint2 c = q2[(e & ~3u) | ((e & 3u) ^ ((e >> 4) & 3u))];
+                    qc[4 * h + 0] = c.x & 0xFFFFu; qc[4 * h + 1] = c.x >> 16;
+                    qc[4 * h + 2] = c.y & 0xFFFFu; qc[4 * h + 3] = c.y >> 16;
+                }
+            }
+            uint32_t st[PER];
             for (int i = 0; i < PER; ++i) {
                 const uint32_t raw = vr[i], low = vl[i];
-                bool is_low = false;
+                bool is_low = false;                                                  // callable_profiler.rs:100-101
                 if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
                     if (raw < kLutSize) is_low = low >= a.lut[raw];
                     else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
                 }
-                lowbits |= (is_low ? 1u : 0u) << i;
+                const uint32_t rb = (refw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                uint32_t sx = 1u;                                                     // CALLABLE
+                sx = (a.o.max_depth > 0 && qc[i] > a.o.max_depth) ? 4u : sx;          // EXCESSIVE_COVERAGE
+                sx = qc[i] < a.o.min_depth ? 3u : sx;                                 // LOW_COVERAGE
+                sx = is_low ? 5u : sx;                                                // POOR_MAPPING_QUALITY
+                sx = raw == 0 ? 2u : sx;                                              // NO_COVERAGE
+                sx = ((rb | 0x20u) == 'n') ? 0u : sx;                                 // REF_N
+                const bool ok = (uint32_t)i < n_ok;
+                if (ok) { cnt[sx] += 1; ncov += raw > 0 ? 1u : 0u; sqc += qc[i]; }
+                st[i] = ok ? sx : 0xFFu;
+                if (DEBUG) {
+                    if (a.dbg_raw) a.dbg_raw[p0 + i] = raw;
+                    if (a.dbg_low) a.dbg_low[p0 + i] = low;
+                    if (a.dbg_qc) a.dbg_qc[p0 + i] = qc[i];
+                }
             }
-        }
-        // state, callable_profiler.rs:104-116 (later tests have priority, so apply them last)
-        uint32_t st[PER];
-        uint32_t cnt4 = 0, ncov = 0;                // six 4-bit fields (at most 8 each)
-        unsigned long long sqc = 0;
-        const uint32_t n_ok = p0 >= a.extent ? 0u : (a.extent - p0 < (uint32_t)PER ? a.extent - p0 : (uint32_t)PER);
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            const uint32_t rb = ((i < 4 ? refv.x : refv.y) >> (8 * (i & 3))) & 0xFFu;
-            uint32_t s = 1u;                                                      // CALLABLE
-            s = (a.o.max_depth > 0 && qc[i] > a.o.max_depth) ? 4u : s;            // EXCESSIVE_COVERAGE
-            s = qc[i] < a.o.min_depth ? 3u : s;                                   // LOW_COVERAGE
-            s = ((lowbits >> i) & 1u) ? 5u : s;                                   // POOR_MAPPING_QUALITY
-            s = vr[i] == 0 ? 2u : s;                                              // NO_COVERAGE
-            s = ((rb | 0x20u) == 'n') ? 0u : s;                                   // REF_N
-            const bool ok = (uint32_t)i < n_ok;
-            cnt4 += ok ? (1u << (4u * s)) : 0u;
-            ncov += (ok && vr[i] > 0) ? 1u : 0u;
-            sqc += ok ? qc[i] : 0u;
-            st[i] = ok ? s : 0xFFu;
-            if (DEBUG) {
-                if (a.dbg_raw) a.dbg_raw[p0 + i] = vr[i];
-                if (a.dbg_low) a.dbg_low[p0 + i] = vl[i];
-                if (a.dbg_qc) a.dbg_qc[p0 + i] = qc[i];
-            }
+            for (int h = 0; h < PER / 4; ++h)
+                S[h] = st[4 * h] | (st[4 * h + 1] << 8) | (st[4 * h + 2] << 16) | (st[4 * h + 3] << 24);
         }
         // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
-        s_last[tid] = (uint8_t)st[PER - 1];
+        s_last[tid] = (uint8_t)(S[PER / 4 - 1] >> 24);
         mx = wave_max_u32(mx);
         if (lane == 0) s_wmax[wv] = mx;
         __syncthreads();
         uint32_t nb = 0;
-        uint32_t prev = tid > 0 ? s_last[tid - 1] : st[0];
+        {
+            uint32_t prevb = tid > 0 ? (uint32_t)s_last[tid - 1] : (S[0] & 0xFFu);
+            const uint4 okm = s_mend[n_ok];                                  // 0x01 for the positions < extent
+            const uint32_t okw[2] = {okm.x, okm.y};
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            nb += ((uint32_t)i < n_ok && st[i] != prev) ? 1u : 0u;
-            prev = st[i];
+            for (int h = 0; h < PER / 4; ++h) {
+                const uint32_t P = (S[h] << 8) | prevb;
+                const uint32_t d = S[h] ^ P;
+                nb += __popc(((((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) >> 7) & okw[h]);
+                prevb = S[h] >> 24;
+            }
         }
-        uint2 sv;
-        sv.x = st[0] | (st[1] << 8) | (st[2] << 16) | (st[3] << 24);
-        sv.y = st[4] | (st[5] << 8) | (st[6] << 16) | (st[7] << 24);
-        *reinterpret_cast<uint2 *>(a.state + p0) = sv;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const uint32_t v = (cnt4 >> (4 * c)) & 15u;
-            if (v) atomicAdd(&s_acc[c], (unsigned long long)v);
-        }
+        for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (cnt[c]) atomicAdd(&s_acc[c], (unsigned long long)cnt[c]);
         if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
         if (sqc) atomicAdd(&s_acc[7], sqc);
         if (sumq) atomicAdd(&s_acc[8], sumq);
@@ -820,19 +880,12 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint8_t *__restrict_
     const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t p0 = w * (uint32_t)T + tid * PER;
     uint8_t st[PER];
-    if (PER >= 16) {
+    static_assert(PER % 4 == 0, "window / threads must be a multiple of 4");
 #pragma unroll
-        for (int i = 0; i < PER; i += 16) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(state + p0 + i);
-            const uint32_t ww[4] = {v.x, v.y, v.z, v.w};
+    for (int h = 0; h < PER / 4; ++h) {
+        const uint32_t v = reinterpret_cast<const uint32_t *>(state + p0)[h];
 #pragma unroll
-            for (int j = 0; j < 16; ++j) st[i + j] = (uint8_t)(ww[j >> 2] >> (8 * (j & 3)));
-        }
-    } else {
-        const uint2 v = *reinterpret_cast<const uint2 *>(state + p0);
-        const uint32_t ww[2] = {v.x, v.y};
-#pragma unroll
-        for (int j = 0; j < 8; ++j) st[j] = (uint8_t)(ww[j >> 2] >> (8 * (j & 3)));
+        for (int j = 0; j < 4; ++j) st[4 * h + j] = (uint8_t)(v >> (8 * j));
     }
     uint32_t prev = p0 > 0 ? state[p0 - 1] : 0x100u;   // position 0 always starts a run
     uint32_t flags = 0, c = 0;

@@ -212,8 +212,8 @@ __global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPar
     win_q0[w] = R.qual_off[lo];                    // lo <= n: the offsets array has n+1 entries
     // k_pileup addresses the quality bytes of a window with 32-bit offsets
     if (hi > lo && R.qual_off[hi] - R.qual_off[lo] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
-    // more reads than the 16-bit qc_depth counters of k_pileup can hold: the 32-bit variant is needed
-    if (hi - lo > 65535u) atomicOr(err_flag, kNeedDeep);
+    // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
+    if (hi - lo > 32767u) atomicOr(err_flag, kNeedDeep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -276,7 +276,7 @@ struct PileupArgs {
 // Reads are dealt to waves round-robin (read = base + 4*lane + wave) so that the segments a
 // wave's 16 quads work on at the same time are ~16 reads apart and never share a counter word.
 //
-// DEEP = false: 16-bit counters; valid while the window is touched by <= 65535 reads (otherwise
+// DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window is touched by <= 32767 reads (otherwise
 // k_window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one 32-bit
 // counter per position).
 // ---------------------------------------------------------------------------------------------
@@ -365,10 +365,10 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 }
 
 #ifndef CL_MINWAVES
-#define CL_MINWAVES 6
+#define CL_MINWAVES 8
 #endif
 template <int T, bool DEBUG, bool ORF, bool DEEP>
-__global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(PileupArgs a)
+__global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
@@ -376,8 +376,13 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
     constexpr int kSegRound = 2;                    // segments a lane may emit per round
     constexpr int kListCap = 64 * kSegRound;        // entries of one wave's list
     constexpr uint32_t kLutLds = 256;
-    __shared__ __attribute__((aligned(16))) uint32_t s_raw[T];     // +-1 differences, then unused
-    __shared__ __attribute__((aligned(16))) uint32_t s_low[T];
+    // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
+    // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
+    // subtraction of 1 from the whole word) never borrows from the high half; exact while the window
+    // is touched by < 32768 reads (k_window_bounds raises kNeedDeep beyond that).
+    constexpr int kDiffWords = DEEP ? T : T / 2;
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_low[kDiffWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_qcw[DEEP ? T : T / 2];   // qc_depth counters
     __shared__ __attribute__((aligned(8))) uint2 s_list[kWaves][kListCap];
     __shared__ uint16_t s_lut[kLutLds];             // low-mapq threshold for raw < 256 (0xFFFF = never)
@@ -415,7 +420,8 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
         const uint4 z = make_uint4(0, 0, 0, 0);
         uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low),
               *q4 = reinterpret_cast<uint4 *>(s_qcw);
-        for (int i = tid; i < T / 4; i += kBlock) { r4[i] = z; l4[i] = z; }
+        const uint4 zb = DEEP ? z : make_uint4(0x8000u, 0x8000u, 0x8000u, 0x8000u);
+        for (int i = tid; i < kDiffWords / 4; i += kBlock) { r4[i] = zb; l4[i] = zb; }
         for (int i = tid; i < (DEEP ? T : T / 2) / 4; i += kBlock) q4[i] = z;
         if (tid < 10) s_acc[tid] = 0;
         if (tid < 34) {
@@ -460,11 +466,17 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
             qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
             if (e > W) {
                 const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
-                atomicAdd(&s_raw[cb], 1u);
-                if (ce < (uint32_t)T) atomicAdd(&s_raw[ce], 0xFFFFFFFFu);
+                uint32_t ib, vb, ie, ve2;            // word index and addend of the +1 and of the -1
+                if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
+                else {
+                    ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
+                    ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                }
+                atomicAdd(&s_raw[ib], vb);
+                if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
                 if (mq <= a.o.max_low_mapq) {
-                    atomicAdd(&s_low[cb], 1u);
-                    if (ce < (uint32_t)T) atomicAdd(&s_low[ce], 0xFFFFFFFFu);
+                    atomicAdd(&s_low[ib], vb);
+                    if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
                 }
                 live = mq >= a.o.min_mapq && k < k1;
             }
@@ -571,10 +583,22 @@ __global__ __launch_bounds__(kBlock, DEEP ? 5 : CL_MINWAVES) void k_pileup(Pileu
     {
         uint32_t vr[PER], vl[PER];
         uint32_t sr = 0, sl = 0;
+        if (DEEP) {
 #pragma unroll
-        for (int i = 0; i < PER; ++i) {
-            sr += s_raw[tid * PER + i]; vr[i] = sr;
-            sl += s_low[tid * PER + i]; vl[i] = sl;
+            for (int i = 0; i < PER; ++i) {
+                sr += s_raw[tid * PER + i]; vr[i] = sr;
+                sl += s_low[tid * PER + i]; vl[i] = sl;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < PER / 2; ++h) {
+                const uint32_t wr = s_raw[tid * (PER / 2) + h], wl = s_low[tid * (PER / 2) + h];
+                // low half: biased by 0x8000; high half: two's complement 16-bit
+                sr += (wr & 0xFFFFu) - 0x8000u; vr[2 * h] = sr;
+                sr += (uint32_t)((int32_t)wr >> 16); vr[2 * h + 1] = sr;
+                sl += (wl & 0xFFFFu) - 0x8000u; vl[2 * h] = sl;
+                sl += (uint32_t)((int32_t)wl >> 16); vl[2 * h + 1] = sl;
+            }
         }
         uint32_t ir = sr, il = sl;
         for (int o = 1; o < 64; o <<= 1) {

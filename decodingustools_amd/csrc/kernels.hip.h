@@ -391,7 +391,9 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
     __shared__ __attribute__((aligned(16))) uint4 s_mstart[17], s_mend[17];
     __shared__ uint32_t s_wraw[kWaves], s_wlow[kWaves], s_wmax[kWaves];
     __shared__ uint8_t s_last[kBlock];
-    __shared__ unsigned long long s_acc[10];        // cnt[6], n_cov, sum_qc, sum_q, n_inner
+    // per-wave totals: cnt[6], n_cov, sum_qc, sum_q, n_inner.  (Same-address LDS atomics are avoided:
+    // hipcc turns them into a scalar loop over the active lanes.)
+    __shared__ unsigned long long s_wtot[kWaves][10];
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
     // each XCD one contiguous range of windows so neighbouring windows share its L2.
@@ -423,7 +425,6 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
         const uint4 zb = DEEP ? z : make_uint4(0x8000u, 0x8000u, 0x8000u, 0x8000u);
         for (int i = tid; i < kDiffWords / 4; i += kBlock) { r4[i] = zb; l4[i] = zb; }
         for (int i = tid; i < (DEEP ? T : T / 2) / 4; i += kBlock) q4[i] = z;
-        if (tid < 10) s_acc[tid] = 0;
         if (tid < 34) {
             const uint32_t e = tid < 17 ? tid : tid - 17;                       // vs or ve
             const uint32_t bits = tid < 17 ? (0xFFFFu & ~((1u << e) - 1u)) : ((1u << e) - 1u);
@@ -742,20 +743,48 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
         }
 #pragma unroll
         for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
+        if (mode8) {
+            // <= 510 reads: a thread's counts are <= 8 and every wave total fits 10 bits (sum_qc 17,
+            // sum_q 29): five packed words, one butterfly reduction each
+            uint32_t pk[5];
+            pk[0] = cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
+            pk[1] = cnt[3] | (cnt[4] << 10) | (cnt[5] << 20);
+            pk[2] = ncov | (nb << 10);
+            pk[3] = (uint32_t)sqc;
+            pk[4] = (uint32_t)sumq;
 #pragma unroll
-        for (int c = 0; c < 6; ++c)
-            if (cnt[c]) atomicAdd(&s_acc[c], (unsigned long long)cnt[c]);
-        if (ncov) atomicAdd(&s_acc[6], (unsigned long long)ncov);
-        if (sqc) atomicAdd(&s_acc[7], sqc);
-        if (sumq) atomicAdd(&s_acc[8], sumq);
-        if (nb) atomicAdd(&s_acc[9], (unsigned long long)nb);
+            for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+                for (int c = 0; c < 5; ++c) pk[c] += __shfl_xor(pk[c], o, 64);
+            }
+            if (lane == 0) {
+                unsigned long long *t = s_wtot[wv];
+                t[0] = pk[0] & 1023u; t[1] = (pk[0] >> 10) & 1023u; t[2] = pk[0] >> 20;
+                t[3] = pk[1] & 1023u; t[4] = (pk[1] >> 10) & 1023u; t[5] = pk[1] >> 20;
+                t[6] = pk[2] & 1023u; t[9] = pk[2] >> 10;
+                t[7] = pk[3]; t[8] = pk[4];
+            }
+        } else {
+            // denser windows: totals may pass 2^32
+            unsigned long long v[10];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) v[c] = cnt[c];
+            v[6] = ncov; v[7] = sqc; v[8] = sumq; v[9] = nb;
+#pragma unroll
+            for (int c = 0; c < 10; ++c) {
+                const unsigned long long r = wave_sum_u64(v[c]);
+                if (lane == 0) s_wtot[wv][c] = r;
+            }
+        }
     }
     __syncthreads();
     if (tid == 0) {
         WinPartial wp;
-        for (int c = 0; c < 6; ++c) wp.cnt[c] = s_acc[c];
-        wp.n_cov = s_acc[6]; wp.sum_qc = s_acc[7]; wp.sum_q = s_acc[8];
-        wp.n_inner = (uint32_t)s_acc[9];
+        unsigned long long tot[10];
+        for (int c = 0; c < 10; ++c) { tot[c] = 0; for (int i = 0; i < kWaves; ++i) tot[c] += s_wtot[i][c]; }
+        for (int c = 0; c < 6; ++c) wp.cnt[c] = tot[c];
+        wp.n_cov = tot[6]; wp.sum_qc = tot[7]; wp.sum_q = tot[8];
+        wp.n_inner = (uint32_t)tot[9];
         uint32_t m = 0;
         for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
         wp.max_raw = m;

@@ -127,28 +127,44 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
     __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
     unsigned long long sum_len = 0, sum_mq = 0;
     uint32_t max_span = 0, max_end = 0, err = 0;
-    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < R.n; r += gridDim.x * kBlock) {
-        const uint32_t k0 = R.cigar_off[r], k1 = R.cigar_off[r + 1];
-        unsigned long long reflen = 0;
-        for (uint32_t k = k0; k < k1; ++k) {
-            const uint32_t c = R.cigar[k], op = c & 15u, l = c >> 4;
-            if (op_match(op) || op_del(op)) {
-                reflen += l;
-                if (l == 0) err |= kErrCigar;          // zero-length reference-consuming op
-            }
+    // four reads per thread and trip: all their loads are issued before any is used
+    constexpr int U = 4;
+    const uint32_t stride = gridDim.x * kBlock;
+    for (uint32_t r0 = blockIdx.x * kBlock + threadIdx.x; r0 < R.n; r0 += U * stride) {
+        uint32_t k0[U], k1[U], ps[U], mq[U], c0[U];
+        bool in[U];
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            const uint32_t r = r0 + i * stride;
+            in[i] = r < R.n;
+            const uint32_t rr = in[i] ? r : r0;
+            k0[i] = R.cigar_off[rr]; k1[i] = R.cigar_off[rr + 1]; ps[i] = (uint32_t)R.pos[rr]; mq[i] = R.mapq[rr];
         }
-        // a read that reaches a column with a single non-match op is undefined in htslib
-        if (reflen > 0 && k1 - k0 == 1 && !op_match(R.cigar[k0] & 15u)) err |= kErrCigar;
-        const unsigned long long e = (unsigned long long)(uint32_t)R.pos[r] + reflen;
-        if (e > 0xFFFF0000ull) { err |= kErrRange; }
-        const uint32_t e32 = e > 0xFFFF0000ull ? (uint32_t)R.pos[r] : (uint32_t)e;
-        end_out[r] = e32;
-        const uint32_t span = e32 - (uint32_t)R.pos[r];
-        sum_len += span;
-        const uint32_t mq = R.mapq[r];
-        if (mq >= o.min_mapq) sum_mq += (unsigned long long)mq * span;
-        max_span = span > max_span ? span : max_span;
-        max_end = e32 > max_end ? e32 : max_end;
+#pragma unroll
+        for (int i = 0; i < U; ++i) c0[i] = k0[i] < k1[i] ? R.cigar[k0[i]] : 0u;
+#pragma unroll
+        for (int i = 0; i < U; ++i) {
+            if (!in[i]) continue;
+            unsigned long long reflen = 0;
+            for (uint32_t k = k0[i]; k < k1[i]; ++k) {
+                const uint32_t c = k == k0[i] ? c0[i] : R.cigar[k], op = c & 15u, l = c >> 4;
+                if (op_match(op) || op_del(op)) {
+                    reflen += l;
+                    if (l == 0) err |= kErrCigar;          // zero-length reference-consuming op
+                }
+            }
+            // a read that reaches a column with a single non-match op is undefined in htslib
+            if (reflen > 0 && k1[i] - k0[i] == 1 && !op_match(c0[i] & 15u)) err |= kErrCigar;
+            const unsigned long long e = (unsigned long long)ps[i] + reflen;
+            if (e > 0xFFFF0000ull) { err |= kErrRange; }
+            const uint32_t e32 = e > 0xFFFF0000ull ? ps[i] : (uint32_t)e;
+            end_out[r0 + i * stride] = e32;
+            const uint32_t span = e32 - ps[i];
+            sum_len += span;
+            if (mq[i] >= o.min_mapq) sum_mq += (unsigned long long)mq[i] * span;
+            max_span = span > max_span ? span : max_span;
+            max_end = e32 > max_end ? e32 : max_end;
+        }
     }
     sum_len = wave_sum_u64(sum_len);
     sum_mq = wave_sum_u64(sum_mq);

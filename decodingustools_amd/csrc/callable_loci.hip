@@ -56,6 +56,7 @@ struct cl_ctx {
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
     bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
+    bool has_long = false;           // some read has more than kLongOps CIGAR ops (k_read_prep_long needed)
     int32_t tid = 0;
     uint32_t contig_len = 0;
     std::vector<uint8_t> h_ref;
@@ -82,7 +83,8 @@ struct cl_ctx {
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
     DevBuf<uint32_t> d_blk_off;
-    DevBuf<uint32_t> d_errflag;
+    DevBuf<uint32_t> d_errflag;        // [0] error bits of k_window_bounds, [1] number of long reads
+    DevBuf<uint32_t> d_long_list, d_ck_x, d_ck_y;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
     DevBuf<Interval> d_iv;
@@ -228,19 +230,23 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
     R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
 
-    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, sizeof(uint32_t), c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
-                       c->d_end.p, c->d_prep.p);
+                       c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p);
+    if (c->has_long)
+        hipLaunchKernelGGL(k_read_prep_long, dim3(kLongBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
+                           c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p, c->d_ck_x.p, c->d_ck_y.p);
+    const uint32_t n_parts = c->has_long ? (uint32_t)kPrepParts : (uint32_t)kPrepBlocks;
     if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     if (c->n_win) {
         hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                           c->stream, R, c->d_prep.p, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p, c->d_win_q0.p, c->d_errflag.p);
+                           c->stream, R, c->d_prep.p, n_parts, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p, c->d_win_q0.p, c->d_errflag.p);
     }
     if (prof) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     PileupArgs a;
     a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p; a.win_q0 = c->d_win_q0.p;
-    a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
+    a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
     {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
@@ -254,7 +260,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
         hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_state.p,
                            kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
     hipLaunchKernelGGL(k_fin_summary, dim3(1), dim3(kBlock), 0, c->stream, c->d_fin.p, n_fin, c->d_prep.p,
-                       (uint32_t)kPrepBlocks, c->extent, c->d_errflag.p, c->d_blk_off.p, c->d_summary.p);
+                       n_parts, c->extent, c->d_errflag.p, c->d_blk_off.p, c->d_summary.p);
     if (c->n_win) {
         hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream,
                            c->d_state.p, c->d_win_off.p, c->d_blk_off.p, c->n_win, c->extent, c->d_iv.p,
@@ -309,8 +315,8 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     make_ge_consts((uint8_t)(o.xd_on ? opt->max_depth + 1 : 255), o.xd_add, o.xd_or, o.xd_and);
     std::vector<uint32_t> lut;
     build_lut(opt->max_low_mapq_fraction, lut);
-    bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepBlocks) == hipSuccess &&
-              c->d_summary.reserve(1) == hipSuccess && c->d_errflag.reserve(1) == hipSuccess &&
+    bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepParts) == hipSuccess &&
+              c->d_summary.reserve(1) == hipSuccess && c->d_errflag.reserve(2) == hipSuccess &&
               hipMemcpy(c->d_lut.p, lut.data(), kLutSize * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok) { cl_destroy(c); return CL_ERR_DEVICE; }
     *out = c;
@@ -326,7 +332,7 @@ void cl_destroy(cl_ctx *c)
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
     c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release(); c->d_errflag.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
@@ -348,7 +354,7 @@ cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uin
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_qual.clear();
     c->h_cigar_off.assign(1, 0u); c->h_qual_off.assign(1, 0ull);
     c->h_iv.clear();
-    c->in_contig = true; c->uploaded = false; c->ran = false;
+    c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
 
@@ -370,6 +376,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
         last = p;
         if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i])
             return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+        if (t->cigar_off[i + 1] - t->cigar_off[i] > kLongOps) c->has_long = true;
     }
     const uint32_t cig0 = t->cigar_off[0];
     const uint64_t ncig = (uint64_t)t->cigar_off[n] - cig0;
@@ -412,6 +419,9 @@ cl_status cl_contig_upload(cl_ctx *c)
     HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
     HIP_TRY(c, c->d_qual_off.reserve(n + 1));
     HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 1));
+    HIP_TRY(c, c->d_long_list.reserve(n + 1));
+    HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
+    HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_qual.reserve(c->n_qual + 2 * kQualPad));
     if (n) {
         HIP_TRY(c, hipMemcpyAsync(c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));

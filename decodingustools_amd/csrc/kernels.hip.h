@@ -22,6 +22,10 @@ namespace clk {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kPrepBlocks = 4096;    // grid of k_read_prep (grid-stride)
+constexpr int kLongBlocks = 512;     // grid of k_read_prep_long (one wave per long read)
+constexpr int kPrepParts = kPrepBlocks + kLongBlocks;
+constexpr uint32_t kLongOps = 64;    // reads with more CIGAR ops are scanned by a whole wave and get a
+                                     // checkpoint (reference, query position) before every 64th op
 constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
 constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
 
@@ -121,7 +125,9 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
 // CIGAR shapes htslib's resolve_cigar2 asserts on / indexes out of bounds for are flagged.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t *__restrict__ end_out,
-                                                       PrepPartial *__restrict__ part)
+                                                       PrepPartial *__restrict__ part,
+                                                       uint32_t *__restrict__ long_cnt,
+                                                       uint32_t *__restrict__ long_list)
 {
     __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
     __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
@@ -145,6 +151,10 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             if (!in[i]) continue;
+            if (k1[i] - k0[i] > kLongOps) {             // left to k_read_prep_long
+                long_list[atomicAdd(long_cnt, 1u)] = r0 + i * stride;
+                continue;
+            }
             unsigned long long reflen = 0;
             for (uint32_t k = k0[i]; k < k1[i]; ++k) {
                 const uint32_t c = k == k0[i] ? c0[i] : R.cigar[k], op = c & 15u, l = c >> 4;
@@ -190,6 +200,81 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_read_prep_long: the reads k_read_prep diverted (more than kLongOps CIGAR ops, e.g. long reads
+// with an indel every ~15 bases), one wave per read.  The wave scans the CIGAR in aligned chunks
+// of 64 ops (one op per lane, wave prefix sums of the reference / query advance) and stores, for
+// every op index k that is a multiple of 64 inside the read, the reference and query position
+// before op k: ck_x[k/64], ck_y[k/64].  k_pileup starts its walk at the checkpoint nearest to the
+// window instead of at the read's first op.  Same outputs as k_read_prep otherwise.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint32_t *__restrict__ end_out,
+                                                            PrepPartial *__restrict__ part,
+                                                            const uint32_t *__restrict__ long_cnt,
+                                                            const uint32_t *__restrict__ long_list,
+                                                            uint32_t *__restrict__ ck_x, uint32_t *__restrict__ ck_y)
+{
+    __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
+    __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const uint32_t n_long = *long_cnt;
+    unsigned long long sum_len = 0, sum_mq = 0;          // meaningful in lane 0
+    uint32_t max_span = 0, max_end = 0, err = 0;
+    for (uint32_t i = blockIdx.x * (kBlock / 64) + wv; i < n_long; i += gridDim.x * (kBlock / 64)) {
+        const uint32_t r = long_list[i];
+        const uint32_t k0 = R.cigar_off[r], k1 = R.cigar_off[r + 1];
+        const uint32_t ps = (uint32_t)R.pos[r];
+        unsigned long long xc = 0;                       // reference / query advance before the chunk
+        uint32_t yc = 0;
+        for (uint32_t kb = k0 & ~63u; kb < k1; kb += 64u) {
+            const uint32_t k = kb + lane;
+            const bool valid = k >= k0 && k < k1;
+            const uint32_t c = valid ? R.cigar[k] : 0u, op = c & 15u, l = c >> 4;
+            const bool radv = valid && ((0x18Du >> op) & 1u), qadv = valid && ((0x193u >> op) & 1u);
+            if (radv && l == 0) err |= kErrCigar;        // zero-length reference-consuming op
+            unsigned long long ra = radv ? l : 0u;
+            uint32_t qa = qadv ? l : 0u;
+            for (int d = 1; d < 64; d <<= 1) {           // inclusive wave scans
+                const unsigned long long tr = __shfl_up(ra, d, 64);
+                const uint32_t tq = __shfl_up(qa, d, 64);
+                if (lane >= (uint32_t)d) { ra += tr; qa += tq; }
+            }
+            if (lane == 0 && kb >= k0) {
+                const unsigned long long cx = (unsigned long long)ps + xc;
+                ck_x[kb >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
+                ck_y[kb >> 6] = yc;
+            }
+            xc += __shfl(ra, 63, 64);
+            yc += __shfl(qa, 63, 64);
+        }
+        if (lane == 0) {
+            const unsigned long long e = (unsigned long long)ps + xc;
+            if (e > 0xFFFF0000ull) err |= kErrRange;
+            const uint32_t e32 = e > 0xFFFF0000ull ? ps : (uint32_t)e;
+            end_out[r] = e32;
+            const uint32_t span = e32 - ps, mq = R.mapq[r];
+            sum_len += span;
+            if (mq >= o.min_mapq) sum_mq += (unsigned long long)mq * span;
+            max_span = span > max_span ? span : max_span;
+            max_end = e32 > max_end ? e32 : max_end;
+        }
+    }
+    err = wave_or_u32(err);
+    if (lane == 0) { s_a[wv] = sum_len; s_b[wv] = sum_mq; s_c[wv] = max_span; s_d[wv] = max_end; s_e[wv] = err; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        PrepPartial p;
+        p.sum_reflen = 0; p.sum_mapq_reflen = 0; p.max_span = 0; p.max_end = 0; p.err = 0; p.pad = 0;
+        for (int i = 0; i < kBlock / 64; ++i) {
+            p.sum_reflen += s_a[i]; p.sum_mapq_reflen += s_b[i];
+            p.max_span = s_c[i] > p.max_span ? s_c[i] : p.max_span;
+            p.max_end = s_d[i] > p.max_end ? s_d[i] : p.max_end;
+            p.err |= s_e[i];
+        }
+        part[kPrepBlocks + blockIdx.x] = p;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_window_bounds: thread per window.  Reads are sorted by pos; a read can touch window
 // [W, W+T) only if pos < W+T and pos + max_span > W.
 // ---------------------------------------------------------------------------------------------
@@ -204,7 +289,7 @@ __device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t
 }
 
 __global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPartial *__restrict__ part,
-                                                           uint32_t T, uint32_t n_win,
+                                                           uint32_t n_parts, uint32_t T, uint32_t n_win,
                                                            uint32_t *__restrict__ win_lo,
                                                            uint32_t *__restrict__ win_hi,
                                                            unsigned long long *__restrict__ win_q0,
@@ -212,7 +297,7 @@ __global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPar
 {
     __shared__ uint32_t s_m[kBlock / 64];
     uint32_t m = 0;
-    for (int i = threadIdx.x; i < kPrepBlocks; i += kBlock) { uint32_t v = part[i].max_span; m = v > m ? v : m; }
+    for (uint32_t i = threadIdx.x; i < n_parts; i += kBlock) { uint32_t v = part[i].max_span; m = v > m ? v : m; }
     m = wave_max_u32(m);
     if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
     __syncthreads();
@@ -263,6 +348,7 @@ struct PileupArgs {
     const unsigned long long *win_q0;   // qual_off[win_lo[w]]
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
+    const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (k_read_prep_long)
     uint8_t        *state;        // n_win*T bytes
     WinPartial     *winpart;
     uint32_t        extent;       // positions >= extent are not classified
@@ -496,6 +582,18 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
                     if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
                 }
                 live = mq >= a.o.min_mapq && k < k1;
+            }
+            if (live && k1 - k > kLongOps && x < W) {
+                // long read that starts before the window: jump to the last checkpoint at or before W
+                const uint32_t jlo = (k + 63u) >> 6, jhi = (k1 - 1u) >> 6;
+                if (jlo <= jhi && a.ck_x[jlo] <= W) {
+                    uint32_t lo_j = jlo, hi_j = jhi;                 // invariant: ck_x[lo_j] <= W
+                    while (lo_j < hi_j) {
+                        const uint32_t mid = lo_j + ((hi_j - lo_j + 1u) >> 1);
+                        if (a.ck_x[mid] <= W) lo_j = mid; else hi_j = mid - 1u;
+                    }
+                    k = lo_j << 6; x = a.ck_x[lo_j]; y = a.ck_y[lo_j];
+                }
             }
             if (live) cw = a.R.cigar[k];             // invariant: cw == cigar[k] while live
         }

@@ -294,3 +294,66 @@ def test_coverage_analyzer_and_sharded_driver_on_gpu(tmp_path):
     with Engine(opt, 0) as eng:
         out2 = analyze_sharded(inp2, 0, 1, lambda tid, c: engine_process_contig(eng, opt, tid, c))
     assert open(out2.bed_file).read() == o_bed and out2.export == out.export
+
+
+def test_full_size_chr21_properties_and_sampled_regions(tmp_path):
+    """BASELINE.json configs[1] at full size (46.7 Mb, 30x): size-independent properties of the
+    result, plus bit-exact comparison with the oracle on sampled 60 kb regions (the oracle is run on
+    the reads overlapping the region; positions near the region ends are excluded because reads
+    were cut there)."""
+    L = 46_709_983
+    seed = synth.seed_for(2, 20)
+    rec = synth.short_read_contig(L, 30, seed)
+    ref = synth.make_reference(L, seed)
+    opt = CallableOptions()
+    acc, n_names = admit_reads(opt, 20, L, rec)
+    with Engine(opt, 0) as eng:
+        counter = CallableProfiler(str(tmp_path / "g.bed"))
+        st = ContigProfiler("chr21", L)
+        process_single_contig(eng, counter, st, opt, 20, rec, ref)
+        counts = counter.get_contig_counts("chr21")
+        counter.close()
+        r1 = eng.contig_collect()
+        eng.contig_run()
+        r2 = eng.contig_collect()
+        raw, qc, low, state = eng.debug_depths(L)
+    iv = r1.intervals
+    # idempotence of the resident re-run
+    assert r1.as_dict() == r2.as_dict() and np.array_equal(iv, r2.intervals)
+    # runs tile [0, L) exactly, neighbours differ, states valid
+    assert iv[0, 0] == 0 and iv[-1, 1] == L and np.array_equal(iv[1:, 0], iv[:-1, 1])
+    assert np.all(iv[1:, 2] != iv[:-1, 2]) and iv[:, 2].max() <= 5
+    # conservation: run lengths per state == state counts == histogram of the state bytes; sum == L
+    lens = (iv[:, 1] - iv[:, 0]).astype(np.int64)
+    per_state = [int(lens[iv[:, 2] == k].sum()) for k in range(6)]
+    assert per_state == counts == [int((state == k).sum()) for k in range(6)] and sum(counts) == L
+    # REF_N positions are exactly the N / n bases of the reference
+    assert counts[0] == int(((ref | 0x20) == ord("n")).sum())
+    # per-read separable sums (SURVEY 8a-7) against numpy on the accepted reads
+    ops = rec.cigar & 15
+    lens_c = (rec.cigar >> 4).astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(np.where(np.isin(ops, [0, 2, 3, 7, 8]), lens_c, 0))])
+    rl = cs[rec.cigar_off[1:].astype(np.int64)] - cs[rec.cigar_off[:-1].astype(np.int64)]
+    assert st.summed_coverage == int(rl[acc].sum()) == int(raw.astype(np.int64).sum())
+    sel = acc & (rec.mapq >= opt.min_mapping_quality)
+    assert st.summed_mapq == int((rec.mapq[sel].astype(np.int64) * rl[sel]).sum())
+    assert st.n_covered_bases == int((raw > 0).sum()) and st.quality_bases == int(qc.astype(np.int64).sum())
+    assert st.n_reads == n_names and np.all(qc <= raw) and np.all(low <= raw)
+    # sampled regions against the oracle
+    rng = np.random.default_rng(5)
+    for a in rng.integers(20_000, L - 100_000, size=6).tolist() + [0, L - 60_000]:
+        b = a + 60_000
+        i0 = int(np.searchsorted(rec.pos, a - 400)); i1 = int(np.searchsorted(rec.pos, b))
+        sub = ContigRecords(pos=rec.pos[i0:i1], flag=rec.flag[i0:i1], mapq=rec.mapq[i0:i1],
+                            cigar_off=(rec.cigar_off[i0:i1 + 1] - rec.cigar_off[i0]).astype(np.uint32),
+                            cigar=rec.cigar[rec.cigar_off[i0]:rec.cigar_off[i1]],
+                            qual_off=(rec.qual_off[i0:i1 + 1] - rec.qual_off[i0]).astype(np.uint64),
+                            qual=rec.qual[int(rec.qual_off[i0]):int(rec.qual_off[i1])],
+                            qname_off=(rec.qname_off[i0:i1 + 1] - rec.qname_off[i0]).astype(np.uint32),
+                            qname=rec.qname[rec.qname_off[i0]:rec.qname_off[i1]])
+        prof = oracle.Profiler(str(tmp_path / "s.bed"))
+        _, d = oracle.process_single_contig(prof, make_options({}), "chr21", 20, min(b, L), ref[:min(b, L)], sub, dump=True)
+        prof.close()
+        lo_p, hi_p = a, min(b, L) - (0 if b >= L else 0)
+        for name, arr_o, arr_g in (("raw", d[0], raw), ("qc", d[1], qc), ("low", d[2], low), ("state", d[3], state)):
+            assert np.array_equal(arr_o[lo_p:hi_p], arr_g[lo_p:hi_p]), (name, a)

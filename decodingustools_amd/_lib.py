@@ -111,6 +111,21 @@ SYMBOLS = [
     ("dut_genome_summary_build", None, [C.POINTER(dut_contig_stats), C.POINTER(C.c_uint64), C.c_size_t,
                                         C.POINTER(dut_genome_summary)]),
     ("dut_state_name", C.c_char_p, [C.c_uint32]),
+    ("dut_bam_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("dut_bam_close", None, [C.c_void_p]),
+    ("dut_bam_error", C.c_char_p, [C.c_void_p]),
+    ("dut_bam_n_ref", C.c_int, [C.c_void_p]),
+    ("dut_bam_ref_name", C.c_char_p, [C.c_void_p, C.c_int]),
+    ("dut_bam_ref_len", C.c_uint32, [C.c_void_p, C.c_int]),
+    ("dut_bam_header_text", C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
+    ("dut_bam_has_index", C.c_int, [C.c_void_p]),
+    ("dut_bam_read_contig", C.c_int, [C.c_void_p, C.c_int, C.POINTER(dut_records), C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_void_p)]),
+    ("dut_fasta_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("dut_fasta_close", None, [C.c_void_p]),
+    ("dut_fasta_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("dut_coverage_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(cl_options),
+                                     C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]),
 ]
 
 

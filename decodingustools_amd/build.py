@@ -12,14 +12,18 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcallable_hip.so")
-SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "host_coverage.cpp")]
+SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "host_coverage.cpp"),
+           os.path.join(CSRC, "bam_io.cpp")]
+CLI = os.path.join(LIBDIR, "dut-coverage")
+CLI_SRC = os.path.join(CSRC, "coverage_main.cpp")
 HEADERS = [os.path.join(CSRC, "kernels.hip.h"),
            os.path.join(HERE, "..", "include", "callable_loci.h"),
-           os.path.join(HERE, "..", "include", "dut_coverage.h")]
+           os.path.join(HERE, "..", "include", "dut_coverage.h"),
+           os.path.join(HERE, "..", "include", "dut_bam.h"), CLI_SRC]
 
 
 def _stale():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
@@ -34,13 +38,19 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build libcallable_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + SOURCES + ["-o", LIB + ".tmp"]
+           "-Wall", "-Wno-unused-function"] + SOURCES + ["-lz", "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
     os.replace(LIB + ".tmp", LIB)
+    # the `coverage` command line tool, linked against the library beside it
+    cmd = [hipcc, "-O2", "-std=c++17", CLI_SRC, "-L" + LIBDIR, "-lcallable_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI + ".tmp"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building dut-coverage failed:\n" + r.stdout + r.stderr)
+    os.replace(CLI + ".tmp", CLI)
     return LIB
 
 

@@ -1,0 +1,509 @@
+// bam_io.cpp -- implementation of include/dut_bam.h: BGZF/BAM/BAI and FASTA/FAI input and the
+// file-level `coverage` driver.  Host-only code (zlib for the inflate); the per-position work is the
+// device engine's (callable_loci.hip).
+#include "../../include/dut_bam.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cinttypes>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace {
+
+void set_err(char *err, size_t n, const std::string &m)
+{
+    if (err && n) { snprintf(err, n, "%s", m.c_str()); }
+}
+
+inline uint32_t rd32(const uint8_t *p) { uint32_t v; memcpy(&v, p, 4); return v; }
+inline uint16_t rd16(const uint8_t *p) { uint16_t v; memcpy(&v, p, 2); return v; }
+inline uint64_t rd64(const uint8_t *p) { uint64_t v; memcpy(&v, p, 8); return v; }
+
+// ---------------------------------------------------------------------------------------------
+// BGZF: a series of gzip members with a BC extra field that gives the member size
+// ---------------------------------------------------------------------------------------------
+struct Bgzf {
+    FILE *fp = nullptr;
+    std::vector<uint8_t> cbuf, ubuf;      // compressed / uncompressed block
+    uint64_t block_coff = 0;              // file offset of the current block
+    uint64_t next_coff = 0;               // file offset of the next block
+    size_t upos = 0;                      // read position inside ubuf
+    bool eof = false;
+    std::string err;
+
+    bool load_block()
+    {
+        // returns false at EOF or on error (err set)
+        for (;;) {
+            block_coff = next_coff;
+            if (fseeko(fp, (off_t)block_coff, SEEK_SET) != 0) { err = "seek failed"; return false; }
+            uint8_t hdr[18];
+            size_t got = fread(hdr, 1, 18, fp);
+            if (got == 0) { eof = true; ubuf.clear(); upos = 0; return false; }
+            if (got < 18 || hdr[0] != 31 || hdr[1] != 139 || hdr[2] != 8 || !(hdr[3] & 4)) { err = "not a BGZF block"; return false; }
+            const uint16_t xlen = rd16(hdr + 10);
+            // find the BC subfield (normally the only one: SI1='B', SI2='C', SLEN=2)
+            std::vector<uint8_t> extra(xlen);
+            memcpy(extra.data(), hdr + 12, std::min<size_t>(6, xlen));
+            if (xlen > 6 && fread(extra.data() + 6, 1, xlen - 6, fp) != (size_t)(xlen - 6)) { err = "truncated BGZF header"; return false; }
+            int bsize = -1;
+            for (size_t i = 0; i + 4 <= extra.size();) {
+                const uint16_t slen = rd16(&extra[i + 2]);
+                if (extra[i] == 'B' && extra[i + 1] == 'C' && slen == 2 && i + 6 <= extra.size()) bsize = rd16(&extra[i + 4]);
+                i += 4 + slen;
+            }
+            if (bsize < 0) { err = "BGZF block without BC field"; return false; }
+            const size_t total = (size_t)bsize + 1;                  // whole member
+            const size_t hlen = 12 + xlen;
+            if (total < hlen + 8) { err = "bad BGZF block size"; return false; }
+            const size_t clen = total - hlen - 8;
+            cbuf.resize(clen + 8);
+            if (fread(cbuf.data(), 1, clen + 8, fp) != clen + 8) { err = "truncated BGZF block"; return false; }
+            const uint32_t isize = rd32(&cbuf[clen + 4]);
+            if (isize > 65536) { err = "bad BGZF ISIZE"; return false; }
+            ubuf.resize(isize);
+            next_coff = block_coff + total;
+            upos = 0;
+            if (isize) {
+                z_stream zs;
+                memset(&zs, 0, sizeof(zs));
+                if (inflateInit2(&zs, -15) != Z_OK) { err = "inflateInit2 failed"; return false; }
+                zs.next_in = cbuf.data(); zs.avail_in = (uInt)clen;
+                zs.next_out = ubuf.data(); zs.avail_out = isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                inflateEnd(&zs);
+                if (rc != Z_STREAM_END || zs.total_out != isize) { err = "inflate failed"; return false; }
+                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), ubuf.data(), isize) != rd32(&cbuf[clen])) { err = "BGZF CRC mismatch"; return false; }
+                return true;
+            }
+            // empty block (e.g. the EOF marker): continue with the next one
+        }
+    }
+    // read exactly n bytes; returns bytes read (< n only at EOF / error)
+    size_t read(void *dst, size_t n)
+    {
+        uint8_t *d = (uint8_t *)dst;
+        size_t done = 0;
+        while (done < n) {
+            if (upos >= ubuf.size()) { if (!load_block()) break; }
+            const size_t take = std::min(n - done, ubuf.size() - upos);
+            memcpy(d + done, ubuf.data() + upos, take);
+            upos += take; done += take;
+        }
+        return done;
+    }
+    uint64_t tell() const { return upos >= ubuf.size() && !ubuf.empty() ? (next_coff << 16) : ((block_coff << 16) | (uint64_t)upos); }
+    bool seek(uint64_t voff)
+    {
+        next_coff = voff >> 16; eof = false; err.clear();
+        ubuf.clear(); upos = 0;
+        if (!load_block()) return eof && (voff & 0xFFFF) == 0;
+        upos = (size_t)(voff & 0xFFFF);
+        return upos <= ubuf.size();
+    }
+};
+
+struct RefSeq { std::string name; uint32_t len; };
+
+// nibble-continuous 4-bit sequence store (what cl_site_tile wants)
+struct Seq4 {
+    std::vector<uint8_t> bytes;
+    uint64_t n_bases = 0;
+    void clear() { bytes.clear(); n_bases = 0; }
+    void append(const uint8_t *packed, uint32_t l_seq)      // BAM packing: high nibble first
+    {
+        if ((n_bases & 1u) == 0) {
+            bytes.insert(bytes.end(), packed, packed + (l_seq + 1) / 2);
+            if (l_seq & 1u) bytes.back() &= 0xF0;
+        } else {
+            for (uint32_t i = 0; i < l_seq; ++i) {
+                const uint8_t code = (i & 1u) ? (packed[i >> 1] & 15u) : (packed[i >> 1] >> 4);
+                const uint64_t pos = n_bases + i;
+                if (pos & 1u) bytes.back() |= code; else bytes.push_back((uint8_t)(code << 4));
+            }
+        }
+        n_bases += l_seq;
+    }
+};
+
+} // namespace
+
+struct dut_bam {
+    Bgzf z;
+    std::string path, err, text;
+    std::vector<RefSeq> refs;
+    uint64_t data_start = 0;                 // virtual offset of the first record
+    // .bai: smallest chunk start per reference
+    bool has_index = false;
+    std::vector<uint64_t> ref_start;         // UINT64_MAX = no records
+    // sequential state
+    bool pending = false;                    // `rec` holds a record that was read but not consumed
+    std::vector<uint8_t> rec;
+    int32_t last_tid_done = -1;
+    // SoA of the last contig read
+    std::vector<int32_t> pos;
+    std::vector<uint16_t> flag;
+    std::vector<uint8_t> mapq, qual, qname;
+    std::vector<uint32_t> cigar_off, cigar, qname_off;
+    std::vector<uint64_t> qual_off, seq_off;
+    Seq4 seq;
+};
+
+namespace {
+
+bool read_record(dut_bam *b)
+{
+    uint8_t szb[4];
+    const size_t g = b->z.read(szb, 4);
+    if (g == 0) return false;                               // clean EOF
+    if (g < 4) { b->err = b->z.err.empty() ? "truncated BAM record" : b->z.err; return false; }
+    const uint32_t bs = rd32(szb);
+    if (bs < 32 || bs > (1u << 29)) { b->err = "bad BAM block_size"; return false; }
+    b->rec.resize(bs);
+    if (b->z.read(b->rec.data(), bs) != bs) { b->err = b->z.err.empty() ? "truncated BAM record" : b->z.err; return false; }
+    return true;
+}
+
+bool load_bai(dut_bam *b)
+{
+    std::string p1 = b->path + ".bai", p2 = b->path;
+    if (p2.size() > 4 && p2.substr(p2.size() - 4) == ".bam") p2 = p2.substr(0, p2.size() - 4) + ".bai";
+    FILE *f = fopen(p1.c_str(), "rb");
+    if (!f) f = fopen(p2.c_str(), "rb");
+    if (!f) return false;
+    std::vector<uint8_t> d;
+    uint8_t buf[65536];
+    size_t g;
+    while ((g = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + g);
+    fclose(f);
+    if (d.size() < 8 || memcmp(d.data(), "BAI\1", 4) != 0) return false;
+    size_t o = 4;
+    const uint32_t n_ref = rd32(&d[o]); o += 4;
+    std::vector<uint64_t> start(n_ref, UINT64_MAX);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (o + 4 > d.size()) return false;
+        const uint32_t n_bin = rd32(&d[o]); o += 4;
+        for (uint32_t i = 0; i < n_bin; ++i) {
+            if (o + 8 > d.size()) return false;
+            const uint32_t bin = rd32(&d[o]), n_chunk = rd32(&d[o + 4]); o += 8;
+            if (o + 16ull * n_chunk > d.size()) return false;
+            if (bin != 37450)                                 // the metadata pseudo-bin
+                for (uint32_t c = 0; c < n_chunk; ++c) start[r] = std::min(start[r], rd64(&d[o + 16ull * c]));
+            o += 16ull * n_chunk;
+        }
+        if (o + 4 > d.size()) return false;
+        const uint32_t n_intv = rd32(&d[o]); o += 4;
+        if (o + 8ull * n_intv > d.size()) return false;
+        o += 8ull * n_intv;
+    }
+    if (n_ref != b->refs.size()) return false;
+    b->ref_start.swap(start);
+    return true;
+}
+
+} // namespace
+
+extern "C" {
+
+dut_bam *dut_bam_open(const char *path, char *err, size_t err_len)
+{
+    if (!path) { set_err(err, err_len, "null path"); return nullptr; }
+    dut_bam *b = new dut_bam();
+    b->path = path;
+    b->z.fp = fopen(path, "rb");
+    if (!b->z.fp) { set_err(err, err_len, std::string("cannot open ") + path); delete b; return nullptr; }
+    uint8_t m[12];
+    auto bad = [&](const std::string &why) { set_err(err, err_len, why + (b->z.err.empty() ? "" : ": " + b->z.err)); dut_bam_close(b); return (dut_bam *)nullptr; };
+    if (b->z.read(m, 8) != 8 || memcmp(m, "BAM\1", 4) != 0) return bad("not a BAM file");
+    const uint32_t l_text = rd32(m + 4);
+    b->text.resize(l_text);
+    if (l_text && b->z.read(&b->text[0], l_text) != l_text) return bad("truncated BAM header");
+    if (b->z.read(m, 4) != 4) return bad("truncated BAM header");
+    const uint32_t n_ref = rd32(m);
+    for (uint32_t i = 0; i < n_ref; ++i) {
+        if (b->z.read(m, 4) != 4) return bad("truncated BAM header");
+        const uint32_t l_name = rd32(m);
+        std::string nm(l_name, '\0');
+        if (l_name == 0 || b->z.read(&nm[0], l_name) != l_name || b->z.read(m, 4) != 4) return bad("truncated BAM header");
+        nm.resize(strlen(nm.c_str()));
+        b->refs.push_back({nm, rd32(m)});
+    }
+    b->data_start = b->z.tell();
+    b->has_index = load_bai(b);
+    return b;
+}
+
+void dut_bam_close(dut_bam *b)
+{
+    if (!b) return;
+    if (b->z.fp) fclose(b->z.fp);
+    delete b;
+}
+
+const char *dut_bam_error(const dut_bam *b) { return b ? b->err.c_str() : "null reader"; }
+int dut_bam_n_ref(const dut_bam *b) { return b ? (int)b->refs.size() : 0; }
+const char *dut_bam_ref_name(const dut_bam *b, int tid) { return (b && tid >= 0 && (size_t)tid < b->refs.size()) ? b->refs[tid].name.c_str() : nullptr; }
+uint32_t dut_bam_ref_len(const dut_bam *b, int tid) { return (b && tid >= 0 && (size_t)tid < b->refs.size()) ? b->refs[tid].len : 0; }
+const char *dut_bam_header_text(const dut_bam *b, size_t *len) { if (len) *len = b ? b->text.size() : 0; return b ? b->text.data() : nullptr; }
+int dut_bam_has_index(const dut_bam *b) { return b && b->has_index ? 1 : 0; }
+
+int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4)
+{
+    if (!b || !out || tid < 0 || (size_t)tid >= b->refs.size()) return CL_ERR_INVALID;
+    b->err.clear();
+    b->pos.clear(); b->flag.clear(); b->mapq.clear(); b->qual.clear(); b->qname.clear(); b->cigar.clear();
+    b->cigar_off.assign(1, 0u); b->qname_off.assign(1, 0u); b->qual_off.assign(1, 0ull); b->seq_off.assign(1, 0ull);
+    b->seq.clear();
+    const bool want_seq = seq_off && seq4;
+
+    // position the stream at the first record that can belong to tid
+    bool positioned = false;
+    if (b->has_index) {
+        if (b->ref_start[tid] == UINT64_MAX) positioned = true;          // no records at all: read nothing
+        else { b->pending = false; if (!b->z.seek(b->ref_start[tid])) { b->err = "BAI offset beyond the file"; return CL_ERR_INVALID; } positioned = true; }
+        if (b->ref_start[tid] == UINT64_MAX) goto done;
+    }
+    if (!positioned) {
+        // forward-only: rewind when an earlier contig is requested again
+        if (tid <= b->last_tid_done) { b->pending = false; if (!b->z.seek(b->data_start)) { b->err = "rewind failed"; return CL_ERR_INVALID; } }
+    }
+    for (;;) {
+        if (!b->pending) {
+            if (!read_record(b)) { if (!b->err.empty()) return CL_ERR_INVALID; break; }
+        }
+        b->pending = false;
+        const uint8_t *r = b->rec.data();
+        const int32_t ref_id = (int32_t)rd32(r);
+        if (ref_id < 0 || ref_id > tid) { b->pending = true; break; }     // sorted: past this contig
+        if (ref_id < tid) continue;
+        const uint32_t bs = (uint32_t)b->rec.size();
+        const int32_t p = (int32_t)rd32(r + 4);
+        const uint32_t l_read_name = r[8], mq = r[9];
+        uint32_t n_cigar = rd16(r + 12);
+        const uint16_t fl = rd16(r + 14);
+        const uint32_t l_seq = rd32(r + 16);
+        size_t o = 32;
+        if (o + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq > bs || l_read_name == 0) { b->err = "malformed BAM record"; return CL_ERR_INVALID; }
+        const uint8_t *name = r + o; o += l_read_name;
+        const uint8_t *cig = r + o; o += 4ull * n_cigar;
+        const uint8_t *sq = r + o; o += (l_seq + 1) / 2;
+        const uint8_t *ql = r + o; o += l_seq;
+        // long CIGARs live in the CG:B,I tag behind a <l_seq>S<reflen>N placeholder
+        const uint8_t *cig_real = cig;
+        if (n_cigar == 2 && (rd32(cig) & 15u) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15u) == 3) {
+            size_t a = o;
+            while (a + 3 <= bs) {
+                const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+                a += 3;
+                size_t len = 0;
+                auto elt = [](uint8_t c) -> size_t { switch (c) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
+                if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) ++len; len += 1; }
+                else if (ty == 'B') {
+                    if (a + 5 > bs) break;
+                    const uint8_t sub = r[a]; const uint32_t cnt = rd32(r + a + 1);
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= bs) { cig_real = r + a + 5; n_cigar = cnt; break; }
+                    len = 5 + elt(sub) * (size_t)cnt;
+                } else { len = elt(ty); if (!len) break; }
+                a += len;
+            }
+        }
+        b->pos.push_back(p); b->flag.push_back(fl); b->mapq.push_back((uint8_t)mq);
+        for (uint32_t k = 0; k < n_cigar; ++k) b->cigar.push_back(rd32(cig_real + 4ull * k));
+        b->cigar_off.push_back((uint32_t)b->cigar.size());
+        b->qual.insert(b->qual.end(), ql, ql + l_seq);
+        b->qual_off.push_back(b->qual.size());
+        b->qname.insert(b->qname.end(), name, name + (l_read_name - 1));       // without the NUL
+        b->qname_off.push_back((uint32_t)b->qname.size());
+        if (want_seq) { b->seq.append(sq, l_seq); b->seq_off.push_back(b->seq.n_bases); }
+        if (b->cigar.size() > 0xFFFFFFF0ull || b->qname.size() > 0xFFFFFFF0ull) { b->err = "contig too large for 32-bit offsets"; return CL_ERR_RANGE; }
+    }
+done:
+    b->last_tid_done = tid;
+    out->n = b->pos.size();
+    out->pos = b->pos.data(); out->flag = b->flag.data(); out->mapq = b->mapq.data();
+    out->cigar_off = b->cigar_off.data(); out->cigar = b->cigar.data();
+    out->qual_off = b->qual_off.data(); out->qual = b->qual.data();
+    out->qname_off = b->qname_off.data(); out->qname = b->qname.data();
+    if (want_seq) { *seq_off = b->seq_off.data(); *seq4 = b->seq.bytes.data(); }
+    return CL_OK;
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// FASTA + .fai
+// ---------------------------------------------------------------------------------------------
+struct dut_fasta {
+    FILE *fp = nullptr;
+    struct Ent { std::string name; uint64_t len, off, linebases, linewidth; };
+    std::vector<Ent> ents;
+    std::vector<uint8_t> seq;
+};
+
+extern "C" {
+
+dut_fasta *dut_fasta_open(const char *path, char *err, size_t err_len)
+{
+    if (!path) { set_err(err, err_len, "null path"); return nullptr; }
+    FILE *fi = fopen((std::string(path) + ".fai").c_str(), "r");
+    if (!fi) { set_err(err, err_len, std::string("cannot open ") + path + ".fai (the reference needs a faidx index)"); return nullptr; }
+    dut_fasta *f = new dut_fasta();
+    char line[4096];
+    while (fgets(line, sizeof(line), fi)) {
+        char nm[2048]; unsigned long long a, b, c, d;
+        if (sscanf(line, "%2047[^\t]\t%llu\t%llu\t%llu\t%llu", nm, &a, &b, &c, &d) == 5) f->ents.push_back({nm, a, b, c, d});
+    }
+    fclose(fi);
+    f->fp = fopen(path, "rb");
+    if (!f->fp) { set_err(err, err_len, std::string("cannot open ") + path); delete f; return nullptr; }
+    return f;
+}
+
+void dut_fasta_close(dut_fasta *f)
+{
+    if (!f) return;
+    if (f->fp) fclose(f->fp);
+    delete f;
+}
+
+int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len)
+{
+    if (!f || !name || !bases || !len) return CL_ERR_INVALID;
+    *bases = nullptr; *len = 0;
+    for (const auto &e : f->ents) {
+        if (e.name != name) continue;
+        f->seq.clear();
+        if (e.len == 0 || e.linebases == 0) return CL_OK;
+        const uint64_t n_lines = (e.len + e.linebases - 1) / e.linebases;
+        const uint64_t span = e.len + (n_lines - 1) * (e.linewidth - e.linebases) ;
+        std::vector<uint8_t> raw(span);
+        if (fseeko(f->fp, (off_t)e.off, SEEK_SET) != 0) return CL_ERR_INVALID;
+        const size_t got = fread(raw.data(), 1, span, f->fp);
+        f->seq.reserve(e.len);
+        for (size_t i = 0; i < got && f->seq.size() < e.len; ++i) {
+            if (i % e.linewidth < e.linebases) f->seq.push_back(raw[i]);
+        }
+        *bases = f->seq.data(); *len = f->seq.size();
+        return CL_OK;
+    }
+    return CL_OK;       // unknown name: zero bases, every position reads as 'N'
+}
+
+} // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// the file-level coverage driver
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+void json_num(std::string &s, double v)
+{
+    char b[64];
+    if (v == std::floor(v) && std::fabs(v) < 1e15) snprintf(b, sizeof(b), "%.1f", v);   // serde_json prints 60.0
+    else snprintf(b, sizeof(b), "%.17g", v);
+    // shortest representation that round-trips
+    for (int prec = 1; prec < 17; ++prec) {
+        char t[64]; snprintf(t, sizeof(t), "%.*g", prec, v);
+        if (strtod(t, nullptr) == v) { if (strchr(t, '.') || strchr(t, 'e') || strchr(t, 'n') || strchr(t, 'i')) snprintf(b, sizeof(b), "%s", t); else snprintf(b, sizeof(b), "%s.0", t); break; }
+    }
+    s += b;
+}
+
+} // namespace
+
+extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
+                                  const char *summary_json, const cl_options *opt, const char *const *contigs,
+                                  size_t n_contigs, int device_id, char *err, size_t err_len)
+{
+    if (!bam_path || !fasta_path || !bed_path || !opt) { set_err(err, err_len, "null argument"); return CL_ERR_INVALID; }
+    char e[512] = {0};
+    dut_bam *bam = dut_bam_open(bam_path, e, sizeof(e));
+    if (!bam) { set_err(err, err_len, std::string("Failed to open BAM file: ") + e); return CL_ERR_INVALID; }   // api/coverage.rs:69-70
+    dut_fasta *fa = dut_fasta_open(fasta_path, e, sizeof(e));
+    if (!fa) { dut_bam_close(bam); set_err(err, err_len, std::string("Failed to open reference: ") + e); return CL_ERR_INVALID; }   // :73-74
+    // initialize_contig_stats / validate_contig_selection, api/coverage.rs:149-204
+    std::vector<int> tids;
+    for (int t = 0; t < dut_bam_n_ref(bam); ++t) {
+        bool take = contigs == nullptr;
+        for (size_t i = 0; !take && i < n_contigs; ++i) take = strcmp(contigs[i], dut_bam_ref_name(bam, t)) == 0;
+        if (take) tids.push_back(t);
+    }
+    int rc = CL_OK;
+    cl_ctx *ctx = nullptr;
+    dut_profiler *prof = nullptr;
+    std::vector<dut_contig_stats> stats;
+    std::vector<std::string> names;
+    std::vector<std::vector<uint64_t>> counts;
+    if (contigs && tids.empty()) {
+        std::string list;
+        for (size_t i = 0; i < n_contigs; ++i) { if (i) list += ", "; list += contigs[i]; }
+        set_err(err, err_len, "None of the specified contigs (" + list + ") were found in the BAM file");
+        rc = CL_ERR_INVALID; goto out;
+    }
+    rc = cl_create(opt, device_id, nullptr, &ctx);
+    if (rc != CL_OK) { set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)"); goto out; }
+    prof = dut_profiler_new(bed_path);
+    if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; goto out; }
+    for (int t : tids) {                                          // ascending tid, api/coverage.rs:229-234
+        dut_records rec;
+        rc = dut_bam_read_contig(bam, t, &rec, nullptr, nullptr);
+        if (rc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_bam_error(bam)); goto out; }
+        const uint8_t *bases = nullptr; uint64_t blen = 0;
+        dut_fasta_fetch(fa, dut_bam_ref_name(bam, t), &bases, &blen);
+        dut_contig_stats st;
+        memset(&st, 0, sizeof(st));
+        rc = dut_process_single_contig(ctx, prof, &st, opt, dut_bam_ref_name(bam, t), t, dut_bam_ref_len(bam, t), bases, blen, &rec);
+        if (rc != CL_OK) {
+            const char *m = cl_last_error(ctx);
+            set_err(err, err_len, std::string("Error processing contig: ") + ((m && *m) ? m : (rc == CL_ERR_UNSORTED ? "the input is not sorted" : "failed")));
+            goto out;
+        }
+        uint64_t c6[6];
+        dut_profiler_contig_counts(prof, dut_bam_ref_name(bam, t), c6);
+        stats.push_back(st); names.push_back(dut_bam_ref_name(bam, t)); counts.push_back(std::vector<uint64_t>(c6, c6 + 6));
+    }
+    if (summary_json) {
+        // report.rs:37-134 numbers; contigs in compare_contig_names order
+        std::vector<size_t> order(stats.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dut_compare_contig_names(names[a].c_str(), names[b].c_str()) < 0; });
+        std::vector<dut_contig_stats> so; std::vector<uint64_t> call;
+        for (size_t i : order) { so.push_back(stats[i]); call.push_back(counts[i][1]); }
+        dut_genome_summary g;
+        dut_genome_summary_build(so.data(), call.data(), so.size(), &g);
+        std::string s = "{\n  \"summary\": {\n";
+        s += "    \"total_bases\": " + std::to_string(g.total_bases) + ",\n    \"callable_bases\": " + std::to_string(g.callable_bases) + ",\n    \"callable_percentage\": ";
+        json_num(s, g.callable_percentage); s += ",\n    \"average_depth\": "; json_num(s, g.average_depth);
+        s += ",\n    \"contigs_analyzed\": " + std::to_string(g.contigs_analyzed) + "\n  },\n  \"contigs\": [\n";
+        for (size_t k = 0; k < order.size(); ++k) {
+            const size_t i = order[k];
+            dut_contig_derived d; dut_contig_derive(&stats[i], &d);
+            s += "    {\n      \"name\": \"" + names[i] + "\",\n      \"length\": " + std::to_string(stats[i].length) + ",\n      \"unique_reads\": " + std::to_string(stats[i].n_reads) + ",\n      \"coverage_percent\": ";
+            json_num(s, d.coverage_percent); s += ",\n      \"average_depth\": "; json_num(s, d.average_depth);
+            s += ",\n      \"covered_bases\": " + std::to_string(stats[i].n_covered_bases) + ",\n      \"total_bases\": " + std::to_string(stats[i].length) + ",\n      \"quality_stats\": {\n        \"average_mapq\": ";
+            json_num(s, d.average_mapq); s += ",\n        \"average_baseq\": "; json_num(s, d.average_baseq); s += ",\n        \"q30_percentage\": "; json_num(s, d.q30_percentage);
+            s += "\n      },\n      \"state_distribution\": {\n        \"ref_n\": " + std::to_string(counts[i][0]) + ",\n        \"callable\": " + std::to_string(counts[i][1]) + ",\n        \"no_coverage\": " + std::to_string(counts[i][2]) +
+                 ",\n        \"low_coverage\": " + std::to_string(counts[i][3]) + ",\n        \"excessive_coverage\": " + std::to_string(counts[i][4]) + ",\n        \"poor_mapping_quality\": " + std::to_string(counts[i][5]) + "\n      }\n    }";
+            s += (k + 1 < order.size()) ? ",\n" : "\n";
+        }
+        s += "  ],\n  \"quality_metrics\": {\n    \"average_mapq\": "; json_num(s, g.average_mapq); s += ",\n    \"average_baseq\": "; json_num(s, g.average_baseq);
+        s += ",\n    \"q30_percentage\": "; json_num(s, g.q30_percentage); s += "\n  },\n  \"total_unique_reads\": " + std::to_string(g.total_unique_reads) + "\n}\n";
+        FILE *jf = fopen(summary_json, "wb");
+        if (!jf) { set_err(err, err_len, std::string("cannot create ") + summary_json); rc = CL_ERR_INVALID; goto out; }
+        fwrite(s.data(), 1, s.size(), jf);
+        fclose(jf);
+    }
+out:
+    if (prof) dut_profiler_free(prof);
+    if (ctx) cl_destroy(ctx);
+    dut_fasta_close(fa);
+    dut_bam_close(bam);
+    return rc;
+}

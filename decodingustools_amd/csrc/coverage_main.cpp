@@ -1,0 +1,61 @@
+// dut-coverage -- the `coverage` subcommand of the reference CLI (src/cli.rs:14-61, src/main.rs:36-70)
+// on the MI355X engine.  Same flags and defaults; BED to -o, numeric summary to ./summary.json.
+// (-s/--summary names the reference's HTML report, which is presentation and not produced.)
+#include "../../include/dut_bam.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static void usage()
+{
+    fprintf(stderr,
+            "Usage: dut-coverage [coverage] <BAM_FILE> -r <REFERENCE_FILE> [-o callable_regions.bed] [-s summary.html]\n"
+            "       [-L <CONTIG>]... [--min-depth 4] [--max-depth 500] [--min-mapping-quality 10]\n"
+            "       [--min-base-quality 20] [--min-depth-for-low-mapq 10] [--max-low-mapq 1]\n"
+            "       [--max-low-mapq-fraction 0.1] [--device 0]\n");
+}
+
+int main(int argc, char **argv)
+{
+    cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};      // src/cli.rs:34-60
+    std::string bam, ref, out = "callable_regions.bed", summary = "summary.html";
+    std::vector<const char *> contigs;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        std::string val;
+        const size_t eq = a.find('=');
+        const bool has_eq = a.rfind("--", 0) == 0 && eq != std::string::npos;
+        if (has_eq) { val = a.substr(eq + 1); a = a.substr(0, eq); }
+        auto next = [&]() -> const char * {
+            if (has_eq) return val.c_str();
+            if (i + 1 >= argc) { usage(); exit(2); }
+            return argv[++i];
+        };
+        if (a == "coverage" && bam.empty()) continue;
+        else if (a == "-r" || a == "--reference") ref = next();
+        else if (a == "-o" || a == "--output") out = next();
+        else if (a == "-s" || a == "--summary") summary = next();
+        else if (a == "-L" || a == "--contig") contigs.push_back(strdup(next()));
+        else if (a == "--min-depth") opt.min_depth = (uint32_t)strtoul(next(), nullptr, 10);
+        else if (a == "--max-depth") opt.max_depth = (uint32_t)strtoul(next(), nullptr, 10);
+        else if (a == "--min-mapping-quality") opt.min_mapping_quality = (uint8_t)strtoul(next(), nullptr, 10);
+        else if (a == "--min-base-quality") opt.min_base_quality = (uint8_t)strtoul(next(), nullptr, 10);
+        else if (a == "--min-depth-for-low-mapq") opt.min_depth_for_low_mapq = (uint32_t)strtoul(next(), nullptr, 10);
+        else if (a == "--max-low-mapq") opt.max_low_mapq = (uint8_t)strtoul(next(), nullptr, 10);
+        else if (a == "--max-low-mapq-fraction") opt.max_low_mapq_fraction = strtod(next(), nullptr);
+        else if (a == "--device") device = atoi(next());
+        else if (a == "-h" || a == "--help") { usage(); return 0; }
+        else if (!a.empty() && a[0] != '-' && bam.empty()) bam = a;
+        else { fprintf(stderr, "error: unexpected argument '%s'\n", argv[i]); usage(); return 2; }
+    }
+    if (bam.empty() || ref.empty()) { usage(); return 2; }
+    char err[1024] = {0};
+    const int rc = dut_coverage_files(bam.c_str(), ref.c_str(), out.c_str(), "summary.json", &opt,
+                                      contigs.empty() ? nullptr : contigs.data(), contigs.size(), device, err, sizeof(err));
+    if (rc != CL_OK) { fprintf(stderr, "Error: Analysis error: %s\n", err); return 1; }
+    return 0;
+}

@@ -1,0 +1,60 @@
+/*
+ * dut_bam.h -- alignment / reference file input for the coverage path, in C.
+ *
+ * Replaces what the reference gets from rust-htslib before the hot path starts:
+ *   BamReaderFactory::open_indexed            src/utils/bam_reader.rs:7-14
+ *   bam.fetch((tid, 0, contig_len)) + records src/callable_loci/mod.rs:53-55
+ *   faidx::Reader::from_path / fetch_seq      src/api/coverage.rs:73, mod.rs:79-80
+ * and the file-level driver CoverageAnalyzer::run_analysis (src/api/coverage.rs:53-115) minus
+ * BamStats and the HTML report (presentation, out of scope).
+ *
+ * BAM only (BGZF + BAM records; a .bai beside the file is used to seek to a contig when present,
+ * otherwise the file is read forward).  CRAM is not supported.
+ */
+#ifndef DUT_BAM_H
+#define DUT_BAM_H
+
+#include "dut_coverage.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct dut_bam dut_bam;
+typedef struct dut_fasta dut_fasta;
+
+/* Opens a BAM file and parses its header.  NULL on failure (message in err). */
+dut_bam *dut_bam_open(const char *path, char *err, size_t err_len);
+void dut_bam_close(dut_bam *b);
+const char *dut_bam_error(const dut_bam *b);
+int dut_bam_n_ref(const dut_bam *b);
+const char *dut_bam_ref_name(const dut_bam *b, int tid);      /* header.tid2name */
+uint32_t dut_bam_ref_len(const dut_bam *b, int tid);          /* header.target_len */
+const char *dut_bam_header_text(const dut_bam *b, size_t *len);
+int dut_bam_has_index(const dut_bam *b);
+
+/* All records with refID == tid, file order, decoded into reader-owned SoA buffers that stay
+ * valid until the next call on this reader.  seq_off (in bases) / seq4 (4-bit codes, two per
+ * byte, continuous) are filled when non-NULL.  Returns 0 or a negative cl_status. */
+int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4);
+
+/* FASTA with a .fai beside it (faidx).  NULL on failure. */
+dut_fasta *dut_fasta_open(const char *path, char *err, size_t err_len);
+void dut_fasta_close(dut_fasta *f);
+/* The bases of one sequence, case preserved, reader-owned until the next call.  *len = 0 when the
+ * name is unknown (every base then reads as 'N', mod.rs:79-80). */
+int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len);
+
+/* `coverage <bam> -r <fasta> -o <bed> [-L contig]...` on one GPU: per selected contig (ascending
+ * tid) read, admit, run the engine, append BED lines; then write the numeric summary as JSON to
+ * summary_json (may be NULL).  contigs == NULL selects every header contig.
+ * Errors: negative cl_status, message in err ("None of the specified contigs (...) were found in
+ * the BAM file" for an -L list that matches nothing, api/coverage.rs:187-204). */
+int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
+                       const char *summary_json, const cl_options *opt, const char *const *contigs,
+                       size_t n_contigs, int device_id, char *err, size_t err_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DUT_BAM_H */

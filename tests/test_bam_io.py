@@ -1,0 +1,104 @@
+"""CPU tests of the native BGZF/BAM/BAI and FASTA/FAI reader against files written by the
+independent pure-Python writer in tests/bamio.py."""
+import numpy as np
+import pytest
+
+from bamio import write_bam, write_fasta
+from decodingustools_amd import synth
+from decodingustools_amd.bam import BamReader, FastaReader
+from decodingustools_amd.records import ContigRecords
+
+
+def _same(a: ContigRecords, b: ContigRecords, seq=False):
+    for f in ("pos", "flag", "mapq", "cigar_off", "cigar", "qual_off", "qual", "qname_off", "qname"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    if seq:
+        assert np.array_equal(a.seq_off, b.seq_off)
+        n = int(a.seq_off[-1])
+        ca = np.array([(a.seq4[j >> 1] >> 4) if j % 2 == 0 else (a.seq4[j >> 1] & 15) for j in range(n)])
+        cb = np.array([(b.seq4[j >> 1] >> 4) if j % 2 == 0 else (b.seq4[j >> 1] & 15) for j in range(n)])
+        assert np.array_equal(ca, cb)
+
+
+def _dataset():
+    refs = [("chr1", 30_000), ("chr2", 5_000), ("chrEmpty", 1_000), ("chrM", 16_569)]
+    per = {0: synth.short_read_contig(30_000, 20, 11), 1: synth.adversarial_contig(5_000, 400, 12, overhang=True),
+           3: synth.adversarial_contig(16_569, 900, 13, deep=True)}
+    return refs, per
+
+
+@pytest.mark.parametrize("index", [True, False])
+@pytest.mark.parametrize("block_every", [None, 7])
+def test_bam_round_trip(tmp_path, index, block_every):
+    refs, per = _dataset()
+    path = str(tmp_path / "t.bam")
+    write_bam(path, refs, per, write_index=index, block_every=block_every,
+              header_text="@HD\tVN:1.6\tSO:coordinate\n@PG\tID:bwa\tPN:bwa\n")
+    with BamReader(path) as r:
+        assert r.target_names == [n for n, _ in refs] and r.target_lens == [l for _, l in refs]
+        assert r.has_index == index and "@PG\tID:bwa" in r.header_text
+        # any order of contigs, including going back and an empty one
+        for tid in (3, 0, 2, 1, 0):
+            got = r.fetch_contig(tid)
+            _same(got, per.get(tid, ContigRecords.empty()))
+
+
+def test_bam_sequences_and_long_cigar_tag(tmp_path):
+    L = 4000
+    ref = synth.make_reference(L, 3)
+    rec = synth.short_read_contig(L, 15, 21, with_seq=True, ref=ref)
+    lr = synth.long_read_contig(20_000, 10, 5)
+    refs = [("chrA", L), ("chrB", 20_000)]
+    path = str(tmp_path / "s.bam")
+    write_bam(path, refs, {0: rec, 1: lr}, long_cigar_tag=True)
+    with BamReader(path) as r:
+        _same(r.fetch_contig(0, with_seq=True), rec, seq=True)
+        _same(r.fetch_contig(1), lr)            # CIGARs come back from the CG tag
+
+
+def test_fasta_fetch(tmp_path):
+    a = synth.make_reference(1234, 1, lowercase=True)
+    b = synth.make_reference(61, 2)
+    c = np.zeros(0, np.uint8)
+    path = str(tmp_path / "r.fa")
+    write_fasta(path, [("chr1", a), ("chr2", b), ("empty", c)], width=50)
+    f = FastaReader(path)
+    assert np.array_equal(f.fetch("chr2"), b) and np.array_equal(f.fetch("chr1"), a)
+    assert f.fetch("empty").shape[0] == 0 and f.fetch("nope").shape[0] == 0
+    f.close()
+    with pytest.raises(OSError):
+        FastaReader(str(tmp_path / "missing.fa"))
+
+
+def test_not_a_bam(tmp_path):
+    p = tmp_path / "x.bam"
+    p.write_bytes(b"hello world, not bgzf at all........")
+    with pytest.raises(OSError):
+        BamReader(str(p))
+
+
+def test_config1_chrM_plumbing_through_files(tmp_path):
+    """BASELINE.json configs[0]: coverage -L chrM on a tiny ~16 kb BAM @ 20x -- file plumbing only, the
+    per-position work done by the CPU oracle: records read back from BAM/FASTA files give the same
+    BED as the in-memory records."""
+    import oracle
+    from helpers import make_options, oracle_run
+    L = 16_569
+    seed = synth.seed_for(1, 24)
+    rec = synth.short_read_contig(L, 20, seed)
+    ref = synth.make_reference(L, seed, lowercase=True)
+    refs = [("chr1", 50_000), ("chrM", L)]
+    other = synth.short_read_contig(50_000, 5, seed + 1)
+    bam = str(tmp_path / "m.bam"); fa = str(tmp_path / "m.fa")
+    write_bam(bam, refs, {0: other, 1: rec})
+    write_fasta(fa, [("chr1", synth.make_reference(50_000, 9)), ("chrM", ref)])
+    with BamReader(bam) as r:
+        tid = r.target_names.index("chrM")
+        got = r.fetch_contig(tid)
+        assert r.target_lens[tid] == L
+    f = FastaReader(fa); ref2 = f.fetch("chrM"); f.close()
+    assert np.array_equal(ref2, ref)
+    opt = make_options({})
+    _, bed_files = oracle_run([("chrM", 1, L, ref2, got)], opt, str(tmp_path / "a.bed"))
+    _, bed_mem = oracle_run([("chrM", 1, L, ref, rec)], opt, str(tmp_path / "b.bed"))
+    assert bed_files == bed_mem and bed_files.count("\n") > 10

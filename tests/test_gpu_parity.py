@@ -357,3 +357,44 @@ def test_full_size_chr21_properties_and_sampled_regions(tmp_path):
         lo_p, hi_p = a, min(b, L) - (0 if b >= L else 0)
         for name, arr_o, arr_g in (("raw", d[0], raw), ("qc", d[1], qc), ("low", d[2], low), ("state", d[3], state)):
             assert np.array_equal(arr_o[lo_p:hi_p], arr_g[lo_p:hi_p]), (name, a)
+
+
+def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
+    import json as _json
+    import subprocess
+    from bamio import write_bam, write_fasta
+    from decodingustools_amd import build as _b
+    from decodingustools_amd.bam import coverage_files
+    names = ["chr1", "chr2", "chrX", "chrM"]
+    lens = [120_000, 40_000, 30_000, 16_569]
+    recs = {0: synth.short_read_contig(lens[0], 30, 700), 1: synth.adversarial_contig(lens[1], 3000, 701, deep=True),
+            3: synth.short_read_contig(lens[3], 20, 703)}
+    refs = [synth.make_reference(l, 800 + i, lowercase=(i == 3)) for i, l in enumerate(lens)]
+    bam = str(tmp_path / "t.bam"); fa = str(tmp_path / "t.fa")
+    write_bam(bam, list(zip(names, lens)), recs, block_every=1000)
+    write_fasta(fa, list(zip(names, refs)))
+    contigs = [(n, t, lens[t], refs[t], recs.get(t, ContigRecords.empty())) for t, n in enumerate(names)]
+    o_res, o_bed = oracle_run(contigs, make_options({}), str(tmp_path / "o.bed"))
+    bed = str(tmp_path / "g.bed"); js = str(tmp_path / "summary.json")
+    coverage_files(bam, fa, bed, js, CallableOptions())
+    assert open(bed).read() == o_bed
+    summ = _json.load(open(js))
+    assert [c["name"] for c in summ["contigs"]] == ["chr1", "chr2", "chrX", "chrM"]
+    for c in summ["contigs"]:
+        st = o_res[c["name"]]["stats"]
+        assert c["unique_reads"] == st["n_reads"] and c["average_depth"] == st["derived"]["average_depth"]
+        assert c["quality_stats"]["average_baseq"] == st["derived"]["average_baseq"]
+        assert c["state_distribution"]["callable"] == o_res[c["name"]]["state_counts"][1]
+    # -L subset + option flags through the command line tool
+    sub = [contigs[1], contigs[3]]
+    oo = dict(min_depth=2, max_depth=50, min_base_quality=13, max_low_mapq_fraction=0.25)
+    _, o_bed2 = oracle_run(sub, make_options(oo), str(tmp_path / "o2.bed"))
+    out = str(tmp_path / "cli.bed")
+    r = subprocess.run([_b.CLI, "coverage", bam, "-r", fa, "-o", out, "-L", "chr2", "-L", "chrM", "-L", "nope",
+                        "--min-depth", "2", "--max-depth=50", "--min-base-quality", "13", "--max-low-mapq-fraction", "0.25"],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert open(out).read() == o_bed2
+    assert (tmp_path / "summary.json").exists()
+    r = subprocess.run([_b.CLI, bam, "-r", fa, "-o", out, "-L", "nope"], cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 1 and "None of the specified contigs (nope) were found in the BAM file" in r.stderr

@@ -628,15 +628,27 @@ cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, ui
         if (t->cigar_off[i + 1] < t->cigar_off[i] || t->seq_off[i + 1] < t->seq_off[i])
             return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
     const uint64_t ncig = t->cigar_off[n], nbase = t->seq_off[n];
-    DevBuf<int32_t> d_pos; DevBuf<uint8_t> d_mapq, d_seq; DevBuf<uint32_t> d_coff, d_cig, d_p0, d_ix, d_hist;
+    // bucket index: first sorted site at or after every 256th position
+    const uint32_t n_buckets = (uint32_t)(((uint64_t)pos0.back() >> 8) + 2);
+    std::vector<uint32_t> bucket(n_buckets);
+    {
+        size_t j = 0;
+        for (uint32_t bk = 0; bk < n_buckets; ++bk) {
+            while (j < pos0.size() && pos0[j] < ((uint64_t)bk << 8)) ++j;
+            bucket[bk] = (uint32_t)j;
+        }
+    }
+    DevBuf<int32_t> d_pos; DevBuf<uint8_t> d_mapq, d_seq; DevBuf<uint32_t> d_coff, d_cig, d_p0, d_ix, d_hist, d_bk;
     DevBuf<unsigned long long> d_soff;
     cl_status rc = CL_OK;
     auto cleanup = [&]() { d_pos.release(); d_mapq.release(); d_seq.release(); d_coff.release(); d_cig.release();
-                           d_p0.release(); d_ix.release(); d_hist.release(); d_soff.release(); };
+                           d_p0.release(); d_ix.release(); d_hist.release(); d_soff.release(); d_bk.release(); };
 #define SITE_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = fail(c, CL_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); cleanup(); return rc; } } while (0)
     SITE_TRY(d_pos.reserve(n)); SITE_TRY(d_mapq.reserve(n)); SITE_TRY(d_coff.reserve(n + 1)); SITE_TRY(d_soff.reserve(n + 1));
     SITE_TRY(d_cig.reserve(ncig + 1)); SITE_TRY(d_seq.reserve((nbase + 1) / 2 + 1));
     SITE_TRY(d_p0.reserve(pos0.size())); SITE_TRY(d_ix.reserve(pos0.size())); SITE_TRY(d_hist.reserve(n_sites * 16));
+    SITE_TRY(d_bk.reserve(n_buckets));
+    SITE_TRY(hipMemcpy(d_bk.p, bucket.data(), (size_t)n_buckets * 4, hipMemcpyHostToDevice));
     SITE_TRY(hipMemcpy(d_pos.p, t->pos, n * 4, hipMemcpyHostToDevice));
     SITE_TRY(hipMemcpy(d_mapq.p, t->mapq, n, hipMemcpyHostToDevice));
     SITE_TRY(hipMemcpy(d_coff.p, t->cigar_off, (n + 1) * 4, hipMemcpyHostToDevice));
@@ -651,7 +663,7 @@ cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, ui
     R.seq4 = d_seq.p; R.n = (uint32_t)n;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, 8192);
     hipLaunchKernelGGL(k_site_pileup, dim3(grid), dim3(kBlock), 0, c->stream, R, (uint32_t)min_quality, contig_len,
-                       (unsigned long long)ref_len, d_p0.p, d_ix.p, (uint32_t)pos0.size(), d_hist.p);
+                       (unsigned long long)ref_len, d_p0.p, d_ix.p, d_bk.p, n_buckets, (uint32_t)pos0.size(), d_hist.p);
     SITE_TRY(hipGetLastError());
     SITE_TRY(hipMemcpyAsync(hist, d_hist.p, n_sites * 16 * 4, hipMemcpyDeviceToHost, c->stream));
     SITE_TRY(hipStreamSynchronize(c->stream));

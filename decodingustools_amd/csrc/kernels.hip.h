@@ -1084,7 +1084,8 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint8_t *__restrict_
 // ---------------------------------------------------------------------------------------------
 // config 5: site-list pileup (src/haplogroup/caller.rs:62-152).  Thread per read; for every
 // M/=/X base whose 1-based position is a listed site, hist[site][4-bit code] += 1.
-// site_of: dense map position(0-based) -> site index or 0xFFFFFFFF, length map_len.
+// sorted_pos0 / sorted_idx: the sites sorted by 0-based position and their original indices;
+// bucket[b]: index of the first sorted site with position >= 256*b.
 // ---------------------------------------------------------------------------------------------
 struct SiteReads {
     const int32_t  *pos;
@@ -1100,7 +1101,9 @@ __global__ __launch_bounds__(kBlock) void k_site_pileup(SiteReads R, uint32_t mi
                                                          unsigned long long ref_len,
                                                          const uint32_t *__restrict__ sorted_pos0,
                                                          const uint32_t *__restrict__ sorted_idx,
-                                                         uint32_t n_sites, uint32_t *__restrict__ hist)
+                                                         const uint32_t *__restrict__ bucket,
+                                                         uint32_t n_buckets, uint32_t n_sites,
+                                                         uint32_t *__restrict__ hist)
 {
     for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < R.n; r += gridDim.x * kBlock) {
         if ((uint32_t)R.pos[r] >= contig_len) continue;          // fetch("chr:1-len"), caller.rs:33-36
@@ -1111,9 +1114,10 @@ __global__ __launch_bounds__(kBlock) void k_site_pileup(SiteReads R, uint32_t mi
         for (uint32_t k = R.cigar_off[r]; k < R.cigar_off[r + 1]; ++k) {
             const uint32_t c = R.cigar[k], op = c & 15u, l = c >> 4;
             if (op_match(op)) {
-                // sites with 0-based position in [x, x+l): binary search the first one
-                uint32_t lo = 0, hi = n_sites;
-                while (lo < hi) { uint32_t m = lo + ((hi - lo) >> 1); if (sorted_pos0[m] < x) lo = m + 1; else hi = m; }
+                // sites with 0-based position in [x, x+l): bucket[b] = first site with position >= 256*b
+                const unsigned long long bx = x >> 8;
+                uint32_t lo = bx < n_buckets ? bucket[bx] : n_sites;
+                while (lo < n_sites && sorted_pos0[lo] < x) ++lo;
                 for (; lo < n_sites && sorted_pos0[lo] < x + l; ++lo) {
                     const unsigned long long p = sorted_pos0[lo];
                     const unsigned long long qi = y + (p - x);

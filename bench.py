@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--length", type=int, default=46_709_983, help="contig length (default chr21)")
     ap.add_argument("--depth", type=float, default=30.0)
     ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="positions of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank logic on one GPU)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -69,12 +70,16 @@ def main():
 
     import torch
     import torch.distributed as dist
+    n_dev = torch.cuda.device_count()
+    dev_id = local_rank % max(n_dev, 1)          # one GPU per rank on a real node
+    torch.cuda.set_device(dev_id)
+    coll_dev = "cuda" if args.backend == "nccl" else "cpu"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_id))
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     import __graft_entry__ as ge
     if rank == 0:
@@ -94,7 +99,7 @@ def main():
         f"({time.perf_counter() - t0:.1f}s)")
 
     opt = CallableOptions()          # the CLI defaults (cli.rs:34-60)
-    eng = Engine(opt, local_rank)
+    eng = Engine(opt, dev_id)
     tmpd = tempfile.mkdtemp()
     # ---- first pass through the module API: admission + H2D + kernels + D2H + BED text ----
     counter = CallableProfiler(os.path.join(tmpd, f"g{rank}.bed"))
@@ -131,12 +136,12 @@ def main():
         "resident re-run changed the result"
 
     # max over ranks + RCCL gather of the per-contig summaries (the path's only exchange)
-    tsr = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tsr = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     summ = torch.tensor([int(x) for x in first.state_counts] +
                         [int(first.summary.n_covered_bases), int(first.summary.summed_coverage),
                          int(first.summary.summed_baseq), int(first.summary.summed_mapq),
                          int(first.summary.quality_bases), int(first.summary.extent)],
-                        dtype=torch.int64, device="cuda")
+                        dtype=torch.int64, device=coll_dev)
     if world > 1:
         dist.all_reduce(tsr, op=dist.ReduceOp.MAX)
         allsum = [torch.zeros_like(summ) for _ in range(world)]

@@ -476,7 +476,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
     constexpr int kWaves = kBlock / 64;
     constexpr int kSegRound = 2;                    // segments a lane may emit per round
-    constexpr int kListCap = 64 * kSegRound;        // entries of one wave's list
+    constexpr int kListCap = 64 * kSegRound + 16;   // entries of one wave's list (+ carried-over entries)
     constexpr uint32_t kLutLds = 256;
     // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
     // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
@@ -554,6 +554,49 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
     unsigned long long sumq = 0;
     const uint32_t ql = lane & 3u, quad = lane >> 2;
     uint2 *list = s_list[wv];
+    uint32_t n_keep = 0;                            // list entries carried over from the previous round (< 16)
+    // quads consume list entries [0, n_use): quad q takes entries q*Q .. q*Q+Q-1 (Q = n_use/16 rounded
+    // up), i.e. concurrently active quads are Q entries (~4Q reads) apart.  Three units per lane and
+    // trip: u, u+4, u+8; a unit past the end is clamped onto the last one and gets an empty mask.
+    // MODE 0: 8-bit two-set counters, 1: 16-bit fields, 2: 32-bit words (DEEP)
+    auto consume = [&](auto mode_tag, uint32_t n_use) {
+        constexpr int MODE = decltype(mode_tag)::value;
+        const uint32_t Q = (n_use + 15u) >> 4;
+        for (uint32_t i = 0; i < Q; ++i) {
+            const uint32_t idx = quad * Q + i;
+            uint2 d = make_uint2(0u, 0u);
+            if (idx < n_use) d = list[idx];
+            const SegView sv = seg_view(d, ql);
+            for (uint32_t u = sv.ub; u <= sv.u1; u += 12u) {
+                Q16 v[3];
+                uint32_t uu[3];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t un = u + 4u * j;
+                    uu[j] = un < sv.u1 ? un : sv.u1;
+                    __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const uint32_t ps = uu[j] << 4;
+                    const uint32_t vs = sv.srel > ps ? sv.srel - ps : 0u;
+                    uint32_t ve = (sv.trel - ps) < 16u ? (sv.trel - ps) : 16u;
+                    ve = (sv.on && u + 4u * j <= sv.u1) ? ve : 0u;
+                    const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                    const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                    if (MODE == 2) sq32 += apply_unit32<ORF>(v[j], vm, uu[j], s_qcw, a.o);
+                    else if (MODE == 0) sq32 += apply_unit8<ORF>(v[j], vm, uu[j], sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                    else sq32 += apply_unit16<ORF>(v[j], vm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                }
+            }
+        }
+    };
+    auto consume_list = [&](uint32_t n_use) {
+        if (a.ablate & 1u) return;
+        if (DEEP) consume(std::integral_constant<int, 2>{}, n_use);
+        else if (mode8) consume(std::integral_constant<int, 0>{}, n_use);
+        else consume(std::integral_constant<int, 1>{}, n_use);
+    };
     for (uint32_t base = lo; base < ((a.ablate & 2u) ? lo : hi); base += kBlock) {
         const uint32_t r = base + 4u * lane + wv;
         __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
@@ -629,8 +672,9 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
                     if (live) cw = a.R.cigar[k];
                 }
             }
-            // -- wave-private list in lane (= position) order: first segments, then second ones --
-            uint32_t n_list = 0;
+            // -- wave-private list in lane (= position) order: carried-over entries, first segments,
+            //    then second ones --
+            uint32_t n_list = n_keep;
 #pragma unroll
             for (int i = 0; i < kSegRound; ++i) {
                 const bool has = (seg[i].y >> 31) != 0u;
@@ -644,52 +688,26 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // -- quads consume: quad q takes entries q*Q .. q*Q+Q-1, i.e. concurrently active
-            //    quads are Q list entries (~4Q reads) apart --
-            if (!(a.ablate & 1u)) {
-                const uint32_t Q = (n_list + 15u) >> 4;
-                // MODE 0: 8-bit two-set counters, 1: 16-bit fields, 2: 32-bit words (DEEP)
-                auto consume = [&](auto mode_tag) {
-                    constexpr int MODE = decltype(mode_tag)::value;
-                    for (uint32_t i = 0; i < Q; ++i) {
-                        const uint32_t idx = quad * Q + i;
-                        uint2 d = make_uint2(0u, 0u);
-                        if (idx < n_list) d = list[idx];
-                        const SegView sv = seg_view(d, ql);
-                        // three units per lane and trip: u, u+4, u+8; a unit past the end is clamped
-                        // onto the last one and gets an empty mask
-                        for (uint32_t u = sv.ub; u <= sv.u1; u += 12u) {
-                            Q16 v[3];
-                            uint32_t uu[3];
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const uint32_t un = u + 4u * j;
-                                uu[j] = un < sv.u1 ? un : sv.u1;
-                                __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
-                            }
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                const uint32_t ps = uu[j] << 4;
-                                const uint32_t vs = sv.srel > ps ? sv.srel - ps : 0u;
-                                uint32_t ve = (sv.trel - ps) < 16u ? (sv.trel - ps) : 16u;
-                                ve = (sv.on && u + 4u * j <= sv.u1) ? ve : 0u;
-                                const uint4 ms = s_mstart[vs], me = s_mend[ve];
-                                const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
-                                if (MODE == 2) sq32 += apply_unit32<ORF>(v[j], vm, uu[j], s_qcw, a.o);
-                                else if (MODE == 0) sq32 += apply_unit8<ORF>(v[j], vm, uu[j], sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                                else sq32 += apply_unit16<ORF>(v[j], vm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                            }
-                        }
-                    }
-                };
-                if (DEEP) consume(std::integral_constant<int, 2>{});
-                else if (mode8) consume(std::integral_constant<int, 0>{});
-                else consume(std::integral_constant<int, 1>{});
-            }
+            // -- only full groups of 16 entries are consumed now; the < 16 left over move to the front
+            //    of the list and wait for the next round (or for the flush after the last pass) --
+            const uint32_t n_full = n_list & ~15u;
+            if (n_full) consume_list(n_full);
+            n_keep = n_list - n_full;
+            uint2 carry = make_uint2(0u, 0u);
+            if (n_full && lane < n_keep) carry = list[n_full + lane];
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();       // the list is rewritten in the next round
+            __builtin_amdgcn_wave_barrier();       // the list is rewritten below and in the next round
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (n_full && lane < n_keep) list[lane] = carry;
             if (!__any(live)) break;
         }
+        sumq += sq32; sq32 = 0;
+    }
+    if (n_keep) {                                   // flush what the last round left over
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        consume_list(n_keep);
         sumq += sq32; sq32 = 0;
     }
     __syncthreads();

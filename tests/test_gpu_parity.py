@@ -398,3 +398,38 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     assert (tmp_path / "summary.json").exists()
     r = subprocess.run([_b.CLI, bam, "-r", fa, "-o", out, "-L", "nope"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 1 and "None of the specified contigs (nope) were found in the BAM file" in r.stderr
+
+
+def test_hifi_like_long_match_runs_and_truncated_qualities(tmp_path):
+    """Reads of 8-20 kb with few, kilobase-long M runs (segments that span whole windows and need
+    several trips), plus reads whose quality array is shorter than the CIGAR's query length (the
+    reference's `qual().get(qpos)` is None beyond it) and reads with exactly 64 / 65 CIGAR ops
+    (either side of the checkpointing threshold)."""
+    L = 120_000
+    rng = np.random.default_rng(77)
+    reads = []
+    for i, p in enumerate(np.sort(rng.integers(0, L - 21_000, size=260))):
+        tl = int(rng.integers(8_000, 20_000))
+        ops, left = [], tl
+        if rng.random() < 0.3: ops.append(("S", int(rng.integers(10, 400))))
+        while left > 0:
+            m = int(min(left, rng.integers(300, 5_000)))
+            ops.append((str(rng.choice(["M", "=", "M"])), m)); left -= m
+            if left > 0:
+                g = rng.random()
+                if g < 0.4: ops.append(("I", int(rng.integers(1, 4))))
+                elif g < 0.8: ops.append(("D", int(rng.integers(1, 30))))
+                else: ops.append(("X", 1))
+        qlen = sum(l for o, l in ops if o in "MIS=X")
+        q = rng.choice([7, 19, 20, 35, 50], size=qlen).tolist()
+        if i % 9 == 0: q = q[: qlen // 2]                      # truncated quality array
+        reads.append((int(p), "".join(f"{l}{o}" for o, l in ops), int(rng.choice([0, 5, 40, 60])), q, 0, f"h{i}"))
+    for n_ops, p in ((64, 500), (65, 700), (63, 900), (129, 1100)):
+        cig = "".join("20M1I" if k % 2 == 0 else "20M2D" for k in range((n_ops - 1) // 2)) + ("30M" if n_ops % 2 else "10M5S")
+        from decodingustools_amd.records import cigar_from_string, cigar_query_length
+        assert len(cigar_from_string(cig)) == n_ops
+        reads.append((p, cig, 60, 30, 0, f"c{n_ops}"))
+    reads.sort(key=lambda r: r[0])
+    rec = ContigRecords.from_reads(reads)
+    ref = synth.make_reference(L, 78)
+    compare([("hifi", 3, L, ref, rec)], dict(min_depth=3, min_depth_for_low_mapq=4), tmp_path, "hifi")

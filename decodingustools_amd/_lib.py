@@ -1,4 +1,4 @@
-"""ctypes binding of libcallable_hip.so (include/callable_loci.h + include/dut_coverage.h).
+"""ctypes binding of libcallable_hip.so (include/callable_loci.h, dut_coverage.h, dut_bam.h, dut_report.h).
 
 There is no fallback: if the shared library is missing or does not load, importing the engine
 raises.  Build it with `python -m decodingustools_amd.build` (or __graft_entry__.build()).
@@ -69,10 +69,17 @@ class dut_genome_summary(C.Structure):
                 ("contigs_analyzed", C.c_uint64)]
 
 
+class dut_export_meta(C.Structure):
+    _fields_ = [("aligner", C.c_char_p), ("reference_build", C.c_char_p),
+                ("sequencing_platform", C.c_char_p), ("read_length", C.c_uint64),
+                ("bed_file", C.c_char_p), ("summary_html", C.c_char_p),
+                ("coverage_plots", C.POINTER(C.c_char_p)), ("n_coverage_plots", C.c_size_t)]
+
+
 CL_K_NAMES = ("prep", "bounds", "pileup", "rle")
 CL_K_COUNT = 4
 
-# every symbol the two headers declare: (name, restype, argtypes)
+# every symbol the headers declare: (name, restype, argtypes)
 SYMBOLS = [
     ("cl_abi_version", C.c_int, []),
     ("cl_device_count", C.c_int, []),
@@ -124,8 +131,36 @@ SYMBOLS = [
     ("dut_fasta_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("dut_fasta_close", None, [C.c_void_p]),
     ("dut_fasta_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
-    ("dut_coverage_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(cl_options),
-                                     C.POINTER(C.c_char_p), C.c_size_t, C.c_int, C.c_char_p, C.c_size_t]),
+    ("dut_coverage_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                     C.POINTER(cl_options), C.POINTER(C.c_char_p), C.c_size_t, C.c_int,
+                                     C.c_char_p, C.c_size_t]),
+    ("dut_bam_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    # include/dut_report.h
+    ("dut_detect_aligner", C.c_char_p, [C.c_char_p, C.c_size_t]),
+    ("dut_reference_build", C.c_char_p, [C.c_char_p, C.c_size_t]),
+    ("dut_detect_platform_from_qname", C.c_int, [C.c_char_p, C.c_size_t]),
+    ("dut_parse_read_name", C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p),
+                                      C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("dut_infer_specific_platform", C.c_char_p, [C.c_int, C.c_char_p]),
+    ("dut_bam_stats_new", C.c_void_p, [C.c_size_t]),
+    ("dut_bam_stats_free", None, [C.c_void_p]),
+    ("dut_bam_stats_set_header", None, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    ("dut_bam_stats_add", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint16, C.c_uint32, C.c_char_p, C.c_size_t,
+                                    C.c_int32]),
+    ("dut_bam_stats_collect", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t]),
+    ("dut_bam_stats_aligner", C.c_char_p, [C.c_void_p]),
+    ("dut_bam_stats_reference_build", C.c_char_p, [C.c_void_p]),
+    ("dut_bam_stats_infer_platform", C.c_char_p, [C.c_void_p]),
+    ("dut_bam_stats_primary_platform", C.c_int, [C.c_void_p]),
+    ("dut_bam_stats_read_count", C.c_uint64, [C.c_void_p]),
+    ("dut_bam_stats_average_read_length", C.c_uint64, [C.c_void_p]),
+    ("dut_bam_stats_modal_read_length", C.c_uint64, [C.c_void_p]),
+    ("dut_bam_stats_get", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double)]),
+    ("dut_format_f64", C.c_size_t, [C.c_double, C.c_char_p]),
+    ("dut_coverage_output_json", C.c_int, [C.POINTER(dut_contig_stats), C.POINTER(C.c_char_p),
+                                           C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(dut_export_meta),
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("dut_free", None, [C.c_void_p]),
 ]
 
 

@@ -2,6 +2,7 @@
 // file-level `coverage` driver.  Host-only code (zlib for the inflate); the per-position work is the
 // device engine's (callable_loci.hip).
 #include "../../include/dut_bam.h"
+#include "../../include/dut_report.h"
 
 #include <zlib.h>
 
@@ -335,6 +336,27 @@ done:
     return CL_OK;
 }
 
+int dut_bam_sample(dut_bam *b, dut_bam_sample_fn fn, void *ud)
+{
+    if (!b || !fn) return CL_ERR_INVALID;
+    b->err.clear();
+    b->pending = false;
+    b->last_tid_done = -1;
+    if (!b->z.seek(b->data_start)) { b->err = "rewind failed"; return CL_ERR_INVALID; }
+    int rc = CL_OK;
+    for (uint64_t i = 0;; ++i) {
+        if (!read_record(b)) { if (!b->err.empty()) rc = CL_ERR_INVALID; break; }
+        const uint8_t *r = b->rec.data();
+        const uint32_t l_read_name = r[8];
+        if (l_read_name == 0 || 32ull + l_read_name > b->rec.size()) { b->err = "malformed BAM record"; rc = CL_ERR_INVALID; break; }
+        if (!fn(ud, i, rd16(r + 14), rd32(r + 16), r + 32, l_read_name - 1, (int32_t)rd32(r + 28))) break;
+    }
+    // leave the reader at the first record again
+    b->pending = false;
+    if (!b->z.seek(b->data_start) && rc == CL_OK) { b->err = "rewind failed"; rc = CL_ERR_INVALID; }
+    return rc;
+}
+
 } // extern "C"
 
 // ---------------------------------------------------------------------------------------------
@@ -401,33 +423,22 @@ int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint6
 // ---------------------------------------------------------------------------------------------
 // the file-level coverage driver
 // ---------------------------------------------------------------------------------------------
-namespace {
-
-void json_num(std::string &s, double v)
-{
-    char b[64];
-    if (v == std::floor(v) && std::fabs(v) < 1e15) snprintf(b, sizeof(b), "%.1f", v);   // serde_json prints 60.0
-    else snprintf(b, sizeof(b), "%.17g", v);
-    // shortest representation that round-trips
-    for (int prec = 1; prec < 17; ++prec) {
-        char t[64]; snprintf(t, sizeof(t), "%.*g", prec, v);
-        if (strtod(t, nullptr) == v) { if (strchr(t, '.') || strchr(t, 'e') || strchr(t, 'n') || strchr(t, 'i')) snprintf(b, sizeof(b), "%s", t); else snprintf(b, sizeof(b), "%s.0", t); break; }
-    }
-    s += b;
-}
-
-} // namespace
-
 extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
-                                  const char *summary_json, const cl_options *opt, const char *const *contigs,
-                                  size_t n_contigs, int device_id, char *err, size_t err_len)
+                                  const char *summary_json, const char *summary_html, const cl_options *opt,
+                                  const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len)
 {
     if (!bam_path || !fasta_path || !bed_path || !opt) { set_err(err, err_len, "null argument"); return CL_ERR_INVALID; }
     char e[512] = {0};
+    dut_bam_stats *bstats = dut_bam_stats_new(10000);                  // api/coverage.rs:56-59
+    if (dut_bam_stats_collect(bstats, bam_path, e, sizeof(e)) != CL_OK) {
+        set_err(err, err_len, std::string("Failed to collect BAM stats: ") + e);
+        dut_bam_stats_free(bstats);
+        return CL_ERR_INVALID;
+    }
     dut_bam *bam = dut_bam_open(bam_path, e, sizeof(e));
-    if (!bam) { set_err(err, err_len, std::string("Failed to open BAM file: ") + e); return CL_ERR_INVALID; }   // api/coverage.rs:69-70
+    if (!bam) { dut_bam_stats_free(bstats); set_err(err, err_len, std::string("Failed to open BAM file: ") + e); return CL_ERR_INVALID; }   // api/coverage.rs:69-70
     dut_fasta *fa = dut_fasta_open(fasta_path, e, sizeof(e));
-    if (!fa) { dut_bam_close(bam); set_err(err, err_len, std::string("Failed to open reference: ") + e); return CL_ERR_INVALID; }   // :73-74
+    if (!fa) { dut_bam_stats_free(bstats); dut_bam_close(bam); set_err(err, err_len, std::string("Failed to open reference: ") + e); return CL_ERR_INVALID; }   // :73-74
     // initialize_contig_stats / validate_contig_selection, api/coverage.rs:149-204
     std::vector<int> tids;
     for (int t = 0; t < dut_bam_n_ref(bam); ++t) {
@@ -470,37 +481,29 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         stats.push_back(st); names.push_back(dut_bam_ref_name(bam, t)); counts.push_back(std::vector<uint64_t>(c6, c6 + 6));
     }
     if (summary_json) {
-        // report.rs:37-134 numbers; contigs in compare_contig_names order
-        std::vector<size_t> order(stats.size());
-        for (size_t i = 0; i < order.size(); ++i) order[i] = i;
-        std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dut_compare_contig_names(names[a].c_str(), names[b].c_str()) < 0; });
-        std::vector<dut_contig_stats> so; std::vector<uint64_t> call;
-        for (size_t i : order) { so.push_back(stats[i]); call.push_back(counts[i][1]); }
-        dut_genome_summary g;
-        dut_genome_summary_build(so.data(), call.data(), so.size(), &g);
-        std::string s = "{\n  \"summary\": {\n";
-        s += "    \"total_bases\": " + std::to_string(g.total_bases) + ",\n    \"callable_bases\": " + std::to_string(g.callable_bases) + ",\n    \"callable_percentage\": ";
-        json_num(s, g.callable_percentage); s += ",\n    \"average_depth\": "; json_num(s, g.average_depth);
-        s += ",\n    \"contigs_analyzed\": " + std::to_string(g.contigs_analyzed) + "\n  },\n  \"contigs\": [\n";
-        for (size_t k = 0; k < order.size(); ++k) {
-            const size_t i = order[k];
-            dut_contig_derived d; dut_contig_derive(&stats[i], &d);
-            s += "    {\n      \"name\": \"" + names[i] + "\",\n      \"length\": " + std::to_string(stats[i].length) + ",\n      \"unique_reads\": " + std::to_string(stats[i].n_reads) + ",\n      \"coverage_percent\": ";
-            json_num(s, d.coverage_percent); s += ",\n      \"average_depth\": "; json_num(s, d.average_depth);
-            s += ",\n      \"covered_bases\": " + std::to_string(stats[i].n_covered_bases) + ",\n      \"total_bases\": " + std::to_string(stats[i].length) + ",\n      \"quality_stats\": {\n        \"average_mapq\": ";
-            json_num(s, d.average_mapq); s += ",\n        \"average_baseq\": "; json_num(s, d.average_baseq); s += ",\n        \"q30_percentage\": "; json_num(s, d.q30_percentage);
-            s += "\n      },\n      \"state_distribution\": {\n        \"ref_n\": " + std::to_string(counts[i][0]) + ",\n        \"callable\": " + std::to_string(counts[i][1]) + ",\n        \"no_coverage\": " + std::to_string(counts[i][2]) +
-                 ",\n        \"low_coverage\": " + std::to_string(counts[i][3]) + ",\n        \"excessive_coverage\": " + std::to_string(counts[i][4]) + ",\n        \"poor_mapping_quality\": " + std::to_string(counts[i][5]) + "\n      }\n    }";
-            s += (k + 1 < order.size()) ? ",\n" : "\n";
-        }
-        s += "  ],\n  \"quality_metrics\": {\n    \"average_mapq\": "; json_num(s, g.average_mapq); s += ",\n    \"average_baseq\": "; json_num(s, g.average_baseq);
-        s += ",\n    \"q30_percentage\": "; json_num(s, g.q30_percentage); s += "\n  },\n  \"total_unique_reads\": " + std::to_string(g.total_unique_reads) + "\n}\n";
+        // CoverageOutput as main.rs:68-69 serialises it (the HTML report and the SVG plots are not produced)
+        std::vector<const char *> nm;
+        std::vector<uint64_t> c6;
+        for (size_t i = 0; i < stats.size(); ++i) { nm.push_back(names[i].c_str()); c6.insert(c6.end(), counts[i].begin(), counts[i].end()); }
+        dut_export_meta meta;
+        memset(&meta, 0, sizeof(meta));
+        meta.aligner = dut_bam_stats_aligner(bstats);
+        meta.reference_build = dut_bam_stats_reference_build(bstats);
+        meta.sequencing_platform = dut_bam_stats_infer_platform(bstats);
+        meta.read_length = dut_bam_stats_average_read_length(bstats);
+        meta.bed_file = bed_path;
+        meta.summary_html = summary_html ? summary_html : "summary.html";
+        char *js = nullptr; size_t jl = 0;
+        rc = dut_coverage_output_json(stats.data(), nm.data(), c6.data(), stats.size(), &meta, &js, &jl);
+        if (rc != CL_OK) { set_err(err, err_len, "cannot build the summary"); goto out; }
         FILE *jf = fopen(summary_json, "wb");
-        if (!jf) { set_err(err, err_len, std::string("cannot create ") + summary_json); rc = CL_ERR_INVALID; goto out; }
-        fwrite(s.data(), 1, s.size(), jf);
+        if (!jf) { dut_free(js); set_err(err, err_len, std::string("cannot create ") + summary_json); rc = CL_ERR_INVALID; goto out; }
+        fwrite(js, 1, jl, jf);
         fclose(jf);
+        dut_free(js);
     }
 out:
+    dut_bam_stats_free(bstats);
     if (prof) dut_profiler_free(prof);
     if (ctx) cl_destroy(ctx);
     dut_fasta_close(fa);

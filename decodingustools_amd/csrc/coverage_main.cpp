@@ -1,6 +1,7 @@
 // dut-coverage -- the `coverage` subcommand of the reference CLI (src/cli.rs:14-61, src/main.rs:36-70)
-// on the MI355X engine.  Same flags and defaults; BED to -o, numeric summary to ./summary.json.
-// (-s/--summary names the reference's HTML report, which is presentation and not produced.)
+// on the MI355X engine.  Same flags and defaults; BED to -o, the CoverageOutput JSON to ./summary.json.
+// (-s/--summary names the reference's HTML report, which is presentation and not produced; the name
+// still appears in summary.json as files.summary_html.)
 #include "../../include/dut_bam.h"
 
 #include <cstdio>
@@ -54,7 +55,7 @@ int main(int argc, char **argv)
     }
     if (bam.empty() || ref.empty()) { usage(); return 2; }
     char err[1024] = {0};
-    const int rc = dut_coverage_files(bam.c_str(), ref.c_str(), out.c_str(), "summary.json", &opt,
+    const int rc = dut_coverage_files(bam.c_str(), ref.c_str(), out.c_str(), "summary.json", summary.c_str(), &opt,
                                       contigs.empty() ? nullptr : contigs.data(), contigs.size(), device, err, sizeof(err));
     if (rc != CL_OK) { fprintf(stderr, "Error: Analysis error: %s\n", err); return 1; }
     return 0;

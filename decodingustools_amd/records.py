@@ -97,7 +97,7 @@ class ContigRecords:
             cig.extend(words); coff.append(len(cig))
             qual.extend(ql); qoff.append(len(qual))
             nm = nm if nm is not None else f"r{i}"
-            names.extend(nm.encode()); noff.append(len(names))
+            names.extend(nm if isinstance(nm, bytes) else nm.encode()); noff.append(len(names))
             if sq is not None:
                 have_seq = True
                 seqcodes.extend(SEQ_CODES.index(c) for c in sq)

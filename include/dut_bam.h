@@ -38,6 +38,13 @@ int dut_bam_has_index(const dut_bam *b);
  * byte, continuous) are filled when non-NULL.  Returns 0 or a negative cl_status. */
 int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4);
 
+/* `bam.records()` on a plain reader (utils/bam_reader.rs:16-24): every record of the file, mapped or
+ * not, from the first one, until fn returns 0 or the file ends.  index = 0-based ordinal; qname
+ * without its NUL; tlen = the template length field.  The reader is left at the first record. */
+typedef int (*dut_bam_sample_fn)(void *ud, uint64_t index, uint16_t flag, uint32_t l_seq,
+                                 const uint8_t *qname, size_t qname_len, int32_t tlen);
+int dut_bam_sample(dut_bam *b, dut_bam_sample_fn fn, void *ud);
+
 /* FASTA with a .fai beside it (faidx).  NULL on failure. */
 dut_fasta *dut_fasta_open(const char *path, char *err, size_t err_len);
 void dut_fasta_close(dut_fasta *f);
@@ -45,14 +52,17 @@ void dut_fasta_close(dut_fasta *f);
  * name is unknown (every base then reads as 'N', mod.rs:79-80). */
 int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len);
 
-/* `coverage <bam> -r <fasta> -o <bed> [-L contig]...` on one GPU: per selected contig (ascending
- * tid) read, admit, run the engine, append BED lines; then write the numeric summary as JSON to
- * summary_json (may be NULL).  contigs == NULL selects every header contig.
+/* `coverage <bam> -r <fasta> -o <bed> -s <html> [-L contig]...` on one GPU: BamStats over the first
+ * 10000 records, then per selected contig (ascending tid) read, admit, run the engine, append BED
+ * lines; then write the CoverageOutput JSON (dut_report.h, what main.rs:68-69 puts in
+ * ./summary.json) to summary_json (may be NULL).  summary_html is only named in that JSON -- the
+ * HTML report itself is presentation and is not produced (NULL = "summary.html").
+ * contigs == NULL selects every header contig.
  * Errors: negative cl_status, message in err ("None of the specified contigs (...) were found in
  * the BAM file" for an -L list that matches nothing, api/coverage.rs:187-204). */
 int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
-                       const char *summary_json, const cl_options *opt, const char *const *contigs,
-                       size_t n_contigs, int device_id, char *err, size_t err_len);
+                       const char *summary_json, const char *summary_html, const cl_options *opt,
+                       const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len);
 
 #ifdef __cplusplus
 }

@@ -51,11 +51,13 @@ def _reg2bin(beg, end):
 
 
 def write_bam(path, refs, per_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", write_index=True, block_every=None,
-              long_cigar_tag=False):
+              long_cigar_tag=False, tlen=None, unmapped_tail=()):
     """refs: [(name, length)]; per_tid: {tid: ContigRecords} (coordinate sorted).  Writes path and,
     if asked, path + '.bai'.  block_every: start a new BGZF block every that many records (exercises
     records that straddle / start blocks).  long_cigar_tag: store CIGARs with more than 3 ops in a
-    CG:B,I tag behind the <l_seq>S<reflen>N placeholder, the way BAM stores > 65535 ops."""
+    CG:B,I tag behind the <l_seq>S<reflen>N placeholder, the way BAM stores > 65535 ops.
+    tlen: {tid: sequence of template lengths}; unmapped_tail: [(name bytes, flag, l_seq, tlen)] records
+    with refID -1 written after the last contig."""
     text = header_text + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in refs)
     w = _BgzfWriter(path)
     w.write(b"BAM\1" + struct.pack("<I", len(text)) + text.encode() + struct.pack("<I", len(refs)))
@@ -94,7 +96,7 @@ def write_bam(path, refs, per_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", w
                 aux += b"CG" + b"B" + b"I" + struct.pack("<I", len(cig)) + np.asarray(cig, dtype="<u4").tobytes()
                 cig_store = np.asarray([(l_seq << 4) | 4, (rlen << 4) | 3], dtype=np.uint32)
             body = struct.pack("<iiBBHHHIiii", tid, pos, len(name), int(rec.mapq[i]), _reg2bin(pos, end), len(cig_store),
-                               int(rec.flag[i]), l_seq, -1, -1, 0)
+                               int(rec.flag[i]), l_seq, -1, -1, int(tlen[tid][i]) if tlen and tid in tlen else 0)
             body += name + np.asarray(cig_store, dtype="<u4").tobytes() + seq + q + aux
             v0 = w.tell()
             w.write(struct.pack("<I", len(body)) + body)
@@ -106,6 +108,11 @@ def write_bam(path, refs, per_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", w
             for win in range(pos >> 14, ((end - 1) >> 14) + 1):
                 lin.setdefault(win, v0)
         index[tid] = (bins, lin)
+    for name, flag, l_seq, tl in unmapped_tail:
+        nm = bytes(name) + b"\0"
+        body = struct.pack("<iiBBHHHIiii", -1, -1, len(nm), 0, 4680, 0, int(flag), l_seq, -1, -1, int(tl))
+        body += nm + bytes((l_seq + 1) // 2) + b"\xff" * l_seq
+        w.write(struct.pack("<I", len(body)) + body)
     w.close()
     if write_index:
         with open(path + ".bai", "wb") as f:

@@ -376,9 +376,24 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     contigs = [(n, t, lens[t], refs[t], recs.get(t, ContigRecords.empty())) for t, n in enumerate(names)]
     o_res, o_bed = oracle_run(contigs, make_options({}), str(tmp_path / "o.bed"))
     bed = str(tmp_path / "g.bed"); js = str(tmp_path / "summary.json")
-    coverage_files(bam, fa, bed, js, CallableOptions())
+    coverage_files(bam, fa, bed, js, CallableOptions(), output_summary="rep.html")
     assert open(bed).read() == o_bed
-    summ = _json.load(open(js))
+    # summary.json: the CoverageOutput text, byte for byte (oracle: report.rs:15-134 + serde_json pretty)
+    from oracle import report_oracle as RO
+    hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(names, lens))
+    ob = RO.BamStats(10000); ob.set_header(hdr)
+    stream = []
+    for t in sorted(recs):
+        r = recs[t]
+        for i in range(r.n):
+            stream.append((int(r.flag[i]), int(r.qual_off[i + 1] - r.qual_off[i]), bytes(r.qname[r.qname_off[i]:r.qname_off[i + 1]]), 0))
+    ob.collect(stream)
+    assert len(ob.infer_platform_candidates()) == 1
+    want = RO.coverage_output_json([o_res[n]["stats"] for n in names], names, [o_res[n]["state_counts"] for n in names],
+                                   ob.aligner, ob.reference_build, ob.infer_platform_candidates()[0], ob.average_read_length(),
+                                   bed, "rep.html")
+    assert open(js).read() == want
+    summ = _json.load(open(js))["export"]
     assert [c["name"] for c in summ["contigs"]] == ["chr1", "chr2", "chrX", "chrM"]
     for c in summ["contigs"]:
         st = o_res[c["name"]]["stats"]
@@ -395,7 +410,9 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
                        cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     assert open(out).read() == o_bed2
-    assert (tmp_path / "summary.json").exists()
+    cli_js = _json.load(open(tmp_path / "summary.json"))
+    assert cli_js["files"] == {"bed_file": out, "summary_html": "summary.html", "coverage_plots": []}
+    assert [c["name"] for c in cli_js["export"]["contigs"]] == ["chr2", "chrM"] and cli_js["export"]["summary"]["contigs_analyzed"] == 2
     r = subprocess.run([_b.CLI, bam, "-r", fa, "-o", out, "-L", "nope"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 1 and "None of the specified contigs (nope) were found in the BAM file" in r.stderr
 

@@ -1,4 +1,5 @@
-"""ctypes binding of libcallable_hip.so (include/callable_loci.h, dut_coverage.h, dut_bam.h, dut_report.h).
+"""ctypes binding of libcallable_hip.so (include/callable_loci.h, dut_coverage.h, dut_bam.h, dut_report.h,
+dut_haplogroup.h).
 
 There is no fallback: if the shared library is missing or does not load, importing the engine
 raises.  Build it with `python -m decodingustools_amd.build` (or __graft_entry__.build()).
@@ -74,6 +75,16 @@ class dut_export_meta(C.Structure):
                 ("sequencing_platform", C.c_char_p), ("read_length", C.c_uint64),
                 ("bed_file", C.c_char_p), ("summary_html", C.c_char_p),
                 ("coverage_plots", C.POINTER(C.c_char_p)), ("n_coverage_plots", C.c_size_t)]
+
+
+class dut_snp_call(C.Structure):
+    _fields_ = [("position", C.c_uint32), ("depth", C.c_uint32), ("freq", C.c_double), ("base", C.c_char)]
+
+
+class dut_haplogroup_result(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("score", C.c_double), ("matching_snps", C.c_uint32),
+                ("mismatching_snps", C.c_uint32), ("ancestral_matches", C.c_uint32), ("no_calls", C.c_uint32),
+                ("total_snps", C.c_uint32), ("cumulative_snps", C.c_uint32), ("depth", C.c_uint32)]
 
 
 CL_K_NAMES = ("prep", "bounds", "pileup", "rle")
@@ -161,6 +172,25 @@ SYMBOLS = [
                                            C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(dut_export_meta),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("dut_free", None, [C.c_void_p]),
+    # include/dut_haplogroup.h
+    ("dut_tree_parse", C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    ("dut_tree_load", C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
+    ("dut_tree_free", None, [C.c_void_p]),
+    ("dut_tree_total_nodes", C.c_size_t, [C.c_void_p]),
+    ("dut_tree_built_nodes", C.c_size_t, [C.c_void_p]),
+    ("dut_tree_root_name", C.c_char_p, [C.c_void_p]),
+    ("dut_tree_collect_sites", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(C.c_void_p),
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("dut_call_sites", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32,
+                                 C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    ("dut_tree_score", C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.POINTER(C.c_void_p),
+                                 C.POINTER(C.c_size_t), C.c_char_p, C.c_size_t]),
+    ("dut_write_haplogroup_report", C.c_int, [C.c_char_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                              C.c_size_t, C.c_char_p, C.c_int, C.c_char_p, C.c_size_t]),
+    ("dut_validate_reference", C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(C.c_char_p), C.c_size_t, C.c_int,
+                                         C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t]),
+    ("dut_find_branch_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint8,
+                                        C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
 ]
 
 

@@ -13,14 +13,16 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcallable_hip.so")
 SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "host_coverage.cpp"),
-           os.path.join(CSRC, "bam_io.cpp"), os.path.join(CSRC, "report.cpp")]
+           os.path.join(CSRC, "bam_io.cpp"), os.path.join(CSRC, "report.cpp"),
+           os.path.join(CSRC, "haplogroup.cpp")]
 CLI = os.path.join(LIBDIR, "dut-coverage")
 CLI_SRC = os.path.join(CSRC, "coverage_main.cpp")
 HEADERS = [os.path.join(CSRC, "kernels.hip.h"),
            os.path.join(HERE, "..", "include", "callable_loci.h"),
            os.path.join(HERE, "..", "include", "dut_coverage.h"),
            os.path.join(HERE, "..", "include", "dut_bam.h"),
-           os.path.join(HERE, "..", "include", "dut_report.h"), CLI_SRC]
+           os.path.join(HERE, "..", "include", "dut_report.h"),
+           os.path.join(HERE, "..", "include", "dut_haplogroup.h"), CLI_SRC]
 
 
 def _stale():

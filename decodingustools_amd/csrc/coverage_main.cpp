@@ -1,8 +1,10 @@
-// dut-coverage -- the `coverage` subcommand of the reference CLI (src/cli.rs:14-61, src/main.rs:36-70)
+// dut-coverage -- the `coverage`, `find-y-branch` and `find-mt-branch` subcommands of the reference CLI;
+// `coverage` is the default: (src/cli.rs:14-61, src/main.rs:36-70)
 // on the MI355X engine.  Same flags and defaults; BED to -o, the CoverageOutput JSON to ./summary.json.
 // (-s/--summary names the reference's HTML report, which is presentation and not produced; the name
 // still appears in summary.json as files.summary_html.)
 #include "../../include/dut_bam.h"
+#include "../../include/dut_haplogroup.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -19,8 +21,57 @@ static void usage()
             "       [--max-low-mapq-fraction 0.1] [--device 0]\n");
 }
 
+// find-y-branch / find-mt-branch (src/cli.rs:62-105, src/commands/find_branch.rs).  The reference
+// downloads the tree; here --tree names a local JSON file of the provider's shape.
+static int find_branch_main(int argc, char **argv, int tree_type)
+{
+    std::string bam, ref, out, tree;
+    uint32_t min_depth = 10; unsigned min_quality = 20;
+    int provider = DUT_PROVIDER_FTDNA, show_snps = 0, device = 0;
+    auto usage_fb = [&]() {
+        fprintf(stderr, "Usage: dut-coverage %s <BAM_FILE> -r <REFERENCE_FILE> <OUTPUT_FILE> --tree <TREE_JSON>\n"
+                        "       [--min-depth 10] [--min-quality 20] [--provider ftdna|decodingus] [--show-snps] [--device 0]\n",
+                tree_type == DUT_TREE_YDNA ? "find-y-branch" : "find-mt-branch");
+    };
+    for (int i = 2; i < argc; ++i) {
+        std::string a = argv[i], val;
+        const size_t eq = a.find('=');
+        const bool has_eq = a.rfind("--", 0) == 0 && eq != std::string::npos;
+        if (has_eq) { val = a.substr(eq + 1); a = a.substr(0, eq); }
+        auto next = [&]() -> const char * {
+            if (has_eq) return val.c_str();
+            if (i + 1 >= argc) { usage_fb(); exit(2); }
+            return argv[++i];
+        };
+        if (a == "-r" || a == "--reference") ref = next();
+        else if (a == "--tree") tree = next();
+        else if (a == "--min-depth") min_depth = (uint32_t)strtoul(next(), nullptr, 10);
+        else if (a == "--min-quality") min_quality = (unsigned)strtoul(next(), nullptr, 10);
+        else if (a == "--provider") {
+            const std::string p = next();
+            if (p == "ftdna") provider = DUT_PROVIDER_FTDNA;
+            else if (p == "decodingus") provider = DUT_PROVIDER_DECODINGUS;
+            else { fprintf(stderr, "error: invalid value '%s' for '--provider'\n", p.c_str()); return 2; }
+        }
+        else if (a == "--show-snps") show_snps = 1;
+        else if (a == "--device") device = atoi(next());
+        else if (a == "-h" || a == "--help") { usage_fb(); return 0; }
+        else if (!a.empty() && a[0] != '-' && bam.empty()) bam = a;
+        else if (!a.empty() && a[0] != '-' && out.empty()) out = a;
+        else { fprintf(stderr, "error: unexpected argument '%s'\n", argv[i]); usage_fb(); return 2; }
+    }
+    if (bam.empty() || ref.empty() || out.empty() || tree.empty()) { usage_fb(); return 2; }
+    char err[1024] = {0};
+    const int rc = dut_find_branch_files(bam.c_str(), ref.c_str(), tree.c_str(), out.c_str(), min_depth, (uint8_t)min_quality,
+                                         tree_type, provider, show_snps, device, err, sizeof(err));
+    if (rc != CL_OK) { fprintf(stderr, "Error: %s\n", err); return 1; }
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
+    if (argc > 1 && !strcmp(argv[1], "find-y-branch")) return find_branch_main(argc, argv, DUT_TREE_YDNA);
+    if (argc > 1 && !strcmp(argv[1], "find-mt-branch")) return find_branch_main(argc, argv, DUT_TREE_MTDNA);
     cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};      // src/cli.rs:34-60
     std::string bam, ref, out = "callable_regions.bed", summary = "summary.html";
     std::vector<const char *> contigs;

@@ -450,3 +450,75 @@ def test_hifi_like_long_match_runs_and_truncated_qualities(tmp_path):
     rec = ContigRecords.from_reads(reads)
     ref = synth.make_reference(L, 78)
     compare([("hifi", 3, L, ref, rec)], dict(min_depth=3, min_depth_for_low_mapq=4), tmp_path, "hifi")
+
+
+def test_find_y_branch_on_files_and_cli(tmp_path):
+    """find-y-branch end to end (config 5 plumbing): BAM + .bai, FASTA, a tree JSON of the FTDNA shape ->
+    TSV, against oracle site pileup -> call -> score -> report (caller.rs:62-152, scoring.rs, mod.rs:92-258)."""
+    import json as _json
+    import random
+    import subprocess
+    from bamio import write_bam, write_fasta
+    from decodingustools_amd import build as _b
+    from decodingustools_amd import haplogroup as H
+    from oracle import haplogroup_oracle as HO
+    import test_haplogroup as TH
+    L = 300_000
+    ref = synth.make_reference(L, 31)
+    rng = random.Random(21)
+    ok_pos = [p for p in rng.sample(range(20_000, L - 20_000), 900) if chr(ref[p - 1]).upper() in "ACGT"]
+    # tree alleles: ancestral = the reference base, derived = another base (1-based positions)
+    def fix(nodes):
+        for n in nodes.values():
+            for v in n["variants"]:
+                if v.get("position"):
+                    p = abs(v["position"])
+                    anc = chr(ref[p - 1]).upper()
+                    v["ancestral"] = anc; v["derived"] = rng.choice([b for b in "ACGT" if b != anc])
+    text = TH.ftdna_tree(rng, 250, ok_pos, extra=fix)
+    tree_path = str(tmp_path / "ytree.json"); open(tree_path, "w").write(text)
+    _, ot = HO.load_tree(text, "ftdna")
+    # the sample: derived alleles along one root-to-leaf path, written into the reference the reads follow
+    nodes = []
+    def walk(h, path):
+        nodes.append((h, path + [h["name"]]))
+        for c in h["children"]: walk(c, path + [h["name"]])
+    walk(ot, [])
+    deepest = max(nodes, key=lambda x: len(x[1]))[1]
+    sample = ref.copy()
+    for h, _ in nodes:
+        if h["name"] in deepest:
+            for l in h["loci"]:
+                c = l["coordinates"].get("GRCh38")
+                if c: sample[c["position"] - 1] = ord(c["derived"][0])
+    rec = synth.short_read_contig(L, 30, 77, with_seq=True, ref=sample)
+    names = ["chr1", "chrY", "chrM"]; lens = [248956422, L, 16569]        # the chr1 length marks the header as GRCh38 (types.rs:140-142)
+    bam = str(tmp_path / "y.bam"); fa = str(tmp_path / "y.fa")
+    write_bam(bam, list(zip(names, lens)), {1: rec}, block_every=5000)
+    write_fasta(fa, [("chrY", ref), ("chrM", synth.make_reference(16569, 32))])
+    # oracle
+    sites, rel = HO.sites_and_relevance(ot, "GRCh38", "chrY")
+    exp = oracle.site_pileup(10, 20, L, ref, rec, np.asarray(sites, np.uint32))
+    calls = HO.call_sites(sites, rel, exp["hist"], 10)
+    assert len(calls) > 300
+    for show in (False, True):
+        want, rows = HO.report_text(ot, calls, "GRCh38", show)
+        assert len(rows) >= len(deepest) - 3 and rows[0]["name"] == deepest[-1]
+        out = str(tmp_path / f"hap{int(show)}.tsv")
+        H.analyze_haplogroup(bam, fa, tree_path, out, show_snps=show)
+        assert open(out).read() == want
+    out = str(tmp_path / "cli.tsv")
+    r = subprocess.run([_b.CLI, "find-y-branch", bam, "-r", fa, out, "--tree", tree_path, "--min-depth", "12", "--min-quality=30", "--show-snps"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    exp2 = oracle.site_pileup(12, 30, L, ref, rec, np.asarray(sites, np.uint32))
+    want2, _ = HO.report_text(ot, HO.call_sites(sites, rel, exp2["hist"], 12), "GRCh38", True)
+    assert open(out).read() == want2
+    # mt tree from FTDNA has no rCRS coordinates: header only (ftdna.rs:30-38, mod.rs:51-54)
+    out = str(tmp_path / "mt.tsv")
+    H.analyze_haplogroup(bam, fa, tree_path, out, tree_type=H.MTDNA)
+    assert open(out).read().count("\n") == 1
+    with pytest.raises(Exception, match="Could not determine reference genome"):
+        bam2 = str(tmp_path / "n.bam")
+        write_bam(bam2, [("chrY", L)], {0: rec})
+        H.analyze_haplogroup(bam2, fa, tree_path, out)

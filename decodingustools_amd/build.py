@@ -17,7 +17,7 @@ SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "host_cov
            os.path.join(CSRC, "haplogroup.cpp")]
 CLI = os.path.join(LIBDIR, "dut-coverage")
 CLI_SRC = os.path.join(CSRC, "coverage_main.cpp")
-HEADERS = [os.path.join(CSRC, "kernels.hip.h"),
+HEADERS = [os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "host_parallel.h"),
            os.path.join(HERE, "..", "include", "callable_loci.h"),
            os.path.join(HERE, "..", "include", "dut_coverage.h"),
            os.path.join(HERE, "..", "include", "dut_bam.h"),

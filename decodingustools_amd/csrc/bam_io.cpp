@@ -3,10 +3,13 @@
 // device engine's (callable_loci.hip).
 #include "../../include/dut_bam.h"
 #include "../../include/dut_report.h"
+#include "host_parallel.h"
 
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cinttypes>
 #include <cmath>
 #include <cstdio>
@@ -14,6 +17,7 @@
 #include <cstring>
 #include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -113,24 +117,116 @@ struct Bgzf {
 
 struct RefSeq { std::string name; uint32_t len; };
 
-// nibble-continuous 4-bit sequence store (what cl_site_tile wants)
-struct Seq4 {
-    std::vector<uint8_t> bytes;
-    uint64_t n_bases = 0;
-    void clear() { bytes.clear(); n_bases = 0; }
-    void append(const uint8_t *packed, uint32_t l_seq)      // BAM packing: high nibble first
+// grow-only buffer without value initialisation (the decoded arrays are written exactly once)
+template <class T>
+struct RawBuf {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    ~RawBuf() { free(p); }
+    bool reserve(size_t need)
     {
-        if ((n_bases & 1u) == 0) {
-            bytes.insert(bytes.end(), packed, packed + (l_seq + 1) / 2);
-            if (l_seq & 1u) bytes.back() &= 0xF0;
-        } else {
-            for (uint32_t i = 0; i < l_seq; ++i) {
-                const uint8_t code = (i & 1u) ? (packed[i >> 1] & 15u) : (packed[i >> 1] >> 4);
-                const uint64_t pos = n_bases + i;
-                if (pos & 1u) bytes.back() |= code; else bytes.push_back((uint8_t)(code << 4));
+        if (need <= cap) return true;
+        size_t c = std::max<size_t>(need, cap + cap / 2 + 1024);
+        T *q = (T *)realloc(p, c * sizeof(T));
+        if (!q) return false;
+        p = q; cap = c;
+        return true;
+    }
+    void clear() { n = 0; }
+};
+
+using dut::parallel_for;
+
+// BGZF blocks inflated a batch at a time, the blocks of a batch in parallel (each block is an
+// independent deflate stream), into one contiguous buffer the record parser walks.
+struct BlockStream {
+    FILE *fp = nullptr;
+    uint64_t next_coff = 0;           // file offset of the next block to load
+    size_t skip = 0;                  // bytes to skip in the first block after a seek
+    bool valid = false, eof = false;
+    std::string err;
+    RawBuf<uint8_t> buf;              // inflated bytes; [cur, buf.n) not yet consumed
+    size_t cur = 0;
+    RawBuf<uint8_t> cbuf;
+    size_t batch = 32u << 20;         // compressed bytes per fill
+
+    void reset(uint64_t voff)
+    {
+        next_coff = voff >> 16; skip = (size_t)(voff & 0xFFFF);
+        buf.clear(); cur = 0; eof = false; err.clear(); valid = true;
+    }
+    // appends the next batch of blocks to buf (after dropping the consumed prefix); false at EOF or on error
+    bool fill()
+    {
+        if (cur) { memmove(buf.p, buf.p + cur, buf.n - cur); buf.n -= cur; cur = 0; }
+        if (eof) return false;
+        struct Blk { size_t in, clen, out; uint32_t isize, crc; };
+        std::vector<Blk> blks;
+        size_t got = 0, used = 0, out_total = 0;
+        for (;;) {
+            if (!cbuf.reserve(batch)) { err = "out of memory"; return false; }
+            if (fseeko(fp, (off_t)next_coff, SEEK_SET) != 0) { err = "seek failed"; return false; }
+            got = fread(cbuf.p, 1, batch, fp);
+            if (got == 0) { eof = true; return false; }
+            blks.clear(); used = 0; out_total = 0;
+            while (used + 18 <= got) {
+                const uint8_t *h = cbuf.p + used;
+                if (h[0] != 31 || h[1] != 139 || h[2] != 8 || !(h[3] & 4)) { err = "not a BGZF block"; return false; }
+                const size_t xlen = rd16(h + 10);
+                if (used + 12 + xlen > got) break;
+                int bsize = -1;
+                for (size_t i = 0; i + 4 <= xlen;) {
+                    const uint8_t *x = h + 12 + i;
+                    const size_t slen = rd16(x + 2);
+                    if (x[0] == 'B' && x[1] == 'C' && slen == 2 && i + 6 <= xlen) bsize = rd16(x + 4);
+                    i += 4 + slen;
+                }
+                if (bsize < 0) { err = "BGZF block without BC field"; return false; }
+                const size_t total = (size_t)bsize + 1, hlen = 12 + xlen;
+                if (total < hlen + 8) { err = "bad BGZF block size"; return false; }
+                if (used + total > got) break;
+                const uint32_t isize = rd32(h + total - 4);
+                if (isize > 65536) { err = "bad BGZF ISIZE"; return false; }
+                blks.push_back({used + hlen, total - hlen - 8, out_total, isize, rd32(h + total - 8)});
+                out_total += isize;
+                used += total;
             }
+            if (!blks.empty()) break;
+            if (got < batch) { err = "truncated BGZF block"; return false; }
+            batch *= 2;                                   // a block larger than the batch cannot happen (<= 64 KiB); be safe
         }
-        n_bases += l_seq;
+        next_coff += used;
+        const size_t base = buf.n;
+        if (!buf.reserve(base + out_total)) { err = "out of memory"; return false; }
+        buf.n = base + out_total;
+        std::atomic<int> bad{0};
+        const uint8_t *cp = cbuf.p;
+        uint8_t *op = buf.p + base;
+        // one z_stream per contiguous group of blocks
+        const size_t grain = 16;
+        parallel_for((blks.size() + grain - 1) / grain, 1, [&](size_t g) {
+            z_stream zs;
+            memset(&zs, 0, sizeof(zs));
+            if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+            const size_t e = std::min(blks.size(), (g + 1) * grain);
+            for (size_t i = g * grain; i < e; ++i) {
+                const Blk &b = blks[i];
+                if (!b.isize) continue;
+                inflateReset(&zs);
+                zs.next_in = const_cast<uint8_t *>(cp + b.in); zs.avail_in = (uInt)b.clen;
+                zs.next_out = op + b.out; zs.avail_out = b.isize;
+                const int rc = inflate(&zs, Z_FINISH);
+                if (rc != Z_STREAM_END || zs.total_out != b.isize) { bad = 2; break; }
+                if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), op + b.out, b.isize) != b.crc) { bad = 3; break; }
+            }
+            inflateEnd(&zs);
+        });
+        if (bad) { err = bad == 3 ? "BGZF CRC mismatch" : "inflate failed"; return false; }
+        if (skip) {
+            if (skip > buf.n - base) { err = "virtual offset beyond its block"; return false; }
+            cur += skip; skip = 0;
+        }
+        return true;
     }
 };
 
@@ -148,13 +244,13 @@ struct dut_bam {
     bool pending = false;                    // `rec` holds a record that was read but not consumed
     std::vector<uint8_t> rec;
     int32_t last_tid_done = -1;
+    BlockStream st;                          // the record stream of dut_bam_read_contig
     // SoA of the last contig read
-    std::vector<int32_t> pos;
-    std::vector<uint16_t> flag;
-    std::vector<uint8_t> mapq, qual, qname;
-    std::vector<uint32_t> cigar_off, cigar, qname_off;
-    std::vector<uint64_t> qual_off, seq_off;
-    Seq4 seq;
+    RawBuf<int32_t> pos;
+    RawBuf<uint16_t> flag;
+    RawBuf<uint8_t> mapq, qual, qname, seq4;
+    RawBuf<uint32_t> cigar_off, cigar, qname_off;
+    RawBuf<uint64_t> qual_off, seq_off;
 };
 
 namespace {
@@ -259,80 +355,130 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
 {
     if (!b || !out || tid < 0 || (size_t)tid >= b->refs.size()) return CL_ERR_INVALID;
     b->err.clear();
-    b->pos.clear(); b->flag.clear(); b->mapq.clear(); b->qual.clear(); b->qname.clear(); b->cigar.clear();
-    b->cigar_off.assign(1, 0u); b->qname_off.assign(1, 0u); b->qual_off.assign(1, 0ull); b->seq_off.assign(1, 0ull);
-    b->seq.clear();
+    b->pos.clear(); b->flag.clear(); b->mapq.clear(); b->qual.clear(); b->qname.clear(); b->cigar.clear(); b->seq4.clear();
+    b->cigar_off.clear(); b->qname_off.clear(); b->qual_off.clear(); b->seq_off.clear();
     const bool want_seq = seq_off && seq4;
-
+    BlockStream &st = b->st;
+    st.fp = b->z.fp;
+    bool nothing = false;
     // position the stream at the first record that can belong to tid
-    bool positioned = false;
     if (b->has_index) {
-        if (b->ref_start[tid] == UINT64_MAX) positioned = true;          // no records at all: read nothing
-        else { b->pending = false; if (!b->z.seek(b->ref_start[tid])) { b->err = "BAI offset beyond the file"; return CL_ERR_INVALID; } positioned = true; }
-        if (b->ref_start[tid] == UINT64_MAX) goto done;
-    }
-    if (!positioned) {
-        // forward-only: rewind when an earlier contig is requested again
-        if (tid <= b->last_tid_done) { b->pending = false; if (!b->z.seek(b->data_start)) { b->err = "rewind failed"; return CL_ERR_INVALID; } }
-    }
-    for (;;) {
-        if (!b->pending) {
-            if (!read_record(b)) { if (!b->err.empty()) return CL_ERR_INVALID; break; }
+        if (b->ref_start[tid] == UINT64_MAX) nothing = true;            // no records at all: read nothing
+        else st.reset(b->ref_start[tid]);
+    } else if (!st.valid || tid <= b->last_tid_done) st.reset(b->data_start);   // forward-only: rewind for an earlier contig
+
+    uint64_t n = 0, n_cig = 0, n_qual = 0, n_name = 0, n_bases = 0;
+    struct RecInfo { size_t off; uint32_t n_cigar, l_seq, l_name; size_t cig_off; uint64_t d_cig, d_qual, d_name, d_base; };
+    std::vector<RecInfo> recs;
+    bool end = nothing;
+    bool need_fill = st.cur >= st.buf.n;                                  // else: records left over from the previous contig's window
+    while (!end) {
+        if (need_fill && !st.fill()) {
+            if (!st.err.empty()) { b->err = st.err; return CL_ERR_INVALID; }
+            if (st.cur < st.buf.n) { b->err = "truncated BAM record"; return CL_ERR_INVALID; }
+            break;                                                        // clean EOF
         }
-        b->pending = false;
-        const uint8_t *r = b->rec.data();
-        const int32_t ref_id = (int32_t)rd32(r);
-        if (ref_id < 0 || ref_id > tid) { b->pending = true; break; }     // sorted: past this contig
-        if (ref_id < tid) continue;
-        const uint32_t bs = (uint32_t)b->rec.size();
-        const int32_t p = (int32_t)rd32(r + 4);
-        const uint32_t l_read_name = r[8], mq = r[9];
-        uint32_t n_cigar = rd16(r + 12);
-        const uint16_t fl = rd16(r + 14);
-        const uint32_t l_seq = rd32(r + 16);
-        size_t o = 32;
-        if (o + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq > bs || l_read_name == 0) { b->err = "malformed BAM record"; return CL_ERR_INVALID; }
-        const uint8_t *name = r + o; o += l_read_name;
-        const uint8_t *cig = r + o; o += 4ull * n_cigar;
-        const uint8_t *sq = r + o; o += (l_seq + 1) / 2;
-        const uint8_t *ql = r + o; o += l_seq;
-        // long CIGARs live in the CG:B,I tag behind a <l_seq>S<reflen>N placeholder
-        const uint8_t *cig_real = cig;
-        if (n_cigar == 2 && (rd32(cig) & 15u) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15u) == 3) {
-            size_t a = o;
-            while (a + 3 <= bs) {
-                const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
-                a += 3;
-                size_t len = 0;
-                auto elt = [](uint8_t c) -> size_t { switch (c) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
-                if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) ++len; len += 1; }
-                else if (ty == 'B') {
-                    if (a + 5 > bs) break;
-                    const uint8_t sub = r[a]; const uint32_t cnt = rd32(r + a + 1);
-                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= bs) { cig_real = r + a + 5; n_cigar = cnt; break; }
-                    len = 5 + elt(sub) * (size_t)cnt;
-                } else { len = elt(ty); if (!len) break; }
-                a += len;
+        need_fill = true;
+        // -- pass 1: record boundaries of this window, destination offsets --
+        recs.clear();
+        const uint8_t *buf = st.buf.p;
+        const size_t size = st.buf.n;
+        size_t o = st.cur;
+        const uint64_t n0 = n;
+        while (o + 4 <= size) {
+            const uint32_t bs = rd32(buf + o);
+            if (bs < 32 || bs > (1u << 29)) { b->err = "bad BAM block_size"; return CL_ERR_INVALID; }
+            if (o + 4 + (size_t)bs > size) break;                         // needs the next batch
+            const uint8_t *r = buf + o + 4;
+            const int32_t ref_id = (int32_t)rd32(r);
+            if (ref_id < 0 || ref_id > tid) { end = true; break; }        // sorted: past this contig (the record stays in the stream)
+            if (ref_id == tid) {
+                const uint32_t l_read_name = r[8];
+                uint32_t n_cigar = rd16(r + 12);
+                const uint32_t l_seq = rd32(r + 16);
+                size_t q = 32;
+                if (q + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + (uint64_t)l_seq > bs || l_read_name == 0) { b->err = "malformed BAM record"; return CL_ERR_INVALID; }
+                size_t cig_off = q + l_read_name;
+                const uint8_t *cig = r + cig_off;
+                q = cig_off + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq;
+                // long CIGARs live in the CG:B,I tag behind a <l_seq>S<reflen>N placeholder
+                if (n_cigar == 2 && (rd32(cig) & 15u) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15u) == 3) {
+                    size_t a = q;
+                    while (a + 3 <= bs) {
+                        const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+                        a += 3;
+                        size_t len = 0;
+                        auto elt = [](uint8_t c) -> size_t { switch (c) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
+                        if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) ++len; len += 1; }
+                        else if (ty == 'B') {
+                            if (a + 5 > bs) break;
+                            const uint8_t sub = r[a]; const uint32_t cnt = rd32(r + a + 1);
+                            if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= bs) { cig_off = a + 5; n_cigar = cnt; break; }
+                            len = 5 + elt(sub) * (size_t)cnt;
+                        } else { len = elt(ty); if (!len) break; }
+                        a += len;
+                    }
+                }
+                recs.push_back({o + 4, n_cigar, l_seq, l_read_name - 1, cig_off, n_cig, n_qual, n_name, n_bases});
+                n += 1; n_cig += n_cigar; n_qual += l_seq; n_name += l_read_name - 1; n_bases += l_seq;
+                if (n_cig > 0xFFFFFFF0ull || n_name > 0xFFFFFFF0ull) { b->err = "contig too large for 32-bit offsets"; return CL_ERR_RANGE; }
             }
+            o += 4 + (size_t)bs;
         }
-        b->pos.push_back(p); b->flag.push_back(fl); b->mapq.push_back((uint8_t)mq);
-        for (uint32_t k = 0; k < n_cigar; ++k) b->cigar.push_back(rd32(cig_real + 4ull * k));
-        b->cigar_off.push_back((uint32_t)b->cigar.size());
-        b->qual.insert(b->qual.end(), ql, ql + l_seq);
-        b->qual_off.push_back(b->qual.size());
-        b->qname.insert(b->qname.end(), name, name + (l_read_name - 1));       // without the NUL
-        b->qname_off.push_back((uint32_t)b->qname.size());
-        if (want_seq) { b->seq.append(sq, l_seq); b->seq_off.push_back(b->seq.n_bases); }
-        if (b->cigar.size() > 0xFFFFFFF0ull || b->qname.size() > 0xFFFFFFF0ull) { b->err = "contig too large for 32-bit offsets"; return CL_ERR_RANGE; }
+        // -- pass 2: fill the arrays, records in parallel --
+        const size_t seq_bytes_old = b->seq4.n, seq_bytes_new = want_seq ? (size_t)((n_bases + 1) / 2) : 0;
+        if (!b->pos.reserve(n) || !b->flag.reserve(n) || !b->mapq.reserve(n) || !b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) ||
+            !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) || !b->cigar.reserve(n_cig) || !b->qual.reserve(n_qual) ||
+            !b->qname.reserve(n_name) || !b->seq4.reserve(seq_bytes_new + 1)) { b->err = "out of memory"; return CL_ERR_INVALID; }
+        if (want_seq && seq_bytes_new > seq_bytes_old) memset(b->seq4.p + seq_bytes_old, 0, seq_bytes_new - seq_bytes_old);
+        b->seq4.n = seq_bytes_new;
+        int32_t *d_pos = b->pos.p; uint16_t *d_flag = b->flag.p; uint8_t *d_mapq = b->mapq.p;
+        uint32_t *d_coff = b->cigar_off.p, *d_cig = b->cigar.p, *d_noff = b->qname_off.p;
+        uint64_t *d_qoff = b->qual_off.p, *d_soff = b->seq_off.p;
+        uint8_t *d_qual = b->qual.p, *d_name = b->qname.p, *d_seq = b->seq4.p;
+        const RecInfo *ri = recs.data();
+        parallel_for(recs.size(), 8192, [&](size_t k) {
+            const RecInfo &x = ri[k];
+            const uint8_t *r = buf + x.off;
+            const uint64_t idx = n0 + k;
+            d_pos[idx] = (int32_t)rd32(r + 4);
+            d_flag[idx] = rd16(r + 14);
+            d_mapq[idx] = r[9];
+            d_coff[idx] = (uint32_t)x.d_cig; d_qoff[idx] = x.d_qual; d_noff[idx] = (uint32_t)x.d_name; d_soff[idx] = x.d_base;
+            memcpy(d_cig + x.d_cig, r + x.cig_off, 4ull * x.n_cigar);
+            memcpy(d_name + x.d_name, r + 32, x.l_name);
+            const uint8_t *pk = r + 32 + x.l_name + 1 + 4ull * rd16(r + 12);
+            memcpy(d_qual + x.d_qual, pk + (x.l_seq + 1) / 2, x.l_seq);
+            if (want_seq && x.l_seq) {
+                // nibble-continuous store: bytes shared with the neighbouring records are OR-ed atomically
+                auto code = [&](uint32_t i) -> uint8_t { return (i & 1u) ? (uint8_t)(pk[i >> 1] & 15u) : (uint8_t)(pk[i >> 1] >> 4); };
+                const uint64_t B = x.d_base;
+                const uint32_t l = x.l_seq;
+                uint32_t i = 0;
+                if (B & 1u) { __atomic_fetch_or(&d_seq[B >> 1], code(0), __ATOMIC_RELAXED); i = 1; }
+                const uint64_t byte0 = (B + i) >> 1;
+                const uint32_t full = (l - i) >> 1;
+                if (i == 0) memcpy(d_seq + byte0, pk, full);
+                else for (uint32_t k2 = 0; k2 < full; ++k2) d_seq[byte0 + k2] = (uint8_t)((pk[k2] << 4) | (pk[k2 + 1] >> 4));
+                i += 2 * full;
+                if (i < l) __atomic_fetch_or(&d_seq[(B + i) >> 1], (uint8_t)(code(i) << 4), __ATOMIC_RELAXED);
+            }
+        });
+        b->pos.n = b->flag.n = b->mapq.n = n;
+        b->cigar.n = n_cig; b->qual.n = n_qual; b->qname.n = n_name;
+        st.cur = o;
     }
-done:
+    if (!b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) || !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) ||
+        !b->pos.reserve(1) || !b->flag.reserve(1) || !b->mapq.reserve(1) || !b->cigar.reserve(1) || !b->qual.reserve(1) || !b->qname.reserve(1) ||
+        !b->seq4.reserve(1)) { b->err = "out of memory"; return CL_ERR_INVALID; }
+    b->cigar_off.p[n] = (uint32_t)n_cig; b->qual_off.p[n] = n_qual; b->qname_off.p[n] = (uint32_t)n_name; b->seq_off.p[n] = n_bases;
     b->last_tid_done = tid;
-    out->n = b->pos.size();
-    out->pos = b->pos.data(); out->flag = b->flag.data(); out->mapq = b->mapq.data();
-    out->cigar_off = b->cigar_off.data(); out->cigar = b->cigar.data();
-    out->qual_off = b->qual_off.data(); out->qual = b->qual.data();
-    out->qname_off = b->qname_off.data(); out->qname = b->qname.data();
-    if (want_seq) { *seq_off = b->seq_off.data(); *seq4 = b->seq.bytes.data(); }
+    out->n = n;
+    out->pos = b->pos.p; out->flag = b->flag.p; out->mapq = b->mapq.p;
+    out->cigar_off = b->cigar_off.p; out->cigar = b->cigar.p;
+    out->qual_off = b->qual_off.p; out->qual = b->qual.p;
+    out->qname_off = b->qname_off.p; out->qname = b->qname.p;
+    if (want_seq) { *seq_off = b->seq_off.p; *seq4 = b->seq4.p; }
     return CL_OK;
 }
 
@@ -342,6 +488,7 @@ int dut_bam_sample(dut_bam *b, dut_bam_sample_fn fn, void *ud)
     b->err.clear();
     b->pending = false;
     b->last_tid_done = -1;
+    b->st.valid = false;
     if (!b->z.seek(b->data_start)) { b->err = "rewind failed"; return CL_ERR_INVALID; }
     int rc = CL_OK;
     for (uint64_t i = 0;; ++i) {
@@ -423,12 +570,23 @@ int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint6
 // ---------------------------------------------------------------------------------------------
 // the file-level coverage driver
 // ---------------------------------------------------------------------------------------------
+static double io_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static void io_stage_time(const char *what, double &t0)
+{
+    static const bool on = getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1';
+    if (!on) return;
+    const double t1 = io_now();
+    fprintf(stderr, "[dut-timing] %-28s %8.1f ms\n", what, (t1 - t0) * 1e3);
+    t0 = t1;
+}
+
 extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
                                   const char *summary_json, const char *summary_html, const cl_options *opt,
                                   const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len)
 {
     if (!bam_path || !fasta_path || !bed_path || !opt) { set_err(err, err_len, "null argument"); return CL_ERR_INVALID; }
     char e[512] = {0};
+    double tm = io_now();
     dut_bam_stats *bstats = dut_bam_stats_new(10000);                  // api/coverage.rs:56-59
     if (dut_bam_stats_collect(bstats, bam_path, e, sizeof(e)) != CL_OK) {
         set_err(err, err_len, std::string("Failed to collect BAM stats: ") + e);
@@ -464,10 +622,13 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
     if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; goto out; }
     for (int t : tids) {                                          // ascending tid, api/coverage.rs:229-234
         dut_records rec;
+        io_stage_time("(before contig)", tm);
         rc = dut_bam_read_contig(bam, t, &rec, nullptr, nullptr);
         if (rc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_bam_error(bam)); goto out; }
+        io_stage_time("BAM read + decode", tm);
         const uint8_t *bases = nullptr; uint64_t blen = 0;
         dut_fasta_fetch(fa, dut_bam_ref_name(bam, t), &bases, &blen);
+        io_stage_time("FASTA fetch", tm);
         dut_contig_stats st;
         memset(&st, 0, sizeof(st));
         rc = dut_process_single_contig(ctx, prof, &st, opt, dut_bam_ref_name(bam, t), t, dut_bam_ref_len(bam, t), bases, blen, &rec);

@@ -40,6 +40,22 @@ template <typename T> struct DevBuf {
         cap = want;
         return hipSuccess;
     }
+    // like reserve, but the first `used` elements survive a reallocation
+    hipError_t grow_keep(size_t n, size_t used, hipStream_t stream)
+    {
+        if (n <= cap) return hipSuccess;
+        if (!p || used == 0) return reserve(n);
+        T *q = nullptr;
+        size_t want = n + n / 4 + 64;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&q), want * sizeof(T));
+        if (e != hipSuccess) return e;
+        e = hipMemcpyAsync(q, p, used * sizeof(T), hipMemcpyDeviceToDevice, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        if (e != hipSuccess) { (void)hipFree(q); return e; }
+        (void)hipFree(p);
+        p = q; cap = want;
+        return hipSuccess;
+    }
     void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
 };
 
@@ -65,7 +81,8 @@ struct cl_ctx {
     std::vector<uint32_t> h_cigar_off;
     std::vector<uint32_t> h_cigar;
     std::vector<unsigned long long> h_qual_off;
-    std::vector<uint8_t> h_qual;
+    std::vector<uint8_t> h_qual;     // quality bytes of small tiles, not yet on the device
+    uint64_t q_dev = 0;              // quality bytes of this contig that already are (d_qual + kQualPad ..)
 
     // device residents
     DevBuf<int32_t> d_pos;
@@ -354,7 +371,39 @@ cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uin
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_qual.clear();
     c->h_cigar_off.assign(1, 0u); c->h_qual_off.assign(1, 0ull);
     c->h_iv.clear();
+    c->q_dev = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
+    return CL_OK;
+}
+
+namespace {
+// quality bytes staged on the host so far go to the device, behind the ones already there
+cl_status flush_staged_qual(cl_ctx *c)
+{
+    if (c->h_qual.empty()) return CL_OK;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->d_qual.grow_keep(c->q_dev + c->h_qual.size() + 2 * kQualPad, kQualPad + c->q_dev, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_qual.p + kQualPad + c->q_dev, c->h_qual.data(), c->h_qual.size(), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->q_dev += c->h_qual.size();
+    c->h_qual.clear();
+    return CL_OK;
+}
+constexpr uint64_t kDirectQual = 4u << 20;   // tiles with at least this many quality bytes skip the host staging copy
+} // namespace
+
+cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes)
+{
+    if (!c || !c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_reserve outside cl_contig_begin .. upload");
+    try {
+        c->h_pos.reserve(n_reads); c->h_mapq.reserve(n_reads);
+        c->h_cigar_off.reserve(n_reads + 1); c->h_qual_off.reserve(n_reads + 1);
+        c->h_cigar.reserve(n_cigar_ops);
+    } catch (const std::bad_alloc &) {
+        return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, c->d_qual.grow_keep(n_qual_bytes + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
     return CL_OK;
 }
 
@@ -385,14 +434,24 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     if (ncig && !t->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
     if (nq && !t->qual) return fail(c, CL_ERR_INVALID, "null qual array");
     if (c->h_cigar.size() + ncig > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 CIGAR operations in one contig");
-    if (c->h_qual.size() + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality bytes in one contig");
+    if (c->q_dev + c->h_qual.size() + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality bytes in one contig");
     const uint32_t cbase = (uint32_t)c->h_cigar.size();
-    const unsigned long long qbase = c->h_qual.size();
+    const unsigned long long qbase = c->q_dev + c->h_qual.size();
+    if (nq >= kDirectQual) {
+        // a large tile: its quality bytes go from the caller's buffer straight to the device
+        cl_status fs = flush_staged_qual(c);
+        if (fs != CL_OK) return fs;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, c->d_qual.grow_keep(c->q_dev + nq + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_qual.p + kQualPad + c->q_dev, t->qual + q0, nq, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the caller's buffer is free again on return
+        c->q_dev += nq;
+    }
     try {
         c->h_pos.insert(c->h_pos.end(), t->pos, t->pos + n);
         c->h_mapq.insert(c->h_mapq.end(), t->mapq, t->mapq + n);
         c->h_cigar.insert(c->h_cigar.end(), t->cigar + cig0, t->cigar + cig0 + ncig);
-        c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
+        if (nq < kDirectQual) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
         c->h_cigar_off.reserve(c->h_cigar_off.size() + n);
         c->h_qual_off.reserve(c->h_qual_off.size() + n);
         for (uint64_t i = 1; i <= n; ++i) {
@@ -411,7 +470,11 @@ cl_status cl_contig_upload(cl_ctx *c)
     HIP_TRY(c, hipSetDevice(c->device));
     c->n_reads = (uint32_t)c->h_pos.size();
     c->n_cigar = c->h_cigar.size();
-    c->n_qual = c->h_qual.size();
+    {
+        cl_status fs = flush_staged_qual(c);
+        if (fs != CL_OK) return fs;
+    }
+    c->n_qual = c->q_dev;
     const size_t n = c->n_reads;
     HIP_TRY(c, c->d_pos.reserve(n + 1));
     HIP_TRY(c, c->d_mapq.reserve(n + 1));
@@ -422,7 +485,7 @@ cl_status cl_contig_upload(cl_ctx *c)
     HIP_TRY(c, c->d_long_list.reserve(n + 1));
     HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
-    HIP_TRY(c, c->d_qual.reserve(c->n_qual + 2 * kQualPad));
+    HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     if (n) {
         HIP_TRY(c, hipMemcpyAsync(c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_mapq.p, c->h_mapq.data(), n, hipMemcpyHostToDevice, c->stream));
@@ -432,7 +495,6 @@ cl_status cl_contig_upload(cl_ctx *c)
     if (c->n_cigar) HIP_TRY(c, hipMemcpyAsync(c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
-    if (c->n_qual) HIP_TRY(c, hipMemcpyAsync(c->d_qual.p + kQualPad, c->h_qual.data(), c->n_qual, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_len_dev = UINT64_MAX;            // force the reference to be re-laid out
     cl_status s = size_for_extent(c, c->contig_len);

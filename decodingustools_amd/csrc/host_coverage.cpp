@@ -3,8 +3,10 @@
 // The per-position work is done by the device engine (callable_loci.hip); nothing here computes
 // depths or states.
 #include "../../include/dut_coverage.h"
+#include "host_parallel.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -62,12 +64,19 @@ struct NameSet {
             }
         hash.swap(nh); idx.swap(ni);
     }
-    bool insert(uint64_t r)
+    uint64_t hash_of(uint64_t r) const { return mix(rec->qname + rec->qname_off[r], rec->qname_off[r + 1] - rec->qname_off[r]); }
+    void presize(uint64_t expected)
+    {
+        size_t cap = 4096;
+        while (cap < expected * 2 + 2) cap *= 2;
+        hash.assign(cap, 0); idx.assign(cap, 0); count = 0;
+    }
+    bool insert(uint64_t r) { return insert_hashed(r, hash_of(r)); }
+    bool insert_hashed(uint64_t r, uint64_t h)
     {
         if ((count + 1) * 2 > hash.size()) grow();
         const uint8_t *nm = rec->qname + rec->qname_off[r];
         const uint32_t nl = rec->qname_off[r + 1] - rec->qname_off[r];
-        const uint64_t h = mix(nm, nl);
         size_t j = h & (hash.size() - 1);
         while (hash[j]) {
             if (hash[j] == h) {
@@ -182,7 +191,6 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
     // while the columns before s were produced; a read ending AT s is freed only when column s
     // itself is walked).
     std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> live;
-    NameSet names; names.rec = rec;
     bool any_pushed = false;
     int64_t cur_start = -1;
     uint64_t nacc = 0;
@@ -210,14 +218,43 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
         }
         if (!appended) continue;
         live.push(end);
-        if (rl > 0) {
-            accepted[i] = 1; ++nacc;
-            if (rec->qname_off) names.insert(i);
-        }
+        if (rl > 0) { accepted[i] = 1; ++nacc; }
     }
-    if (n_unique_names) *n_unique_names = (uint32_t)names.count;
     if (n_accepted) *n_accepted = nacc;
+    if (n_unique_names) {
+        // distinct names among the accepted reads, exactly: the reads are split into 64 classes by the
+        // top bits of a 64-bit hash of the name, every class gets its own exact set (full comparison
+        // on a hash match), classes are counted in parallel and the counts add up
+        uint64_t total = 0;
+        if (rec->qname_off && nacc) {
+            std::vector<uint64_t> h(rec->n);
+            NameSet hasher; hasher.rec = rec;
+            dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = accepted[i] ? hasher.hash_of(i) : 0; });
+            constexpr int kClasses = 64;
+            std::vector<uint64_t> per(kClasses, 0), cnt(kClasses, 0);
+            for (uint64_t i = 0; i < rec->n; ++i) if (accepted[i]) cnt[h[i] >> 58] += 1;
+            dut::parallel_for(kClasses, 1, [&](size_t c) {
+                if (!cnt[c]) return;
+                NameSet set; set.rec = rec; set.presize(cnt[c]);
+                for (uint64_t i = 0; i < rec->n; ++i) if (accepted[i] && (h[i] >> 58) == c) set.insert_hashed(i, h[i]);
+                per[c] = set.count;
+            });
+            for (uint64_t v : per) total += v;
+        }
+        *n_unique_names = (uint32_t)total;
+    }
     return CL_OK;
+}
+
+// DUT_TIMING=1: wall-clock of the host stages on stderr (tooling; off by default)
+static double dut_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool dut_timing_on() { static const bool on = getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1'; return on; }
+static void dut_stage_time(const char *what, double &t0)
+{
+    if (!dut_timing_on()) return;
+    const double t1 = dut_now();
+    fprintf(stderr, "[dut-timing] %-28s %8.1f ms\n", what, (t1 - t0) * 1e3);
+    t0 = t1;
 }
 
 int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats *stats, const cl_options *opt,
@@ -225,39 +262,74 @@ int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats 
                               uint64_t ref_len, const dut_records *rec)
 {
     if (!ctx || !prof || !stats || !opt || !contig_name || !rec) return CL_ERR_INVALID;
+    double tm = dut_now();
     std::vector<uint8_t> acc(rec->n ? rec->n : 1);
     uint32_t n_names = 0; uint64_t n_acc = 0;
     int rc = dut_admit_reads(opt, tid, contig_len, rec, acc.data(), &n_names, &n_acc);
     if (rc != CL_OK) return rc;
+    dut_stage_time("admit + name set", tm);
     rc = cl_contig_begin(ctx, tid, contig_len, ref, ref_len);
     if (rc != CL_OK) return rc;
-    // compact the accepted reads into SoA tiles
-    const uint64_t kTile = 1u << 20;
-    std::vector<int32_t> pos; std::vector<uint8_t> mapq; std::vector<uint32_t> coff, cig;
-    std::vector<uint64_t> qoff; std::vector<uint8_t> qual;
-    uint64_t i = 0;
-    while (i < rec->n) {
-        pos.clear(); mapq.clear(); cig.clear(); qual.clear();
-        coff.assign(1, 0u); qoff.assign(1, 0ull);
-        for (; i < rec->n && pos.size() < kTile; ++i) {
-            if (!acc[i]) continue;
-            pos.push_back(rec->pos[i]); mapq.push_back(rec->mapq[i]);
-            cig.insert(cig.end(), rec->cigar + rec->cigar_off[i], rec->cigar + rec->cigar_off[i + 1]);
-            qual.insert(qual.end(), rec->qual + rec->qual_off[i], rec->qual + rec->qual_off[i + 1]);
-            coff.push_back((uint32_t)cig.size()); qoff.push_back(qual.size());
+    // One tile, no copy of the quality bytes: the records of the contig are pushed as they lie in
+    // `rec`.  Reads the pileup would not hold (FUNMAP, the depth cap, reads without a reference span)
+    // stay in the tile with their CIGAR operations rewritten to hard clips, which consume neither
+    // reference nor query: they then touch no position and add to no sum.  Reads at or past
+    // contig_len (never yielded by the region fetch) are the sorted tail and are cut off, so are
+    // unaccepted reads in front of position 0.
+    uint64_t a0 = 0, n_keep = rec->n;
+    while (n_keep > 0 && (int64_t)rec->pos[n_keep - 1] >= (int64_t)contig_len) --n_keep;
+    while (a0 < n_keep && rec->pos[a0] < 0 && !acc[a0]) ++a0;
+    bool in_order = true;
+    for (uint64_t i = a0 + 1; i < n_keep && in_order; ++i) in_order = rec->pos[i] >= rec->pos[i - 1];
+    if (in_order && a0 < n_keep) {
+        std::vector<uint32_t> patched;
+        const uint32_t *cig = rec->cigar;
+        uint64_t n_in = 0;
+        for (uint64_t i = a0; i < n_keep; ++i) n_in += acc[i];
+        if (n_in != n_keep - a0) {
+            patched.assign(rec->cigar, rec->cigar + rec->cigar_off[n_keep]);
+            for (uint64_t i = a0; i < n_keep; ++i)
+                if (!acc[i])
+                    for (uint32_t k = rec->cigar_off[i]; k < rec->cigar_off[i + 1]; ++k) patched[k] = (patched[k] & ~15u) | 5u;
+            cig = patched.data();
         }
-        if (pos.empty()) continue;
         cl_read_tile t;
-        t.n_reads = pos.size(); t.pos = pos.data(); t.mapq = mapq.data(); t.cigar_off = coff.data();
-        t.cigar = cig.data(); t.qual_off = qoff.data(); t.qual = qual.data();
+        t.n_reads = n_keep - a0; t.pos = rec->pos + a0; t.mapq = rec->mapq + a0; t.cigar_off = rec->cigar_off + a0;
+        t.cigar = cig; t.qual_off = rec->qual_off + a0; t.qual = rec->qual;
         rc = cl_push_reads(ctx, &t);
         if (rc != CL_OK) return rc;
+    } else if (a0 < n_keep) {
+        // records whose skipped reads are out of order: copy the accepted ones out, tile by tile
+        const uint64_t kTile = 1u << 20;
+        std::vector<int32_t> pos; std::vector<uint8_t> mapq; std::vector<uint32_t> coff, cig;
+        std::vector<uint64_t> qoff; std::vector<uint8_t> qual;
+        uint64_t i = 0;
+        while (i < rec->n) {
+            pos.clear(); mapq.clear(); cig.clear(); qual.clear();
+            coff.assign(1, 0u); qoff.assign(1, 0ull);
+            for (; i < rec->n && pos.size() < kTile; ++i) {
+                if (!acc[i]) continue;
+                pos.push_back(rec->pos[i]); mapq.push_back(rec->mapq[i]);
+                cig.insert(cig.end(), rec->cigar + rec->cigar_off[i], rec->cigar + rec->cigar_off[i + 1]);
+                qual.insert(qual.end(), rec->qual + rec->qual_off[i], rec->qual + rec->qual_off[i + 1]);
+                coff.push_back((uint32_t)cig.size()); qoff.push_back(qual.size());
+            }
+            if (pos.empty()) continue;
+            cl_read_tile t;
+            t.n_reads = pos.size(); t.pos = pos.data(); t.mapq = mapq.data(); t.cigar_off = coff.data();
+            t.cigar = cig.data(); t.qual_off = qoff.data(); t.qual = qual.data();
+            rc = cl_push_reads(ctx, &t);
+            if (rc != CL_OK) return rc;
+        }
     }
+    dut_stage_time("compact + push", tm);
     cl_contig_summary sum; const cl_interval *iv = nullptr; size_t niv = 0;
     rc = cl_contig_finish(ctx, &sum, &iv, &niv);
     if (rc != CL_OK) return rc;
+    dut_stage_time("upload + kernels + collect", tm);
     rc = dut_profiler_feed_contig(prof, contig_name, iv, niv, sum.state_counts);
     if (rc != CL_OK) return rc;
+    dut_stage_time("BED lines", tm);
     stats->length = contig_len;
     stats->n_covered_bases = sum.n_covered_bases;
     stats->summed_coverage = sum.summed_coverage;

@@ -61,6 +61,20 @@ class ContigRecords:
             assert a.flags["C_CONTIGUOUS"]
         return self
 
+    def slice(self, a, b):
+        """Records [a, b) as their own ContigRecords (offsets rebased; the 4-bit sequence store is
+        shared, its offsets stay absolute)."""
+        c0, c1 = int(self.cigar_off[a]), int(self.cigar_off[b])
+        q0, q1 = int(self.qual_off[a]), int(self.qual_off[b])
+        n0, n1 = int(self.qname_off[a]), int(self.qname_off[b])
+        return ContigRecords(
+            pos=np.ascontiguousarray(self.pos[a:b]), flag=np.ascontiguousarray(self.flag[a:b]),
+            mapq=np.ascontiguousarray(self.mapq[a:b]),
+            cigar_off=(self.cigar_off[a:b + 1] - np.uint32(c0)).astype(np.uint32), cigar=np.ascontiguousarray(self.cigar[c0:c1]),
+            qual_off=(self.qual_off[a:b + 1] - np.uint64(q0)).astype(np.uint64), qual=np.ascontiguousarray(self.qual[q0:q1]),
+            qname_off=(self.qname_off[a:b + 1] - np.uint32(n0)).astype(np.uint32), qname=np.ascontiguousarray(self.qname[n0:n1]),
+            seq_off=None if self.seq_off is None else np.ascontiguousarray(self.seq_off[a:b + 1]), seq4=self.seq4)
+
     @staticmethod
     def empty():
         return ContigRecords.from_reads([])

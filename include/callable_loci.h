@@ -122,6 +122,11 @@ const char *cl_last_error(const cl_ctx *ctx);
  * missing base reads as 'N'); ref_len < contig_len is allowed, the rest is 'N'. */
 cl_status cl_contig_begin(cl_ctx *ctx, int32_t tid, uint32_t contig_len,
                           const uint8_t *ref_bases, uint64_t ref_len);
+/* Optional size hint for the contig that was just begun: totals over all tiles that will be pushed.
+ * Saves regrowing the staging / device buffers; never required. */
+cl_status cl_contig_reserve(cl_ctx *ctx, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes);
+/* Appends a tile (coordinate order across tiles).  The caller's buffers are free again on return:
+ * small tiles are copied to host staging, the quality bytes of tiles of >= 4 MiB go straight to HBM. */
 cl_status cl_push_reads(cl_ctx *ctx, const cl_read_tile *tile);
 /* upload + run + collect in one call.  *intervals points at context-owned memory, valid until
  * the next cl_contig_begin / cl_destroy. */

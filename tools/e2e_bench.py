@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Tooling: end-to-end `coverage` on files (BGZF inflate + record parse + admission + H2D + kernels +
+D2H + BED text), with the host stages timed (DUT_TIMING=1).  Writes a chr21-shaped BAM first.
+Not bench.py: the judged metric is the device-resident rate; this is the labelled PCIe/host-inclusive one."""
+import os, sys, time, json, subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import numpy as np
+from decodingustools_amd import synth, build as _b
+import ctypes as C
+
+def write_bam_native(path, name, L, rec, level=1, threads=16):
+    so = os.path.join(out, "bamwriter.so")
+    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tools", "bamwriter.cpp"), "-lz", "-lpthread", "-o", so])
+    lib = C.CDLL(so)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.tool_write_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 9 + [C.c_int, C.c_int]
+    rc = lib.tool_write_bam(path.encode(), b"@HD\tVN:1.6\tSO:coordinate\n@PG\tID:bwa\tPN:bwa\n", name.encode(), L, rec.n, p(rec.pos), p(rec.flag), p(rec.mapq),
+                            p(rec.cigar_off), p(rec.cigar), p(rec.qual_off), p(rec.qual), p(rec.qname_off), p(rec.qname), level, threads)
+    assert rc == 0
+
+out = os.environ.get("E2E_DIR", "/tmp/e2e")
+os.makedirs(out, exist_ok=True)
+L = int(os.environ.get("E2E_LEN", 46_709_983))
+depth = float(os.environ.get("E2E_DEPTH", 30))
+bam, fa = os.path.join(out, "s.bam"), os.path.join(out, "s.fa")
+t0 = time.time()
+seed = synth.seed_for(2, 20)
+rec = synth.short_read_contig(L, depth, seed)
+ref = synth.make_reference(L, seed)
+print(f"generated {rec.n} reads in {time.time() - t0:.1f} s", flush=True)
+t0 = time.time()
+write_bam_native(bam, "chr21", L, rec, threads=int(os.environ.get("E2E_WTHREADS", 16)))
+width = 60
+with open(fa, "wb") as f:
+    f.write(b">chr21\n")
+    full = (L // width) * width
+    body = np.empty((L // width, width + 1), np.uint8); body[:, :width] = ref[:full].reshape(-1, width); body[:, width] = 10
+    f.write(body.tobytes()); f.write(ref[full:].tobytes() + b"\n")
+open(fa + ".fai", "w").write(f"chr21\t{L}\t7\t{width}\t{width + 1}\n")
+print(f"wrote {os.path.getsize(bam) / 1e6:.0f} MB BAM in {time.time() - t0:.1f} s", flush=True)
+del rec
+for threads in os.environ.get("E2E_THREADS", "16,1").split(","):
+    env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads)
+    for rep in range(2):
+        t0 = time.time()
+        r = subprocess.run([_b.CLI, "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")], cwd=out, env=env, capture_output=True, text=True)
+        dt = time.time() - t0
+        print(f"--- DUT_THREADS={threads} run {rep}: {dt:.2f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)
+        print(r.stderr.strip(), flush=True)
+if os.path.exists(os.path.join(out, "o.bed")):
+    print(json.dumps(dict(bed_lines=sum(1 for _ in open(os.path.join(out, "o.bed"))))))

@@ -224,13 +224,17 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     // the byte-parallel threshold test has a shorter form when min_base_quality <= 128;
     // the 32-bit counter variant is used only after k_window_bounds asked for it (kNeedDeep)
     const bool orf = c->opt.min_base_quality <= 128;
+    // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel variant
+    const bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
+#define CL_LAUNCH(ORF_, DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, ORF_, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
     if (!c->deep) {
-        if (orf) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, false>), dim3(grid), dim3(kBlock), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, false, false>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+        if (lng) { if (orf) CL_LAUNCH(true, false, true); else CL_LAUNCH(false, false, true); }
+        else { if (orf) CL_LAUNCH(true, false, false); else CL_LAUNCH(false, false, false); }
     } else {
-        if (orf) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, true>), dim3(grid), dim3(kBlock), 0, c->stream, a);
-        else hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, false, true>), dim3(grid), dim3(kBlock), 0, c->stream, a);
+        if (lng) { if (orf) CL_LAUNCH(true, true, true); else CL_LAUNCH(false, true, true); }
+        else { if (orf) CL_LAUNCH(true, true, false); else CL_LAUNCH(false, true, false); }
     }
+#undef CL_LAUNCH
 }
 
 cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, uint32_t *dbg_low)

@@ -22,7 +22,7 @@ namespace clk {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr int kPrepBlocks = 4096;    // grid of k_read_prep (grid-stride)
-constexpr int kLongBlocks = 512;     // grid of k_read_prep_long (one wave per long read)
+constexpr int kLongBlocks = 2048;    // grid of k_read_prep_long (one wave per long read)
 constexpr int kPrepParts = kPrepBlocks + kLongBlocks;
 constexpr uint32_t kLongOps = 64;    // reads with more CIGAR ops are scanned by a whole wave and get a
                                      // checkpoint (reference, query position) before every 64th op
@@ -115,6 +115,39 @@ __device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
 {
     for (int o = 32; o > 0; o >>= 1) v |= __shfl_down(v, o, 64);
     return v;
+}
+
+// Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (VALU only; __shfl_up
+// compiles to ds_bpermute_b32, an LDS-pipe instruction with far higher latency).
+//   row_shr:1,2,4,8 (0x111..0x118, zero fill) scan each row of 16 lanes,
+//   row_bcast:15 (0x142, rows 1 and 3) adds the previous row's total,
+//   row_bcast:31 (0x143, rows 2 and 3) adds the total of lanes 0..31.
+__device__ __forceinline__ uint32_t dpp_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+// the maximum over the wave, in every lane (same DPP pattern; the zero fill is the identity of an unsigned max)
+__device__ __forceinline__ uint32_t dpp_wave_max_u32(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false); v = t > v ? t : v;
+    t = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false); v = t > v ? t : v;
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// the sum over the wave, in every lane (lane 63 of the scan, read through an SGPR)
+__device__ __forceinline__ uint32_t dpp_wave_sum_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_readlane((int)dpp_incl_scan_u32(v), 63);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -225,26 +258,33 @@ __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint
         const uint32_t ps = (uint32_t)R.pos[r];
         unsigned long long xc = 0;                       // reference / query advance before the chunk
         uint32_t yc = 0;
-        for (uint32_t kb = k0 & ~63u; kb < k1; kb += 64u) {
-            const uint32_t k = kb + lane;
-            const bool valid = k >= k0 && k < k1;
-            const uint32_t c = valid ? R.cigar[k] : 0u, op = c & 15u, l = c >> 4;
-            const bool radv = valid && ((0x18Du >> op) & 1u), qadv = valid && ((0x193u >> op) & 1u);
-            if (radv && l == 0) err |= kErrCigar;        // zero-length reference-consuming op
-            unsigned long long ra = radv ? l : 0u;
-            uint32_t qa = qadv ? l : 0u;
-            for (int d = 1; d < 64; d <<= 1) {           // inclusive wave scans
-                const unsigned long long tr = __shfl_up(ra, d, 64);
-                const uint32_t tq = __shfl_up(qa, d, 64);
-                if (lane >= (uint32_t)d) { ra += tr; qa += tq; }
+        // two chunks of 64 ops per trip: both loads are issued before the first scan
+        for (uint32_t kb = k0 & ~63u; kb < k1; kb += 128u) {
+            uint32_t c2[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t k = kb + 64u * h + lane;
+                c2[h] = (k >= k0 && k < k1) ? R.cigar[k] : 5u;       // outside the read: H, advances nothing
             }
-            if (lane == 0 && kb >= k0) {
-                const unsigned long long cx = (unsigned long long)ps + xc;
-                ck_x[kb >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
-                ck_y[kb >> 6] = yc;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const uint32_t kc = kb + 64u * h;
+                if (kc >= k1) break;
+                const uint32_t c = c2[h], op = c & 15u, l = c >> 4;
+                const bool radv = ((0x18Du >> op) & 1u) != 0u, qadv = ((0x193u >> op) & 1u) != 0u;
+                if (radv && l == 0 && (kc + lane) >= k0 && (kc + lane) < k1) err |= kErrCigar;   // zero-length reference-consuming op
+                const uint32_t rl = radv ? l : 0u;
+                // sum of up to 64 28-bit lengths, exactly: low 16 and high 12 bits separately
+                const unsigned long long tot_r = ((unsigned long long)dpp_wave_sum_u32(rl >> 16) << 16) + dpp_wave_sum_u32(rl & 0xFFFFu);
+                const uint32_t tot_q = dpp_wave_sum_u32(qadv ? l : 0u);
+                if (lane == 0 && kc >= k0) {
+                    const unsigned long long cx = (unsigned long long)ps + xc;
+                    ck_x[kc >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
+                    ck_y[kc >> 6] = yc;
+                }
+                xc += tot_r;
+                yc += tot_q;
             }
-            xc += __shfl(ra, 63, 64);
-            yc += __shfl(qa, 63, 64);
         }
         if (lane == 0) {
             const unsigned long long e = (unsigned long long)ps + xc;
@@ -469,8 +509,8 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 #ifndef CL_MINWAVES
 #define CL_MINWAVES 8
 #endif
-template <int T, bool DEBUG, bool ORF, bool DEEP>
-__global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
+template <int T, bool DEBUG, bool ORF, bool DEEP, bool LONG>
+__global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
@@ -496,6 +536,9 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
     // per-wave totals: cnt[6], n_cov, sum_qc, sum_q, n_inner.  (Same-address LDS atomics are avoided:
     // hipcc turns them into a scalar loop over the active lanes.)
     __shared__ unsigned long long s_wtot[kWaves][10];
+    // LONG: the live reads of a pass, two entries each: {read, op index, x, y}, {op end, quality offset, quality length, -}
+    __shared__ __attribute__((aligned(16))) uint4 s_live[LONG ? 2 * kBlock : 1];
+    __shared__ uint32_t s_nlive;
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
     // each XCD one contiguous range of windows so neighbouring windows share its L2.
@@ -638,68 +681,159 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
                     k = lo_j << 6; x = a.ck_x[lo_j]; y = a.ck_y[lo_j];
                 }
             }
-            if (live) cw = a.R.cigar[k];             // invariant: cw == cigar[k] while live
+            if (!LONG && live) cw = a.R.cigar[k];    // invariant: cw == cigar[k] while live
         }
-        const uint32_t setbit = (r & 1u) << 30;      // which 8-bit counter set this read adds to
-        for (;;) {                                   // rounds: wave-uniform loop
-            // -- each lane: next (at most kSegRound) segments of its read.  Wave-uniform loop,
-            //    per-lane predication, one CIGAR op per iteration; invariant: cw == cigar[k] while live --
-            uint2 seg[kSegRound];
-            seg[0] = make_uint2(0u, 0u); seg[1] = make_uint2(0u, 0u);
-            uint32_t nemit = 0;
-            for (;;) {
-                const bool act = live && nemit < (uint32_t)kSegRound;
-                if (!__any(act)) break;
-                const uint32_t op = cw & 15u, l = cw >> 4;
-                const bool ism = ((0x181u >> op) & 1u) != 0u;        // M = X
-                const bool radv = ((0x18Du >> op) & 1u) != 0u;       // M D N = X consume reference
-                const bool qadv = ((0x193u >> op) & 1u) != 0u;       // M I S = X consume query
-                const uint32_t xe = x + (radv ? l : 0u);
-                const uint32_t sp = x > W ? x : W;
-                const uint32_t lq = y < qlen ? ((qlen - y) < l ? (qlen - y) : l) : 0u;   // bases that have a quality byte
-                uint32_t tp = xe < Wend ? xe : Wend;
-                tp = (x + lq) < tp ? (x + lq) : tp;
-                const bool valid = act && ism && sp < tp;
-                const uint2 d = make_uint2(qrel + y + (sp - x), (sp - W) | ((tp - sp - 1u) << 16) | setbit | 0x80000000u);
-                if (valid && nemit == 0u) seg[0] = d;
-                if (valid && nemit == 1u) seg[1] = d;
-                nemit += valid ? 1u : 0u;
-                if (act) {
-                    x = xe;
-                    y += qadv ? l : 0u;
-                    k += 1u;
-                    live = k < k1 && x < Wend;
-                    if (live) cw = a.R.cigar[k];
+        if constexpr (LONG) {
+            // ---- long-read shape: CIGAR operations in parallel.  The live reads of the pass are
+            //      compacted into s_live; a wave takes a read and 64 of its operations at a time (one
+            //      coalesced load), two wave scans give every operation its reference / query start,
+            //      and each lane consumes its own M/=/X run (runs longer than 64 bases go through
+            //      the wave's list and the quad loop above).  No lane-serial CIGAR walk. ----
+            if (tid == 0) s_nlive = 0;
+            __syncthreads();
+            {
+                const unsigned long long lm = __ballot(live);
+                uint32_t wb = 0;
+                if (lane == 0 && lm) wb = atomicAdd(&s_nlive, (uint32_t)__popcll(lm));
+                wb = __shfl(wb, 0, 64);
+                if (live) {
+                    const uint32_t idx = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
+                    s_live[2u * idx] = make_uint4(r, k, x, y);
+                    s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
                 }
             }
-            // -- wave-private list in lane (= position) order: carried-over entries, first segments,
-            //    then second ones --
-            uint32_t n_list = n_keep;
-#pragma unroll
-            for (int i = 0; i < kSegRound; ++i) {
-                const bool has = (seg[i].y >> 31) != 0u;
-                const unsigned long long m = __ballot(has);
-                if (has) {
-                    const uint32_t idx = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                    list[idx] = seg[i];
+            __syncthreads();
+            const uint32_t nl = s_nlive;
+            for (uint32_t it = wv; it < nl; it += (uint32_t)kWaves) {
+                const uint4 A = s_live[2u * it], B = s_live[2u * it + 1u];
+                uint32_t rk = A.y, rx = A.z, ry = A.w;
+                const uint32_t rk1 = B.x, rqrel = B.y, rqlen = B.z;
+                const uint32_t rset = (A.x & 1u) << 30;
+                uint32_t cw_next = (rk + lane) < rk1 ? a.R.cigar[rk + lane] : 5u;   // beyond the read: H, advances nothing
+                while (rk < rk1 && rx < Wend) {                      // wave-uniform
+                    const uint32_t cwl = cw_next;
+                    {   // the next 64 operations are requested before this block is scanned
+                        const uint32_t kn = rk + 64u + lane;
+                        cw_next = kn < rk1 ? a.R.cigar[kn] : 5u;
+                    }
+                    const uint32_t op = cwl & 15u, l = cwl >> 4;
+                    const bool ism = ((0x181u >> op) & 1u) != 0u;
+                    const uint32_t ax = ((0x18Du >> op) & 1u) ? l : 0u;
+                    const uint32_t ay = ((0x193u >> op) & 1u) ? l : 0u;
+                    const uint32_t ix = dpp_incl_scan_u32(ax), iy = dpp_incl_scan_u32(ay);
+                    const uint32_t xs = rx + (ix - ax), ys = ry + (iy - ay);
+                    const uint32_t xe = xs + ax;
+                    const uint32_t sp = xs > W ? xs : W;
+                    const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
+                    uint32_t tp = xe < Wend ? xe : Wend;
+                    tp = (xs + lq) < tp ? (xs + lq) : tp;
+                    const bool valid = ism && sp < tp && !(a.ablate & 1u);
+                    const uint32_t srel = sp - W, trel = tp - W;
+                    const bool big = valid && (trel - srel) > 64u;
+                    if (valid && !big) {
+                        const uint32_t qo = rqrel + ys + (sp - xs) + (uint32_t)kQualPad - srel;
+                        const uint32_t u1 = (trel - 1u) >> 4;
+                        for (uint32_t u = srel >> 4; u <= u1; ++u) {
+                            Q16 v;
+                            __builtin_memcpy(&v, qbase + (qo + (u << 4)), 16);
+                            const uint32_t ps = u << 4;
+                            const uint32_t vs = srel > ps ? srel - ps : 0u;
+                            const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                            const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                            const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                            if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
+                            else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                            else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                        }
+                    }
+                    const unsigned long long bm = __ballot(big);
+                    if (bm) {                                        // wave-uniform: long runs go through the list
+                        if (big) {
+                            const uint32_t idx = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                            list[idx] = make_uint2(rqrel + ys + (sp - xs), srel | ((trel - srel - 1u) << 16) | rset | 0x80000000u);
+                        }
+                        const uint32_t n_list = n_keep + (uint32_t)__popcll(bm);
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        const uint32_t n_full = n_list & ~15u;
+                        if (n_full) consume_list(n_full);
+                        n_keep = n_list - n_full;
+                        uint2 carry = make_uint2(0u, 0u);
+                        if (n_full && lane < n_keep) carry = list[n_full + lane];
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                        __builtin_amdgcn_wave_barrier();
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (n_full && lane < n_keep) list[lane] = carry;
+                    }
+                    rx += (uint32_t)__builtin_amdgcn_readlane((int)ix, 63);
+                    ry += (uint32_t)__builtin_amdgcn_readlane((int)iy, 63);
+                    rk += 64u;
                 }
-                n_list += (uint32_t)__popcll(m);
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            // -- only full groups of 16 entries are consumed now; the < 16 left over move to the front
-            //    of the list and wait for the next round (or for the flush after the last pass) --
-            const uint32_t n_full = n_list & ~15u;
-            if (n_full) consume_list(n_full);
-            n_keep = n_list - n_full;
-            uint2 carry = make_uint2(0u, 0u);
-            if (n_full && lane < n_keep) carry = list[n_full + lane];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();       // the list is rewritten below and in the next round
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (n_full && lane < n_keep) list[lane] = carry;
-            if (!__any(live)) break;
+            __syncthreads();                                         // s_live is rewritten by the next pass
+        } else {
+            const uint32_t setbit = (r & 1u) << 30;      // which 8-bit counter set this read adds to
+            for (;;) {                                   // rounds: wave-uniform loop
+                // -- each lane: next (at most kSegRound) segments of its read.  Wave-uniform loop,
+                //    per-lane predication, one CIGAR op per iteration; invariant: cw == cigar[k] while live --
+                uint2 seg[kSegRound];
+                seg[0] = make_uint2(0u, 0u); seg[1] = make_uint2(0u, 0u);
+                uint32_t nemit = 0;
+                for (;;) {
+                    const bool act = live && nemit < (uint32_t)kSegRound;
+                    if (!__any(act)) break;
+                    const uint32_t op = cw & 15u, l = cw >> 4;
+                    const bool ism = ((0x181u >> op) & 1u) != 0u;        // M = X
+                    const bool radv = ((0x18Du >> op) & 1u) != 0u;       // M D N = X consume reference
+                    const bool qadv = ((0x193u >> op) & 1u) != 0u;       // M I S = X consume query
+                    const uint32_t xe = x + (radv ? l : 0u);
+                    const uint32_t sp = x > W ? x : W;
+                    const uint32_t lq = y < qlen ? ((qlen - y) < l ? (qlen - y) : l) : 0u;   // bases that have a quality byte
+                    uint32_t tp = xe < Wend ? xe : Wend;
+                    tp = (x + lq) < tp ? (x + lq) : tp;
+                    const bool valid = act && ism && sp < tp;
+                    const uint2 d = make_uint2(qrel + y + (sp - x), (sp - W) | ((tp - sp - 1u) << 16) | setbit | 0x80000000u);
+                    if (valid && nemit == 0u) seg[0] = d;
+                    if (valid && nemit == 1u) seg[1] = d;
+                    nemit += valid ? 1u : 0u;
+                    if (act) {
+                        x = xe;
+                        y += qadv ? l : 0u;
+                        k += 1u;
+                        live = k < k1 && x < Wend;
+                        if (live) cw = a.R.cigar[k];
+                    }
+                }
+                // -- wave-private list in lane (= position) order: carried-over entries, first segments,
+                //    then second ones --
+                uint32_t n_list = n_keep;
+    #pragma unroll
+                for (int i = 0; i < kSegRound; ++i) {
+                    const bool has = (seg[i].y >> 31) != 0u;
+                    const unsigned long long m = __ballot(has);
+                    if (has) {
+                        const uint32_t idx = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                        list[idx] = seg[i];
+                    }
+                    n_list += (uint32_t)__popcll(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                // -- only full groups of 16 entries are consumed now; the < 16 left over move to the front
+                //    of the list and wait for the next round (or for the flush after the last pass) --
+                const uint32_t n_full = n_list & ~15u;
+                if (n_full) consume_list(n_full);
+                n_keep = n_list - n_full;
+                uint2 carry = make_uint2(0u, 0u);
+                if (n_full && lane < n_keep) carry = list[n_full + lane];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();       // the list is rewritten below and in the next round
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (n_full && lane < n_keep) list[lane] = carry;
+                if (!__any(live)) break;
+            }
         }
         sumq += sq32; sq32 = 0;
     }
@@ -733,11 +867,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
                 sl += (uint32_t)((int32_t)wl >> 16); vl[2 * h + 1] = sl;
             }
         }
-        uint32_t ir = sr, il = sl;
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t tr = __shfl_up(ir, o, 64), tl = __shfl_up(il, o, 64);
-            if (lane >= (uint32_t)o) { ir += tr; il += tl; }
-        }
+        const uint32_t ir = dpp_incl_scan_u32(sr), il = dpp_incl_scan_u32(sl);
         if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
         // 8-bit mode: the thread's PER positions are PER consecutive bytes of entry 2u+h (8 positions
         // each) of the two counter sets
@@ -857,7 +987,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
         }
         // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
         s_last[tid] = (uint8_t)(S[PER / 4 - 1] >> 24);
-        mx = wave_max_u32(mx);
+        mx = dpp_wave_max_u32(mx);
         if (lane == 0) s_wmax[wv] = mx;
         __syncthreads();
         uint32_t nb = 0;
@@ -885,10 +1015,7 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
             pk[3] = (uint32_t)sqc;
             pk[4] = (uint32_t)sumq;
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-#pragma unroll
-                for (int c = 0; c < 5; ++c) pk[c] += __shfl_xor(pk[c], o, 64);
-            }
+            for (int c = 0; c < 5; ++c) pk[c] = dpp_wave_sum_u32(pk[c]);
             if (lane == 0) {
                 unsigned long long *t = s_wtot[wv];
                 t[0] = pk[0] & 1023u; t[1] = (pk[0] >> 10) & 1023u; t[2] = pk[0] >> 20;

@@ -95,7 +95,9 @@ struct cl_ctx {
     DevBuf<uint32_t> d_end;
     DevBuf<uint32_t> d_win_lo, d_win_hi, d_win_off;
     DevBuf<unsigned long long> d_win_q0;
-    DevBuf<uint8_t> d_state;
+    DevBuf<uint8_t> d_state;         // per-position states: allocated and written for debug dumps only
+    DevBuf<uint16_t> d_runs;         // per window kT entries: run starts inside the window
+    DevBuf<uint8_t> d_first_state, d_last_state;
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
@@ -205,7 +207,9 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_fin.reserve(c->n_win / kFinBlock + 2));
     HIP_TRY(c, c->d_blk_off.reserve(c->n_win / kFinBlock + 2));
-    HIP_TRY(c, c->d_state.reserve(padded + 16));
+    HIP_TRY(c, c->d_runs.reserve(padded + 16));
+    HIP_TRY(c, c->d_first_state.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_last_state.reserve(c->n_win + 1));
     // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80)
     if (c->d_ref.cap < padded + 16 || c->ref_len_dev == UINT64_MAX) {
         HIP_TRY(c, c->d_ref.reserve(padded + 16));
@@ -268,6 +272,8 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     PileupArgs a;
     a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p; a.win_q0 = c->d_win_q0.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
+    a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
+    if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
     {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
@@ -278,14 +284,14 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (prof) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
     if (n_fin)
-        hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_state.p,
-                           kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
+        hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_first_state.p,
+                           c->d_last_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
     hipLaunchKernelGGL(k_fin_summary, dim3(1), dim3(kBlock), 0, c->stream, c->d_fin.p, n_fin, c->d_prep.p,
                        n_parts, c->extent, c->d_errflag.p, c->d_blk_off.p, c->d_summary.p);
     if (c->n_win) {
-        hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream,
-                           c->d_state.p, c->d_win_off.p, c->d_blk_off.p, c->n_win, c->extent, c->d_iv.p,
-                           (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+        hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+                           c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_blk_off.p,
+                           c->n_win, c->extent, c->d_iv.p, (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
     }
     if (prof) {
         HIP_TRY(c, hipEventRecord(ev[4], c->stream));
@@ -352,6 +358,7 @@ void cl_destroy(cl_ctx *c)
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
     c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
+    c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
     c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
     if (c->ev_made)
@@ -571,9 +578,9 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
         if (c->h_sum.n_intervals > c->d_iv.cap) {
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
             if (c->n_win)
-                hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3(c->n_win), dim3(kBlock), 0, c->stream, c->d_state.p,
-                                   c->d_win_off.p, c->d_blk_off.p, c->n_win, c->extent, c->d_iv.p,
-                                   (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+                hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
+                                   c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_blk_off.p,
+                                   c->n_win, c->extent, c->d_iv.p, (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
             HIP_TRY(c, hipGetLastError());
         }
         break;
@@ -642,11 +649,12 @@ cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_byt
 {
     if (!c || !c->uploaded) return fail(c, CL_ERR_INVALID, "no resident contig");
     // what one run must read at least once: quality bytes, per-read pos/mapq/offsets, CIGAR
-    // words, reference bytes; what it must write: one state byte per position
+    // words, reference bytes; what it must write: the intervals (12 bytes each; the per-position
+    // counters and states never reach HBM)
     const uint64_t n = c->n_reads;
     if (input_bytes)
         *input_bytes = c->n_qual + n * (4 + 1 + 4 + 8) + c->n_cigar * 4 + (uint64_t)c->extent;
-    if (output_bytes) *output_bytes = (uint64_t)c->extent;
+    if (output_bytes) *output_bytes = 12ull * c->h_sum.n_intervals;
     return CL_OK;
 }
 

@@ -389,7 +389,9 @@ struct PileupArgs {
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (k_read_prep_long)
-    uint8_t        *state;        // n_win*T bytes
+    uint8_t        *state;        // n_win*T bytes; written by the DEBUG instantiation only (test dumps)
+    uint16_t       *runs;         // per window T entries: the run starts strictly inside the window, rel. position | state << 12
+    uint8_t        *first_state, *last_state;   // per window: state of its first / last position (run seams)
     WinPartial     *winpart;
     uint32_t        extent;       // positions >= extent are not classified
     uint32_t        n_win;
@@ -991,6 +993,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         if (lane == 0) s_wmax[wv] = mx;
         __syncthreads();
         uint32_t nb = 0;
+        uint32_t bmk[PER / 4];                                               // 0x01 in the bytes that start a run
         {
             uint32_t prevb = tid > 0 ? (uint32_t)s_last[tid - 1] : (S[0] & 0xFFu);
             const uint4 okm = s_mend[n_ok];                                  // 0x01 for the positions < extent
@@ -999,12 +1002,15 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
             for (int h = 0; h < PER / 4; ++h) {
                 const uint32_t P = (S[h] << 8) | prevb;
                 const uint32_t d = S[h] ^ P;
-                nb += __popc(((((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) >> 7) & okw[h]);
+                bmk[h] = ((((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) >> 7) & okw[h];
+                nb += __popc(bmk[h]);
                 prevb = S[h] >> 24;
             }
         }
+        if (DEBUG) {
 #pragma unroll
-        for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
+            for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
+        }
         if (mode8) {
             // <= 510 reads: a thread's counts are <= 8 and every wave total fits 10 bits (sum_qc 17,
             // sum_q 29): five packed words, one butterfly reduction each
@@ -1035,8 +1041,25 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 if (lane == 0) s_wtot[wv][c] = r;
             }
         }
+        __syncthreads();
+        // the window's run list: every run start strictly inside the window, in position order
+        // (k_rle_write turns the lists into intervals; the per-position states never reach HBM)
+        {
+            const uint32_t inc = dpp_incl_scan_u32(nb);
+            if (nb) {
+                uint32_t off = inc - nb;
+                for (uint32_t i = 0; i < wv; ++i) off += (uint32_t)s_wtot[i][9];
+                uint16_t *dst = a.runs + (size_t)w * T + off;
+#pragma unroll
+                for (int h = 0; h < PER / 4; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((bmk[h] >> (8 * j)) & 1u) *dst++ = (uint16_t)((tid * PER + 4 * h + j) | (((S[h] >> (8 * j)) & 7u) << 12));
+            }
+            if (tid == 0) a.first_state[w] = (uint8_t)(S[0] & 0xFFu);
+            if (tid == kBlock - 1) a.last_state[w] = (uint8_t)(S[PER / 4 - 1] >> 24);
+        }
     }
-    __syncthreads();
     if (tid == 0) {
         WinPartial wp;
         unsigned long long tot[10];
@@ -1065,7 +1088,8 @@ struct FinPartial {
 };
 
 __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__restrict__ winpart,
-                                                            const uint8_t *__restrict__ state, uint32_t T,
+                                                            const uint8_t *__restrict__ first_state,
+                                                            const uint8_t *__restrict__ last_state, uint32_t T,
                                                             uint32_t n_win, uint32_t extent,
                                                             uint32_t *__restrict__ win_off,
                                                             FinPartial *__restrict__ fin)
@@ -1080,7 +1104,7 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
         const WinPartial wp = winpart[w];
         c = wp.n_inner;
         const uint32_t p = w * T;
-        if (p < extent) c += (w == 0) ? 1u : (state[p] != state[p - 1] ? 1u : 0u);
+        if (p < extent) c += (w == 0) ? 1u : (first_state[w] != last_state[w - 1] ? 1u : 0u);
         for (int i = 0; i < 6; ++i) acc[i] = wp.cnt[i];
         acc[6] = wp.n_cov; acc[7] = wp.sum_qc; acc[8] = wp.sum_q;
         maxraw = wp.max_raw;
@@ -1179,50 +1203,39 @@ __global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__rest
 // the intervals.  The thread that finds the start of run i also closes run i-1.
 // ---------------------------------------------------------------------------------------------
 template <int T>
-__global__ __launch_bounds__(kBlock) void k_rle_write(const uint8_t *__restrict__ state,
+__global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict__ runs,
+                                                       const uint8_t *__restrict__ first_state,
+                                                       const uint8_t *__restrict__ last_state,
+                                                       const WinPartial *__restrict__ winpart,
                                                        const uint32_t *__restrict__ win_off,
                                                        const uint32_t *__restrict__ blk_off,
                                                        uint32_t n_win, uint32_t extent,
                                                        Interval *__restrict__ iv, uint32_t iv_cap)
 {
-    constexpr int PER = T / kBlock;
-    __shared__ uint32_t s_w[kBlock / 64];
-    const uint32_t w = blockIdx.x;
+    // one wave per window: its seam run (if the first state differs from the previous window's last)
+    // and the run starts of its list; a run start also closes the run before it
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t w = blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6);
     if (w >= n_win) return;
-    const uint32_t tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const uint32_t p0 = w * (uint32_t)T + tid * PER;
-    uint8_t st[PER];
-    static_assert(PER % 4 == 0, "window / threads must be a multiple of 4");
-#pragma unroll
-    for (int h = 0; h < PER / 4; ++h) {
-        const uint32_t v = reinterpret_cast<const uint32_t *>(state + p0)[h];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) st[4 * h + j] = (uint8_t)(v >> (8 * j));
+    const uint32_t W = w * (uint32_t)T;
+    if (W >= extent) return;
+    const uint32_t n_inner = winpart[w].n_inner;
+    const uint32_t seam = (w == 0 || first_state[w] != last_state[w - 1]) ? 1u : 0u;
+    const uint32_t idx0 = blk_off[w / kFinBlock] + win_off[w];
+    if (lane == 0 && seam) {
+        if (idx0 < iv_cap) { iv[idx0].start = W; iv[idx0].state = first_state[w]; }
+        if (idx0 > 0 && idx0 - 1 < iv_cap) iv[idx0 - 1].end = W;
     }
-    uint32_t prev = p0 > 0 ? state[p0 - 1] : 0x100u;   // position 0 always starts a run
-    uint32_t flags = 0, c = 0;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        if (p0 + i < extent && st[i] != prev) { flags |= 1u << i; ++c; }
-        prev = st[i];
+    const uint16_t *rl = runs + (size_t)w * T;
+    for (uint32_t i = lane; i < n_inner; i += 64u) {
+        const uint32_t e = rl[i];
+        const uint32_t idx = idx0 + seam + i, start = W + (e & 0xFFFu);
+        if (idx < iv_cap) { iv[idx].start = start; iv[idx].state = e >> 12; }
+        if (idx > 0 && idx - 1 < iv_cap) iv[idx - 1].end = start;
     }
-    uint32_t inc = c;
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-    if (lane == 63) s_w[wv] = inc;
-    __syncthreads();
-    uint32_t idx = blk_off[w / kFinBlock] + win_off[w] + inc - c;
-    for (uint32_t i = 0; i < wv; ++i) idx += s_w[i];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        if (flags & (1u << i)) {
-            if (idx < iv_cap) { iv[idx].start = p0 + i; iv[idx].state = st[i]; }
-            if (idx > 0 && idx - 1 < iv_cap) iv[idx - 1].end = p0 + i;
-            ++idx;
-        }
-    }
-    // the thread that owns the last classified position closes the last run
-    if (extent > 0 && p0 <= extent - 1 && extent - 1 < p0 + PER) {
-        if (idx > 0 && idx - 1 < iv_cap) iv[idx - 1].end = extent;
+    if (w == n_win - 1 && lane == 0) {                     // the last run ends where classification ends
+        const uint32_t last = idx0 + seam + n_inner;
+        if (last > 0 && last - 1 < iv_cap) iv[last - 1].end = extent;
     }
 }
 

@@ -101,7 +101,6 @@ struct cl_ctx {
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
-    DevBuf<uint32_t> d_blk_off;
     DevBuf<uint32_t> d_errflag;        // [0] error bits of k_window_bounds, [1] number of long reads
     DevBuf<uint32_t> d_long_list, d_ck_x, d_ck_y;
     DevBuf<uint32_t> d_lut;
@@ -206,7 +205,6 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_win_q0.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_fin.reserve(c->n_win / kFinBlock + 2));
-    HIP_TRY(c, c->d_blk_off.reserve(c->n_win / kFinBlock + 2));
     HIP_TRY(c, c->d_runs.reserve(padded + 16));
     HIP_TRY(c, c->d_first_state.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_last_state.reserve(c->n_win + 1));
@@ -286,13 +284,11 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (n_fin)
         hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_first_state.p,
                            c->d_last_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
-    hipLaunchKernelGGL(k_fin_summary, dim3(1), dim3(kBlock), 0, c->stream, c->d_fin.p, n_fin, c->d_prep.p,
-                       n_parts, c->extent, c->d_errflag.p, c->d_blk_off.p, c->d_summary.p);
-    if (c->n_win) {
-        hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-                           c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_blk_off.p,
-                           c->n_win, c->extent, c->d_iv.p, (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
-    }
+    // run lists -> intervals, one wave per window; the extra last workgroup reduces the summary
+    hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
+                       c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
+                       c->d_prep.p, n_parts, c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
+                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
     if (prof) {
         HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         c->ev_pending += 1;
@@ -360,7 +356,7 @@ void cl_destroy(cl_ctx *c)
     c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_blk_off.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
@@ -577,10 +573,14 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
         }
         if (c->h_sum.n_intervals > c->d_iv.cap) {
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
-            if (c->n_win)
-                hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64)), dim3(kBlock), 0, c->stream,
-                                   c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_blk_off.p,
-                                   c->n_win, c->extent, c->d_iv.p, (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+            {
+                const uint32_t n_fin2 = (c->n_win + kFinBlock - 1) / kFinBlock;
+                const uint32_t n_parts2 = c->has_long ? (uint32_t)kPrepParts : (uint32_t)kPrepBlocks;
+                hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
+                                   c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin2,
+                                   c->d_prep.p, n_parts2, c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
+                                   (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+            }
             HIP_TRY(c, hipGetLastError());
         }
         break;

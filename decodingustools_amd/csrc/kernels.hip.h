@@ -7,10 +7,12 @@
 //   k_window_bounds  per window of T reference positions: [lo,hi) range of reads that can touch it
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
-//                    (callable_profiler.rs:100-116) and written as one state byte per position
-//   k_fin_windows /  run-boundary counts -> exclusive offsets (two-level scan); window / read
-//   k_fin_summary    partials -> contig summary
-//   k_rle_write      state bytes -> (start,end,state) intervals (callable_profiler.rs:122-155)
+//                    (callable_profiler.rs:100-116) and reduced to the window's run list (the
+//                    positions inside the window where the state changes) and its totals
+//   k_fin_windows    run counts per window (inner starts + the seam with the previous window) ->
+//                    exclusive offsets inside blocks of kFinBlock windows
+//   k_rle_write      run lists -> (start,end,state) intervals (callable_profiler.rs:122-155), one wave
+//                    per window; its last workgroup reduces the partials to the contig summary
 //
 // Integer / byte work throughout: HBM-bound, no MFMA.  Wave = 64 lanes.
 #pragma once
@@ -318,6 +320,8 @@ __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint
 // k_window_bounds: thread per window.  Reads are sorted by pos; a read can touch window
 // [W, W+T) only if pos < W+T and pos + max_span > W.
 // ---------------------------------------------------------------------------------------------
+// (A K-ary search that loads K-1 pivots per round was tried for fewer dependent loads: K = 4 and 16 were
+// both slower than this binary search, whose first dozen levels hit the same few lines for every thread.)
 __device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t n, long long key)
 {
     uint32_t lo = 0, hi = n;                       // first r with pos[r] >= key
@@ -1075,9 +1079,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_fin_windows / k_fin_summary: two-level exclusive scan of the run starts per window (inner
-// boundaries + the seam with the previous window) and reduction of the window / read partials
-// to the contig summary.
+// k_fin_windows / fin_summary: exclusive scan of the run starts per window inside blocks of kFinBlock
+// windows (inner boundaries + the seam with the previous window) and reduction of the window / read
+// partials to the contig summary (fin_summary runs as the last workgroup of k_rle_write).
 // ---------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
 
@@ -1132,47 +1136,30 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
-                                                         const PrepPartial *__restrict__ prep, uint32_t n_prep,
-                                                         uint32_t extent, const uint32_t *__restrict__ err_flag,
-                                                         uint32_t *__restrict__ blk_off,
-                                                         DevSummary *__restrict__ out)
+// The contig summary: reduction of the per-block window partials and of the read partials.  Run by
+// one workgroup of kBlock threads (the extra, last workgroup of k_rle_write).
+__device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
+                                            const PrepPartial *__restrict__ prep, uint32_t n_prep,
+                                            uint32_t extent, const uint32_t *__restrict__ err_flag,
+                                            DevSummary *__restrict__ out)
 {
-    __shared__ unsigned long long s_red[11][kBlock / 64];
+    __shared__ unsigned long long s_red[12][kBlock / 64];
     __shared__ uint32_t s_u[3][kBlock / 64];
-    __shared__ uint32_t s_w[kBlock / 64];
-    __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) s_carry = 0;
-    __syncthreads();
-    unsigned long long acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [11]: number of runs
     uint32_t maxraw = 0, maxend = 0, err = 0;
-    for (uint32_t base = 0; base < n_fin; base += kBlock) {
-        const uint32_t b = base + tid;
-        uint32_t c = 0;
-        if (b < n_fin) {
-            const FinPartial fp = fin[b];
-            c = fp.n_runs;
-            for (int i = 0; i < 9; ++i) acc[i] += fp.acc[i];
-            maxraw = fp.max_raw > maxraw ? fp.max_raw : maxraw;
-        }
-        uint32_t inc = c;
-        for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
-        if (lane == 63) s_w[wv] = inc;
-        __syncthreads();
-        uint32_t off = s_carry + inc - c;
-        for (int i = 0; i < wv; ++i) off += s_w[i];
-        if (b < n_fin) blk_off[b] = off;
-        __syncthreads();
-        if (tid == kBlock - 1) s_carry = off + c;
-        __syncthreads();
+    for (uint32_t b = tid; b < n_fin; b += kBlock) {
+        const FinPartial fp = fin[b];
+        acc[11] += fp.n_runs;
+        for (int i = 0; i < 9; ++i) acc[i] += fp.acc[i];
+        maxraw = fp.max_raw > maxraw ? fp.max_raw : maxraw;
     }
     for (uint32_t i = tid; i < n_prep; i += kBlock) {
         acc[9] += prep[i].sum_reflen; acc[10] += prep[i].sum_mapq_reflen;
         maxend = prep[i].max_end > maxend ? prep[i].max_end : maxend; err |= prep[i].err;
     }
 #pragma unroll
-    for (int i = 0; i < 11; ++i) {
+    for (int i = 0; i < 12; ++i) {
         const unsigned long long v = wave_sum_u64(acc[i]);
         if (lane == 0) s_red[i][wv] = v;
     }
@@ -1180,8 +1167,8 @@ __global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__rest
     if (lane == 0) { s_u[0][wv] = maxraw; s_u[1][wv] = maxend; s_u[2][wv] = err; }
     __syncthreads();
     if (tid == 0) {
-        unsigned long long tot[11];
-        for (int i = 0; i < 11; ++i) { tot[i] = 0; for (int j = 0; j < kBlock / 64; ++j) tot[i] += s_red[i][j]; }
+        unsigned long long tot[12];
+        for (int i = 0; i < 12; ++i) { tot[i] = 0; for (int j = 0; j < kBlock / 64; ++j) tot[i] += s_red[i][j]; }
         uint32_t mr = 0, me = 0, er = 0;
         for (int j = 0; j < kBlock / 64; ++j) { mr = s_u[0][j] > mr ? s_u[0][j] : mr; me = s_u[1][j] > me ? s_u[1][j] : me; er |= s_u[2][j]; }
         for (int i = 0; i < 6; ++i) out->state_counts[i] = tot[i];
@@ -1192,15 +1179,15 @@ __global__ __launch_bounds__(kBlock) void k_fin_summary(const FinPartial *__rest
         out->summed_mapq = tot[10];
         out->extent = extent;
         out->max_raw_depth = mr;
-        out->n_intervals = s_carry;
+        out->n_intervals = tot[11];
         out->max_end = me;
         out->err = er | *err_flag;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_rle_write: one workgroup per window; recomputes run starts from the state bytes and writes
-// the intervals.  The thread that finds the start of run i also closes run i-1.
+// k_rle_write: one wave per window turns the window's run list into intervals.  The lane that writes
+// the start of run i also closes run i-1.  The extra last workgroup computes the contig summary.
 // ---------------------------------------------------------------------------------------------
 template <int T>
 __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict__ runs,
@@ -1208,10 +1195,17 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
                                                        const uint8_t *__restrict__ last_state,
                                                        const WinPartial *__restrict__ winpart,
                                                        const uint32_t *__restrict__ win_off,
-                                                       const uint32_t *__restrict__ blk_off,
+                                                       const FinPartial *__restrict__ fin, uint32_t n_fin,
+                                                       const PrepPartial *__restrict__ prep, uint32_t n_prep,
+                                                       const uint32_t *__restrict__ err_flag,
+                                                       DevSummary *__restrict__ summary,
                                                        uint32_t n_win, uint32_t extent,
                                                        Interval *__restrict__ iv, uint32_t iv_cap)
 {
+    if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: the contig summary
+        fin_summary(fin, n_fin, prep, n_prep, extent, err_flag, summary);
+        return;
+    }
     // one wave per window: its seam run (if the first state differs from the previous window's last)
     // and the run starts of its list; a run start also closes the run before it
     const uint32_t lane = threadIdx.x & 63u;
@@ -1221,7 +1215,10 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
     if (W >= extent) return;
     const uint32_t n_inner = winpart[w].n_inner;
     const uint32_t seam = (w == 0 || first_state[w] != last_state[w - 1]) ? 1u : 0u;
-    const uint32_t idx0 = blk_off[w / kFinBlock] + win_off[w];
+    // runs before this window: those of the earlier k_fin_windows blocks + the offset inside its block
+    uint32_t before = 0;
+    for (uint32_t b = lane; b < w / kFinBlock; b += 64u) before += fin[b].n_runs;
+    const uint32_t idx0 = dpp_wave_sum_u32(before) + win_off[w];
     if (lane == 0 && seam) {
         if (idx0 < iv_cap) { iv[idx0].start = W; iv[idx0].state = first_state[w]; }
         if (idx0 > 0 && idx0 - 1 < iv_cap) iv[idx0 - 1].end = W;

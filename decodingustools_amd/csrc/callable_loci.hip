@@ -488,7 +488,7 @@ cl_status cl_contig_upload(cl_ctx *c)
     HIP_TRY(c, c->d_end.reserve(n + 1));
     HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
     HIP_TRY(c, c->d_qual_off.reserve(n + 1));
-    HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 1));
+    HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));          // k_read_prep loads four words at a read's first op
     HIP_TRY(c, c->d_long_list.reserve(n + 1));
     HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));

@@ -96,6 +96,9 @@ struct Reads {
     uint32_t n;
 };
 
+// 16 bytes at any byte address (compiles to one unaligned dwordx4 load)
+struct __attribute__((packed, aligned(1))) Q16 { uint32_t w[4]; };
+
 __device__ __forceinline__ bool op_match(uint32_t op) { return op == 0u || op == 7u || op == 8u; }
 __device__ __forceinline__ bool op_del(uint32_t op) { return op == 2u || op == 3u; }
 __device__ __forceinline__ bool op_ins(uint32_t op) { return op == 1u || op == 4u; }
@@ -173,6 +176,7 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
     const uint32_t stride = gridDim.x * kBlock;
     for (uint32_t r0 = blockIdx.x * kBlock + threadIdx.x; r0 < R.n; r0 += U * stride) {
         uint32_t k0[U], k1[U], ps[U], mq[U], c0[U];
+        Q16 cw[U];                                   // the first four CIGAR words of each read, one 16-byte load
         bool in[U];
 #pragma unroll
         for (int i = 0; i < U; ++i) {
@@ -182,7 +186,11 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
             k0[i] = R.cigar_off[rr]; k1[i] = R.cigar_off[rr + 1]; ps[i] = (uint32_t)R.pos[rr]; mq[i] = R.mapq[rr];
         }
 #pragma unroll
-        for (int i = 0; i < U; ++i) c0[i] = k0[i] < k1[i] ? R.cigar[k0[i]] : 0u;
+        for (int i = 0; i < U; ++i) {
+            // reads past the read's own words (the next reads' or the array's padding) are never used
+            __builtin_memcpy(&cw[i], R.cigar + k0[i], 16);
+            c0[i] = k0[i] < k1[i] ? cw[i].w[0] : 0u;
+        }
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             if (!in[i]) continue;
@@ -192,7 +200,9 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
             }
             unsigned long long reflen = 0;
             for (uint32_t k = k0[i]; k < k1[i]; ++k) {
-                const uint32_t c = k == k0[i] ? c0[i] : R.cigar[k], op = c & 15u, l = c >> 4;
+                const uint32_t d = k - k0[i];
+                const uint32_t c = d == 0 ? c0[i] : d == 1 ? cw[i].w[1] : d == 2 ? cw[i].w[2] : d == 3 ? cw[i].w[3] : R.cigar[k];
+                const uint32_t op = c & 15u, l = c >> 4;
                 if (op_match(op) || op_del(op)) {
                     reflen += l;
                     if (l == 0) err |= kErrCigar;          // zero-length reference-consuming op
@@ -382,7 +392,6 @@ __device__ __forceinline__ uint32_t swar_ge7(uint32_t q, uint32_t add, uint32_t 
     return ((d | (q & orm)) & (q | andm)) & 0x80808080u;
 }
 
-struct __attribute__((packed, aligned(1))) Q16 { uint32_t w[4]; };
 
 struct PileupArgs {
     Reads R;

@@ -4,6 +4,7 @@
 // itself is in kernels.hip.h.  No CPU fallback exists: without a HIP device cl_create fails.
 #include "../../include/callable_loci.h"
 #include "kernels.hip.h"
+#include "host_parallel.h"
 
 #include <hip/hip_runtime.h>
 
@@ -83,6 +84,11 @@ struct cl_ctx {
     std::vector<unsigned long long> h_qual_off;
     std::vector<uint8_t> h_qual;     // quality bytes of small tiles, not yet on the device
     uint64_t q_dev = 0;              // quality bytes of this contig that already are (d_qual + kQualPad ..)
+    // reads whose reference span exceeds kWideSpan (ascending read index = ascending position)
+    std::vector<uint32_t> h_wide_idx;
+    std::vector<int32_t> h_wide_pos;
+    uint32_t span_n = 0, span_w = 0; // longest span among the ordinary / the wide reads
+    uint32_t n_wide = 0;
 
     // device residents
     DevBuf<int32_t> d_pos;
@@ -93,7 +99,8 @@ struct cl_ctx {
     DevBuf<uint8_t> d_qual;
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
-    DevBuf<uint32_t> d_win_lo, d_win_hi, d_win_off;
+    DevBuf<uint32_t> d_win_lo, d_win_hi, d_win_off, d_win_wlo, d_win_wn, d_wide_idx;
+    DevBuf<int32_t> d_wide_pos;
     DevBuf<unsigned long long> d_win_q0;
     DevBuf<uint8_t> d_state;         // per-position states: allocated and written for debug dumps only
     DevBuf<uint16_t> d_runs;         // per window kT entries: run starts inside the window
@@ -201,6 +208,8 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     const size_t padded = (size_t)c->n_win * kT;
     HIP_TRY(c, c->d_win_lo.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_hi.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win_wlo.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win_wn.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_off.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_q0.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
@@ -264,11 +273,13 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     if (c->n_win) {
         hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                           c->stream, R, c->d_prep.p, n_parts, kT, c->n_win, c->d_win_lo.p, c->d_win_hi.p, c->d_win_q0.p, c->d_errflag.p);
+                           c->stream, R, c->span_n, c->span_w, c->d_wide_pos.p, c->d_wide_idx.p, c->n_wide, kT, c->n_win,
+                           c->d_win_lo.p, c->d_win_hi.p, c->d_win_wlo.p, c->d_win_wn.p, c->d_win_q0.p, c->d_errflag.p);
     }
     if (prof) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     PileupArgs a;
     a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p; a.win_q0 = c->d_win_q0.p;
+    a.win_wlo = c->d_win_wlo.p; a.win_wn = c->d_win_wn.p; a.wide_idx = c->d_wide_idx.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
     if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
@@ -354,6 +365,7 @@ void cl_destroy(cl_ctx *c)
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
     c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
+    c->d_win_wlo.release(); c->d_win_wn.release(); c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
     c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
@@ -379,6 +391,7 @@ cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uin
     c->h_cigar_off.assign(1, 0u); c->h_qual_off.assign(1, 0ull);
     c->h_iv.clear();
     c->q_dev = 0;
+    c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -436,9 +449,29 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     }
     const uint32_t cig0 = t->cigar_off[0];
     const uint64_t ncig = (uint64_t)t->cigar_off[n] - cig0;
+    if (ncig && !t->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
+    {
+        // reference span of every read (what k_read_prep computes as end - pos): the longest ordinary
+        // span bounds every window's candidate range, reads wider than kWideSpan get their own list
+        std::vector<uint32_t> span(n);
+        const uint64_t rbase = c->h_pos.size();
+        dut::parallel_for(n, 16384, [&](size_t i) {
+            unsigned long long l = 0;
+            for (uint32_t k = t->cigar_off[i]; k < t->cigar_off[i + 1]; ++k) {
+                const uint32_t op = t->cigar[k] & 15u;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += t->cigar[k] >> 4;
+            }
+            span[i] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;     // k_read_prep flags spans beyond the 32-bit range
+        });
+        for (uint64_t i = 0; i < n; ++i) {
+            if (span[i] > kWideSpan) {
+                c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]);
+                c->span_w = std::max(c->span_w, span[i]);
+            } else c->span_n = std::max(c->span_n, span[i]);
+        }
+    }
     const uint64_t q0 = t->qual_off[0];
     const uint64_t nq = t->qual_off[n] - q0;
-    if (ncig && !t->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
     if (nq && !t->qual) return fail(c, CL_ERR_INVALID, "null qual array");
     if (c->h_cigar.size() + ncig > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 CIGAR operations in one contig");
     if (c->q_dev + c->h_qual.size() + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality bytes in one contig");
@@ -500,6 +533,13 @@ cl_status cl_contig_upload(cl_ctx *c)
     HIP_TRY(c, hipMemcpyAsync(c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     if (c->n_cigar) HIP_TRY(c, hipMemcpyAsync(c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    c->n_wide = (uint32_t)c->h_wide_idx.size();
+    HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
+    HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
+    if (c->n_wide) {
+        HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->d_wide_pos.p, c->h_wide_pos.data(), c->n_wide * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -29,6 +29,8 @@ constexpr int kPrepParts = kPrepBlocks + kLongBlocks;
 constexpr uint32_t kLongOps = 64;    // reads with more CIGAR ops are scanned by a whole wave and get a
                                      // checkpoint (reference, query position) before every 64th op
 constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
+constexpr uint32_t kWideSpan = 16384; // reads spanning more reference than this are "wide": looked up per window
+                                      // in their own list instead of widening every window's candidate range
 constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
 
 enum : uint32_t { kErrCigar = 1u, kErrRange = 2u, kNeedDeep = 4u };
@@ -327,8 +329,8 @@ __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_window_bounds: thread per window.  Reads are sorted by pos; a read can touch window
-// [W, W+T) only if pos < W+T and pos + max_span > W.
+// k_window_bounds: thread per window; the candidate reads of every window (binary searches over the
+// sorted positions).
 // ---------------------------------------------------------------------------------------------
 // (A K-ary search that loads K-1 pivots per round was tried for fewer dependent loads: K = 4 and 16 were
 // both slower than this binary search, whose first dozen levels hit the same few lines for every thread.)
@@ -342,33 +344,42 @@ __device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t
     return lo;
 }
 
-__global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, const PrepPartial *__restrict__ part,
-                                                           uint32_t n_parts, uint32_t T, uint32_t n_win,
+__global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, uint32_t span_n, uint32_t span_w,
+                                                           const int32_t *__restrict__ wide_pos,
+                                                           const uint32_t *__restrict__ wide_idx, uint32_t n_wide,
+                                                           uint32_t T, uint32_t n_win,
                                                            uint32_t *__restrict__ win_lo,
                                                            uint32_t *__restrict__ win_hi,
+                                                           uint32_t *__restrict__ win_wlo,
+                                                           uint32_t *__restrict__ win_wn,
                                                            unsigned long long *__restrict__ win_q0,
                                                            uint32_t *__restrict__ err_flag)
 {
-    __shared__ uint32_t s_m[kBlock / 64];
-    uint32_t m = 0;
-    for (uint32_t i = threadIdx.x; i < n_parts; i += kBlock) { uint32_t v = part[i].max_span; m = v > m ? v : m; }
-    m = wave_max_u32(m);
-    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
-    __syncthreads();
-    uint32_t max_span = 0;
-    for (int i = 0; i < kBlock / 64; ++i) max_span = s_m[i] > max_span ? s_m[i] : max_span;
+    // span_n: longest reference span among the reads of ordinary span (<= kWideSpan), span_w: among the
+    // wide ones (both from the host, which sees every CIGAR at cl_push_reads).  A read can touch window
+    // [W, W+T) only if pos < W+T and pos + span > W: the ordinary candidates are the reads [lo, hi) with
+    // pos in (W - span_n, W + T); wide reads that start before that range are looked up in the (short)
+    // list of wide reads, pos in (W - span_w, W - span_n].
     const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
     if (w >= n_win) return;
     const long long W = (long long)w * T;
-    const uint32_t lo = lower_bound_pos(R.pos, R.n, W - (long long)max_span + 1);
+    const uint32_t lo = lower_bound_pos(R.pos, R.n, W - (long long)span_n + 1);
     const uint32_t hi = lower_bound_pos(R.pos, R.n, W + (long long)T);
+    uint32_t wlo = 0, wn = 0;
+    if (n_wide) {
+        wlo = lower_bound_pos(wide_pos, n_wide, W - (long long)span_w + 1);
+        wn = lower_bound_pos(wide_pos, n_wide, W - (long long)span_n + 1) - wlo;
+    }
     win_lo[w] = lo;
     win_hi[w] = hi;
-    win_q0[w] = R.qual_off[lo];                    // lo <= n: the offsets array has n+1 entries
+    win_wlo[w] = wlo;
+    win_wn[w] = wn;
+    const uint32_t first = wn ? wide_idx[wlo] : lo;     // lo <= n: the offsets array has n+1 entries
+    win_q0[w] = R.qual_off[first];
     // k_pileup addresses the quality bytes of a window with 32-bit offsets
-    if (hi > lo && R.qual_off[hi] - R.qual_off[lo] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
+    if (hi > first && R.qual_off[hi] - R.qual_off[first] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
     // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
-    if (hi - lo > 32767u) atomicOr(err_flag, kNeedDeep);
+    if ((hi - lo) + wn > 32767u) atomicOr(err_flag, kNeedDeep);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -398,7 +409,9 @@ struct PileupArgs {
     Opts o;
     const uint32_t *end;          // per read
     const uint32_t *win_lo, *win_hi;
-    const unsigned long long *win_q0;   // qual_off[win_lo[w]]
+    const uint32_t *win_wlo, *win_wn;   // the window's wide candidates: wide_idx[wlo .. wlo+wn)
+    const uint32_t *wide_idx;           // read indices of the wide reads, ascending
+    const unsigned long long *win_q0;   // qual_off of the window's first candidate read
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (k_read_prep_long)
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     // per-wave totals: cnt[6], n_cov, sum_qc, sum_q, n_inner.  (Same-address LDS atomics are avoided:
     // hipcc turns them into a scalar loop over the active lanes.)
     __shared__ unsigned long long s_wtot[kWaves][10];
-    // LONG: the live reads of a pass, two entries each: {read, op index, x, y}, {op end, quality offset, quality length, -}
+    // LONG: the live reads of a pass, two entries each: {candidate number, op index, x, y}, {op end, quality offset, quality length, -}
     __shared__ __attribute__((aligned(16))) uint4 s_live[LONG ? 2 * kBlock : 1];
     __shared__ uint32_t s_nlive;
 
@@ -566,7 +579,10 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     const uint32_t p0 = W + tid * PER;
 
     const uint32_t lo = a.win_lo[w], hi = a.win_hi[w];
-    // all quality bytes of the reads [lo,hi) lie within 2^32 of qual_off[lo] (checked by
+    // candidates: first the wn wide reads that start before read lo, then the reads [lo, hi)
+    const uint32_t wlo = a.win_wlo[w], wn = a.win_wn[w];
+    const uint32_t n_cand = wn + (hi - lo);
+    // all quality bytes of the candidates lie within 2^32 of the first one's (checked by
     // k_window_bounds), so they are addressed by 32-bit offsets from a uniform base.  The base
     // sits kQualPad bytes low so that the offset of a unit start never goes negative.
     const unsigned long long qwin = a.win_q0[w];
@@ -605,7 +621,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
 
     // qc_depth counters: two sets of bytes when the window is touched by <= 510 reads (the reads
     // alternate between the sets, so no byte can pass 255), else 16-bit fields (DEEP: 32-bit words)
-    const bool mode8 = !DEEP && (hi - lo) <= 510u;
+    const bool mode8 = !DEEP && n_cand <= 510u;
 
     // ---- the pass over the reads ----
     uint32_t sq32 = 0;                              // sum of passing qualities handled by this lane
@@ -655,12 +671,14 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         else if (mode8) consume(std::integral_constant<int, 0>{}, n_use);
         else consume(std::integral_constant<int, 1>{}, n_use);
     };
-    for (uint32_t base = lo; base < ((a.ablate & 2u) ? lo : hi); base += kBlock) {
-        const uint32_t r = base + 4u * lane + wv;
+    for (uint32_t base = 0; base < ((a.ablate & 2u) ? 0u : n_cand); base += kBlock) {
+        const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets
+        uint32_t r = lo + (v - wn);
+        if (v < wn) r = a.wide_idx[wlo + v];
         __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
         bool live = false;
         uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
-        if (r < hi) {
+        if (v < n_cand) {
             x = (uint32_t)a.R.pos[r];
             const uint32_t e = a.end[r], mq = a.R.mapq[r];
             k = a.R.cigar_off[r];
@@ -713,7 +731,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 wb = __shfl(wb, 0, 64);
                 if (live) {
                     const uint32_t idx = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    s_live[2u * idx] = make_uint4(r, k, x, y);
+                    s_live[2u * idx] = make_uint4(v, k, x, y);
                     s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
                 }
             }
@@ -788,7 +806,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
             }
             __syncthreads();                                         // s_live is rewritten by the next pass
         } else {
-            const uint32_t setbit = (r & 1u) << 30;      // which 8-bit counter set this read adds to
+            const uint32_t setbit = (v & 1u) << 30;      // which 8-bit counter set this read adds to
             for (;;) {                                   // rounds: wave-uniform loop
                 // -- each lane: next (at most kSegRound) segments of its read.  Wave-uniform loop,
                 //    per-lane predication, one CIGAR op per iteration; invariant: cw == cigar[k] while live --

@@ -522,3 +522,35 @@ def test_find_y_branch_on_files_and_cli(tmp_path):
         bam2 = str(tmp_path / "n.bam")
         write_bam(bam2, [("chrY", L)], {0: rec})
         H.analyze_haplogroup(bam2, fa, tree_path, out)
+
+
+def test_outlier_spans_do_not_widen_every_window(tmp_path):
+    """A few reads with very long reference spans (spliced 'N' gaps, a megabase deletion) among ordinary
+    short reads: they are kept in the engine's wide-read list and looked up per window; results must not
+    change, including raw_depth over the gaps (mod.rs:22-23 counts D/N columns) and the windows far
+    inside a gap that only the wide reads touch."""
+    L = 1_500_000
+    base = synth.short_read_contig(L, 12, 555)
+    ref = synth.make_reference(L, 556)
+    rng = np.random.default_rng(557)
+    extra = []
+    for i in range(40):
+        p = int(rng.integers(0, L - 1_100_000))
+        gap = int(rng.choice([20_000, 70_000, 400_000, 1_000_000]))
+        op = "N" if i % 2 else "D"
+        extra.append((p, f"60M{gap}{op}40M5S", int(rng.choice([0, 30, 60])), 35, 0, f"w{i}"))
+    extra.append((10, f"10M{L - 100}N10M", 60, 30, 0, "span_all"))            # touches every window
+    extra.append((L - 30_000, "50M20000D50M", 60, 30, 0, "tail"))
+    # merge in coordinate order
+    wide = ContigRecords.from_reads(sorted(extra, key=lambda r: r[0]))
+    reads = []
+    def rows(rec):
+        for i in range(rec.n):
+            cig = "".join(f"{int(c) >> 4}{'MIDNSHP=XB'[int(c) & 15]}" for c in rec.cigar[rec.cigar_off[i]:rec.cigar_off[i + 1]])
+            reads.append((int(rec.pos[i]), cig, int(rec.mapq[i]), rec.qual[int(rec.qual_off[i]):int(rec.qual_off[i + 1])].tolist(), int(rec.flag[i]),
+                          bytes(rec.qname[rec.qname_off[i]:rec.qname_off[i + 1]]).decode()))
+    sub = base.slice(0, min(base.n, 60_000))
+    rows(sub); rows(wide)
+    reads.sort(key=lambda r: r[0])
+    rec = ContigRecords.from_reads(reads)
+    compare([("chrW", 5, L, ref, rec)], dict(min_depth=2, min_depth_for_low_mapq=3), tmp_path, "wide")

@@ -50,6 +50,38 @@ def cpu_baseline(rec, ref, L_sample, opt, tid):
     return sub, st, obed, dt
 
 
+def cpu_baseline_all_cores(rec, ref, opt, tid, start, piece, threads):
+    """The same oracle on `threads` host threads at once, each on its own `piece`-long stretch of the
+    contig (taken as a contig of its own).  The reference is single-threaded; this is the tile-parallel
+    figure SURVEY 8d asks to be shown beside it."""
+    import oracle
+    from concurrent.futures import ThreadPoolExecutor
+    from decodingustools_amd.records import ContigRecords
+    jobs = []
+    for t in range(threads):
+        a = start + t * piece
+        if a + piece > ref.shape[0]:
+            break
+        i0, i1 = int(np.searchsorted(rec.pos, a)), int(np.searchsorted(rec.pos, a + piece))
+        sub = rec.slice(i0, i1)
+        sub.pos = (sub.pos - np.int32(a)).astype(np.int32)
+        jobs.append((sub, ref[a:a + piece]))
+    if not jobs:
+        return None
+    d = tempfile.mkdtemp()
+
+    def run(k):
+        prof = oracle.Profiler(os.path.join(d, f"p{k}.bed"))
+        oracle.process_single_contig(prof, opt, "chr21", tid, piece, jobs[k][1], jobs[k][0])
+        prof.close()
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(len(jobs)) as ex:
+        list(ex.map(run, range(len(jobs))))
+    dt = time.perf_counter() - t0
+    return {"value": len(jobs) * piece / dt, "unit": "bases/s", "cores": len(jobs),
+            "sample": f"{len(jobs)} stretches of {piece} positions, one oracle thread each, {dt:.1f}s"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -196,6 +228,12 @@ def main():
             out["cpu_baseline"] = {"value": Ls / cdt, "unit": "bases/s", "cores": 1, "kind": "port",
                                    "sample": f"first {Ls} positions of the same contig ({sub.n} reads), "
                                              f"oracle/callable_oracle.c single thread, {cdt:.1f}s"}
+            try:
+                allc = cpu_baseline_all_cores(rec, ref, opt, tid, Ls, 2_000_000, min(16, os.cpu_count() or 1))
+                if allc:
+                    out["cpu_baseline"]["all_cores"] = allc
+            except Exception as e:                      # the single-thread figure above is the contract's
+                log(f"[bench] all-cores CPU baseline skipped: {e}")
             out["bed_bit_exact"] = bool(exact)
             if not exact:
                 log("[bench] WARNING: GPU BED/summary differs from the oracle on the sample")

@@ -765,10 +765,8 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                     const bool big = valid && (trel - srel) > 64u;
                     if (valid && !big) {
                         const uint32_t qo = rqrel + ys + (sp - xs) + (uint32_t)kQualPad - srel;
-                        const uint32_t u1 = (trel - 1u) >> 4;
-                        for (uint32_t u = srel >> 4; u <= u1; ++u) {
-                            Q16 v;
-                            __builtin_memcpy(&v, qbase + (qo + (u << 4)), 16);
+                        const uint32_t u0 = srel >> 4, u1 = (trel - 1u) >> 4;
+                        auto unit = [&](const Q16 &v, uint32_t u) {
                             const uint32_t ps = u << 4;
                             const uint32_t vs = srel > ps ? srel - ps : 0u;
                             const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
@@ -777,6 +775,18 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                             if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
                             else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
                             else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                        };
+                        // the first two units of the run are requested together (a ~15-base run covers one or two)
+                        Q16 v0, v1;
+                        __builtin_memcpy(&v0, qbase + (qo + (u0 << 4)), 16);
+                        const uint32_t ub = u0 + 1u <= u1 ? u0 + 1u : u0;
+                        __builtin_memcpy(&v1, qbase + (qo + (ub << 4)), 16);
+                        unit(v0, u0);
+                        if (u0 + 1u <= u1) unit(v1, u0 + 1u);
+                        for (uint32_t u = u0 + 2u; u <= u1; ++u) {
+                            Q16 v;
+                            __builtin_memcpy(&v, qbase + (qo + (u << 4)), 16);
+                            unit(v, u);
                         }
                     }
                     const unsigned long long bm = __ballot(big);

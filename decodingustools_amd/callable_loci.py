@@ -116,6 +116,9 @@ class Engine:
         ref = np.ascontiguousarray(ref, dtype=np.uint8) if ref is not None else np.zeros(0, np.uint8)
         self._check(self._lib.cl_contig_begin(self._h, tid, contig_len, _ptr(ref), ref.shape[0]))
 
+    def contig_reserve(self, n_reads, n_cigar_ops, n_qual_bytes):
+        self._check(self._lib.cl_contig_reserve(self._h, n_reads, n_cigar_ops, n_qual_bytes))
+
     def push_reads(self, pos, mapq, cigar_off, cigar, qual_off, qual):
         t = _lib.cl_read_tile()
         arrs = [np.ascontiguousarray(pos, np.int32), np.ascontiguousarray(mapq, np.uint8),

@@ -554,3 +554,42 @@ def test_outlier_spans_do_not_widen_every_window(tmp_path):
     reads.sort(key=lambda r: r[0])
     rec = ContigRecords.from_reads(reads)
     compare([("chrW", 5, L, ref, rec)], dict(min_depth=2, min_depth_for_low_mapq=3), tmp_path, "wide")
+
+
+@pytest.mark.parametrize("reserve", [False, True])
+def test_tiles_of_mixed_sizes_small_staged_large_direct(reserve):
+    """cl_push_reads copies small tiles to host staging and sends the quality bytes of tiles of >= 4 MiB
+    straight to the device; any mix of the two, in any order, must give the one-tile result."""
+    L = 900_000
+    rec = synth.short_read_contig(L, 30, 91)
+    ref = synth.make_reference(L, 92)
+    opt = CallableOptions()
+    acc, _ = admit_reads(opt, 0, L, rec)
+    idx = np.flatnonzero(acc)
+    keep = rec.slice(0, rec.n)
+    # one tile of everything accepted = the reference result
+    def tile(sel):
+        lens_c = (rec.cigar_off[sel + 1] - rec.cigar_off[sel]).astype(np.int64)
+        lens_q = (rec.qual_off[sel + 1] - rec.qual_off[sel]).astype(np.int64)
+        take_c = np.repeat(rec.cigar_off[sel].astype(np.int64), lens_c) + (np.arange(lens_c.sum()) - np.repeat(np.cumsum(lens_c) - lens_c, lens_c))
+        take_q = np.repeat(rec.qual_off[sel].astype(np.int64), lens_q) + (np.arange(lens_q.sum()) - np.repeat(np.cumsum(lens_q) - lens_q, lens_q))
+        return (rec.pos[sel], rec.mapq[sel], np.concatenate([[0], np.cumsum(lens_c)]).astype(np.uint32), rec.cigar[take_c],
+                np.concatenate([[0], np.cumsum(lens_q)]).astype(np.uint64), rec.qual[take_q])
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref)
+        eng.push_reads(*tile(idx))
+        want = eng.contig_finish()
+    sizes = [100, 40_000, 50, 30_000, 10_000, 1, 45_000]          # reads per tile: 6 MB and 4.5 MB tiles go direct
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref)
+        if reserve:
+            eng.contig_reserve(len(idx), int((rec.cigar_off[idx + 1] - rec.cigar_off[idx]).sum()), int((rec.qual_off[idx + 1] - rec.qual_off[idx]).sum()))
+        a = 0
+        k = 0
+        while a < len(idx):
+            b = min(len(idx), a + sizes[k % len(sizes)]); k += 1
+            eng.push_reads(*tile(idx[a:b]))
+            a = b
+        got = eng.contig_finish()
+    assert k > 7 and got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
+    assert want.summary.n_intervals > 1000

@@ -41,7 +41,7 @@ def build(force=False, verbose=False):
         raise RuntimeError("hipcc not found: cannot build libcallable_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + SOURCES + ["-lz", "-o", LIB + ".tmp"]
+           "-Wall", "-Wno-unused-function"] + SOURCES + ["-lz", "-ldl", "-o", LIB + ".tmp"]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)

@@ -5,6 +5,7 @@
 #include "../../include/dut_report.h"
 #include "host_parallel.h"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -117,6 +118,9 @@ struct Bgzf {
 
 struct RefSeq { std::string name; uint32_t len; };
 
+inline double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+inline bool timing_on() { static const bool on = getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1'; return on; }
+
 // grow-only buffer without value initialisation (the decoded arrays are written exactly once)
 template <class T>
 struct RawBuf {
@@ -137,6 +141,34 @@ struct RawBuf {
 
 using dut::parallel_for;
 
+// libdeflate (what htslib itself prefers for BGZF) when the shared library is on the machine: about twice
+// zlib's inflate speed and a carry-less-multiply CRC-32.  Bound at run time; zlib otherwise or with
+// DUT_INFLATE=zlib.  Prototypes as published in libdeflate.h (1.x).
+struct LibDeflate {
+    void *(*alloc)() = nullptr;
+    int (*decompress)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+    void (*release)(void *) = nullptr;
+    uint32_t (*crc)(uint32_t, const void *, size_t) = nullptr;
+    bool ok = false;
+};
+const LibDeflate &libdeflate()
+{
+    static const LibDeflate ld = [] {
+        LibDeflate l;
+        const char *e = getenv("DUT_INFLATE");
+        if (e && strcmp(e, "zlib") == 0) return l;
+        void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return l;
+        l.alloc = (void *(*)())dlsym(h, "libdeflate_alloc_decompressor");
+        l.decompress = (int (*)(void *, const void *, size_t, void *, size_t, size_t *))dlsym(h, "libdeflate_deflate_decompress");
+        l.release = (void (*)(void *))dlsym(h, "libdeflate_free_decompressor");
+        l.crc = (uint32_t (*)(uint32_t, const void *, size_t))dlsym(h, "libdeflate_crc32");
+        l.ok = l.alloc && l.decompress && l.release && l.crc;
+        return l;
+    }();
+    return ld;
+}
+
 // BGZF blocks inflated a batch at a time, the blocks of a batch in parallel (each block is an
 // independent deflate stream), into one contiguous buffer the record parser walks.
 struct BlockStream {
@@ -149,6 +181,7 @@ struct BlockStream {
     size_t cur = 0;
     RawBuf<uint8_t> cbuf;
     size_t batch = 32u << 20;         // compressed bytes per fill
+    double t_read = 0, t_inflate = 0; // DUT_TIMING
 
     void reset(uint64_t voff)
     {
@@ -166,7 +199,9 @@ struct BlockStream {
         for (;;) {
             if (!cbuf.reserve(batch)) { err = "out of memory"; return false; }
             if (fseeko(fp, (off_t)next_coff, SEEK_SET) != 0) { err = "seek failed"; return false; }
+            const double tr0 = tnow();
             got = fread(cbuf.p, 1, batch, fp);
+            t_read += tnow() - tr0;
             if (got == 0) { eof = true; return false; }
             blks.clear(); used = 0; out_total = 0;
             while (used + 18 <= got) {
@@ -204,7 +239,23 @@ struct BlockStream {
         uint8_t *op = buf.p + base;
         // one z_stream per contiguous group of blocks
         const size_t grain = 16;
+        const LibDeflate &ld = libdeflate();
+        const double ti0 = tnow();
         parallel_for((blks.size() + grain - 1) / grain, 1, [&](size_t g) {
+            if (ld.ok) {
+                void *dec = ld.alloc();
+                if (!dec) { bad = 1; return; }
+                const size_t e = std::min(blks.size(), (g + 1) * grain);
+                for (size_t i = g * grain; i < e; ++i) {
+                    const Blk &b = blks[i];
+                    if (!b.isize) continue;
+                    size_t got_out = 0;
+                    if (ld.decompress(dec, cp + b.in, b.clen, op + b.out, b.isize, &got_out) != 0 || got_out != b.isize) { bad = 2; break; }
+                    if (ld.crc(0u, op + b.out, b.isize) != b.crc) { bad = 3; break; }
+                }
+                ld.release(dec);
+                return;
+            }
             z_stream zs;
             memset(&zs, 0, sizeof(zs));
             if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
@@ -221,6 +272,7 @@ struct BlockStream {
             }
             inflateEnd(&zs);
         });
+        t_inflate += tnow() - ti0;
         if (bad) { err = bad == 3 ? "BGZF CRC mismatch" : "inflate failed"; return false; }
         if (skip) {
             if (skip > buf.n - base) { err = "virtual offset beyond its block"; return false; }
@@ -368,6 +420,8 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
     } else if (!st.valid || tid <= b->last_tid_done) st.reset(b->data_start);   // forward-only: rewind for an earlier contig
 
     uint64_t n = 0, n_cig = 0, n_qual = 0, n_name = 0, n_bases = 0;
+    double t_scan = 0, t_parse = 0;
+    st.t_read = st.t_inflate = 0;
     struct RecInfo { size_t off; uint32_t n_cigar, l_seq, l_name; size_t cig_off; uint64_t d_cig, d_qual, d_name, d_base; };
     std::vector<RecInfo> recs;
     bool end = nothing;
@@ -380,6 +434,7 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
         }
         need_fill = true;
         // -- pass 1: record boundaries of this window, destination offsets --
+        const double ts0 = tnow();
         recs.clear();
         const uint8_t *buf = st.buf.p;
         const size_t size = st.buf.n;
@@ -389,6 +444,10 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
             const uint32_t bs = rd32(buf + o);
             if (bs < 32 || bs > (1u << 29)) { b->err = "bad BAM block_size"; return CL_ERR_INVALID; }
             if (o + 4 + (size_t)bs > size) break;                         // needs the next batch
+            // the chain of block_size fields is a dependent walk with one cache miss per record: most
+            // records have their predecessor's size, so the headers a few records ahead are prefetched
+            __builtin_prefetch(buf + o + 6 * (4 + (size_t)bs));
+            __builtin_prefetch(buf + o + 12 * (4 + (size_t)bs));
             const uint8_t *r = buf + o + 4;
             const int32_t ref_id = (int32_t)rd32(r);
             if (ref_id < 0 || ref_id > tid) { end = true; break; }        // sorted: past this contig (the record stays in the stream)
@@ -425,6 +484,8 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
             }
             o += 4 + (size_t)bs;
         }
+        t_scan += tnow() - ts0;
+        const double tp0 = tnow();
         // -- pass 2: fill the arrays, records in parallel --
         const size_t seq_bytes_old = b->seq4.n, seq_bytes_new = want_seq ? (size_t)((n_bases + 1) / 2) : 0;
         if (!b->pos.reserve(n) || !b->flag.reserve(n) || !b->mapq.reserve(n) || !b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) ||
@@ -467,11 +528,15 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
         b->pos.n = b->flag.n = b->mapq.n = n;
         b->cigar.n = n_cig; b->qual.n = n_qual; b->qname.n = n_name;
         st.cur = o;
+        t_parse += tnow() - tp0;
     }
     if (!b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) || !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) ||
         !b->pos.reserve(1) || !b->flag.reserve(1) || !b->mapq.reserve(1) || !b->cigar.reserve(1) || !b->qual.reserve(1) || !b->qname.reserve(1) ||
         !b->seq4.reserve(1)) { b->err = "out of memory"; return CL_ERR_INVALID; }
     b->cigar_off.p[n] = (uint32_t)n_cig; b->qual_off.p[n] = n_qual; b->qname_off.p[n] = (uint32_t)n_name; b->seq_off.p[n] = n_bases;
+    if (timing_on())
+        fprintf(stderr, "[dut-timing]   read %.0f ms, inflate %.0f ms (%s, %d threads), scan %.0f ms, parse %.0f ms\n", st.t_read * 1e3,
+                st.t_inflate * 1e3, libdeflate().ok ? "libdeflate" : "zlib", dut::worker_threads(), t_scan * 1e3, t_parse * 1e3);
     b->last_tid_done = tid;
     out->n = n;
     out->pos = b->pos.p; out->flag = b->flag.p; out->mapq = b->mapq.p;

@@ -190,7 +190,25 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
     // list holds exactly the appended reads with end >= s (reads that ended earlier were freed
     // while the columns before s were produced; a read ending AT s is freed only when column s
     // itself is walked).
-    std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> live;
+    // `live`: the ends, kept ascending in a ring (reads arrive in start order and their ends are nearly
+    // sorted, so a new end is placed by a short insertion from the back; expired ends leave at the front).
+    std::vector<uint64_t> ring(1024);
+    size_t head = 0, cnt = 0;                                  // ring[(head + i) & mask], i < cnt, ascending
+    auto live_push = [&](uint64_t e) {
+        if (cnt == ring.size()) {                              // grow, unrolled to index 0
+            std::vector<uint64_t> nr(ring.size() * 2);
+            for (size_t i = 0; i < cnt; ++i) nr[i] = ring[(head + i) & (ring.size() - 1)];
+            ring.swap(nr); head = 0;
+        }
+        const size_t mask = ring.size() - 1;
+        size_t i = cnt;
+        while (i > 0 && ring[(head + i - 1) & mask] > e) { ring[(head + i) & mask] = ring[(head + i - 1) & mask]; --i; }
+        ring[(head + i) & mask] = e;
+        ++cnt;
+    };
+    // reference spans of all reads up front, in parallel (the sequential rule below only compares numbers)
+    std::vector<uint64_t> rlen(rec->n);
+    dut::parallel_for(rec->n, 65536, [&](size_t i) { rlen[i] = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]); });
     bool any_pushed = false;
     int64_t cur_start = -1;
     uint64_t nacc = 0;
@@ -199,7 +217,7 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
         const int64_t p = rec->pos[i];
         if (p >= (int64_t)contig_len) continue;              // not yielded by fetch((tid,0,len))
         if (rec->flag[i] & 0x4) continue;                    // BAM_FUNMAP: bam_plp_push skips it
-        const uint64_t rl = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]);
+        const uint64_t rl = rlen[i];
         const uint64_t end = (uint64_t)p + rl;
         bool appended;
         if (!any_pushed) {
@@ -208,16 +226,17 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
             any_pushed = true; cur_start = p;
         } else if (p == cur_start) {
             // not the first read at this start: the cursor sits here, the cap applies
-            if (live.size() >= maxcnt) continue;
+            if (cnt >= maxcnt) continue;
             appended = end > (uint64_t)p;
         } else {
             if (p < cur_start) return CL_ERR_UNSORTED;
             cur_start = p;
-            while (!live.empty() && live.top() < (uint64_t)p) live.pop();
+            const size_t mask = ring.size() - 1;
+            while (cnt && ring[head & mask] < (uint64_t)p) { head = (head + 1) & mask; --cnt; }
             appended = true;                                  // cursor still on the previous start
         }
         if (!appended) continue;
-        live.push(end);
+        live_push(end);
         if (rl > 0) { accepted[i] = 1; ++nacc; }
     }
     if (n_accepted) *n_accepted = nacc;

@@ -1,5 +1,6 @@
 """CPU tests of the native BGZF/BAM/BAI and FASTA/FAI reader against files written by the
 independent pure-Python writer in tests/bamio.py."""
+import os
 import numpy as np
 import pytest
 
@@ -169,3 +170,26 @@ def test_corrupted_files_fail_cleanly(tmp_path):
         w = _BgzfWriter(bad); w.write(bytes(d)); w.close()
         n_err += not try_read(t % 2 == 1)
     assert 0 < n_err < 60
+
+
+def test_zlib_and_libdeflate_inflate_agree(tmp_path):
+    """The reader binds libdeflate at run time when the machine has it and uses zlib otherwise
+    (DUT_INFLATE=zlib forces that): both must decode the same records."""
+    import subprocess
+    import sys
+    L = 50_000
+    rec = synth.short_read_contig(L, 25, 9, with_seq=True, ref=synth.make_reference(L, 10))
+    bam = str(tmp_path / "z.bam")
+    write_bam(bam, [("a", L)], {0: rec}, block_every=300)
+    code = ("import sys, hashlib; sys.path.insert(0, %r); from decodingustools_amd.bam import BamReader\n"
+            "x = BamReader(%r).fetch_contig(0, with_seq=True)\n"
+            "h = hashlib.sha256()\n"
+            "[h.update(getattr(x, f).tobytes()) for f in ('pos','flag','mapq','cigar_off','cigar','qual_off','qual','qname_off','qname','seq_off','seq4')]\n"
+            "print(x.n, h.hexdigest())\n") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), bam)
+    outs = []
+    for mode in ("", "zlib"):
+        env = dict(os.environ, DUT_INFLATE=mode, DUT_THREADS="3")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append(r.stdout.strip())
+    assert outs[0] == outs[1] and outs[0].split()[0] == str(rec.n)

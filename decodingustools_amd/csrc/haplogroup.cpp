@@ -448,13 +448,6 @@ bool find_path(const Haplogroup &h, const std::string &target, std::vector<const
     return false;
 }
 
-const Haplogroup *find_haplogroup(const Haplogroup &h, const std::string &name)
-{
-    if (h.name == name) return &h;
-    for (const Haplogroup &c : h.children) if (const Haplogroup *f = find_haplogroup(c, name)) return f;
-    return nullptr;
-}
-
 void collect_sites(const Haplogroup &h, const std::string &build, const std::string &ref_name, std::map<uint32_t, bool> &out)
 {
     for (const Locus &l : *h.loci)
@@ -618,6 +611,17 @@ int dut_write_haplogroup_report(const char *path, const dut_tree *t, const dut_h
     std::unordered_map<uint32_t, const dut_snp_call *> cm;
     for (size_t i = 0; i < n_calls; ++i) cm[calls[i].position] = &calls[i];
     const std::string build(build_id);
+    // find_haplogroup (mod.rs:183-194) returns the first node of that name in pre-order: one traversal
+    // builds the same mapping for all rows
+    std::unordered_map<std::string, const Haplogroup *> by_name;
+    if (show_snps) {
+        std::vector<const Haplogroup *> stack{&t->root};
+        while (!stack.empty()) {
+            const Haplogroup *h = stack.back(); stack.pop_back();
+            by_name.emplace(h->name, h);                      // keeps the first (pre-order) occurrence
+            for (size_t i = h->children.size(); i-- > 0;) stack.push_back(&h->children[i]);
+        }
+    }
     std::string s = "Haplogroup\tScore\tMatching_SNPs\tMismatching_SNPs\tAncestral_Matches\tNo_Calls\tTotal_SNPs\tCumulative_SNPs\tDepth";
     if (show_snps) s += "\tMatching_SNP_Details\tMismatching_SNP_Details\tNo_Call_Details";
     s += "\n";
@@ -629,7 +633,8 @@ int dut_write_haplogroup_report(const char *path, const dut_tree *t, const dut_h
         s += r.name; s += b;
         if (show_snps) {                                            // get_snp_details, mod.rs:143-181
             std::string m, mm, nc;
-            if (const Haplogroup *h = find_haplogroup(t->root, r.name)) {
+            const auto hit = by_name.find(r.name);
+            if (const Haplogroup *h = hit == by_name.end() ? nullptr : hit->second) {
                 for (const Locus &l : *h->loci) {
                     const Coord *c = l.get(build);
                     if (!c) continue;

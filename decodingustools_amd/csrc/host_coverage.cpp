@@ -6,6 +6,7 @@
 #include "host_parallel.h"
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -13,6 +14,7 @@
 #include <functional>
 #include <queue>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 namespace {
@@ -99,7 +101,7 @@ struct dut_profiler {
     std::string cur_contig;
     uint64_t cur_start = 0, cur_end = 0;
     uint32_t cur_state = 0;
-    std::vector<std::pair<std::string, std::vector<uint64_t>>> counts;
+    std::unordered_map<std::string, std::array<uint64_t, 6>> counts;    // contig_counts, callable_profiler.rs:13
 
     void write_state()                       // callable_profiler.rs:39-62
     {
@@ -135,8 +137,8 @@ void dut_profiler_contig_counts(const dut_profiler *p, const char *contig, uint6
 {
     for (int i = 0; i < 6; ++i) out[i] = 0;
     if (!p || !contig) return;
-    for (const auto &e : p->counts)
-        if (e.first == contig) { for (int i = 0; i < 6; ++i) out[i] = e.second[i]; return; }
+    const auto it = p->counts.find(contig);
+    if (it != p->counts.end()) for (int i = 0; i < 6; ++i) out[i] = it->second[i];
 }
 
 int dut_profiler_feed_contig(dut_profiler *p, const char *contig, const cl_interval *iv, size_t n_iv,
@@ -145,10 +147,8 @@ int dut_profiler_feed_contig(dut_profiler *p, const char *contig, const cl_inter
     if (!p || !contig || (!iv && n_iv)) return CL_ERR_INVALID;
     // contig_counts[contig][state] += 1 per position (:124-126): the device counted them
     if (n_iv) {
-        std::vector<uint64_t> *slot = nullptr;
-        for (auto &e : p->counts) if (e.first == contig) slot = &e.second;
-        if (!slot) { p->counts.emplace_back(contig, std::vector<uint64_t>(6, 0)); slot = &p->counts.back().second; }
-        for (int i = 0; i < 6; ++i) (*slot)[i] += state_counts ? state_counts[i] : 0;
+        std::array<uint64_t, 6> &slot = p->counts[contig];      // value-initialised to zeros on first use
+        for (int i = 0; i < 6; ++i) slot[i] += state_counts ? state_counts[i] : 0;
     }
     for (size_t i = 0; i < n_iv; ++i) {
         const uint64_t start = iv[i].start, end = iv[i].end;

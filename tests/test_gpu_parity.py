@@ -593,3 +593,38 @@ def test_tiles_of_mixed_sizes_small_staged_large_direct(reserve):
         got = eng.contig_finish()
     assert k > 7 and got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
     assert want.summary.n_intervals > 1000
+
+
+def _stacked_multi_op_reads(n, start_lo, start_hi, seed, long_every=0):
+    """n reads with >= 9 CIGAR operations each (the operation-parallel kernel variant is chosen at >= 8
+    operations per read on average), stacked on a short stretch so that a window sees many of them."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i, p in enumerate(np.sort(rng.integers(start_lo, start_hi, size=n))):
+        k = int(rng.integers(4, 7))
+        ops = []
+        for j in range(k):
+            ops.append(f"{int(rng.integers(8, 40))}{rng.choice(['M', 'M', '=', 'X'])}")
+            ops.append(f"{int(rng.integers(1, 4))}{rng.choice(['I', 'D', 'D', 'N'])}")
+        ops.append(f"{int(rng.integers(10, 30))}M")
+        if long_every and i % long_every == 0:
+            ops.append("3D"); ops.append("150M")                       # a run longer than 64 bases: list + quad loop
+        if i % 5 == 0:
+            ops = [f"{int(rng.integers(1, 9))}S"] + ops
+        reads.append((int(p), "".join(ops), int(rng.choice([0, 1, 20, 60, 60])), int(rng.choice([5, 20, 21, 38])), 0, f"s{i}"))
+    return ContigRecords.from_reads(reads)
+
+
+def test_operation_parallel_variant_with_16bit_and_32bit_counters(tmp_path):
+    """The long-read shaped kernel variant on windows with more than 510 candidates (16-bit counter
+    fields) and with more than 32 767 (32-bit re-run)."""
+    L = 12_000
+    ref = synth.make_reference(L, 41)
+    rec = _stacked_multi_op_reads(2500, 3000, 5000, 42, long_every=7)
+    assert rec.cigar.shape[0] >= 8 * rec.n
+    o, _ = compare([("m16", 0, L, ref, rec)], dict(max_depth=100_000, min_depth_for_low_mapq=10), tmp_path, "long16")
+    assert o["m16"]["dumps"][0].max() > 200
+    rec = _stacked_multi_op_reads(34_000, 3000, 4500, 43, long_every=11)
+    assert rec.cigar.shape[0] >= 8 * rec.n
+    o, _ = compare([("m32", 0, L, ref, rec)], dict(max_depth=1_000_000, min_depth_for_low_mapq=10), tmp_path, "long32")
+    assert o["m32"]["dumps"][0].max() > 3_000

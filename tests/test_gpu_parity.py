@@ -624,6 +624,9 @@ def test_operation_parallel_variant_with_16bit_and_32bit_counters(tmp_path):
     assert rec.cigar.shape[0] >= 8 * rec.n
     o, _ = compare([("m16", 0, L, ref, rec)], dict(max_depth=100_000, min_depth_for_low_mapq=10), tmp_path, "long16")
     assert o["m16"]["dumps"][0].max() > 200
+    # the AND form of the byte-parallel quality test (thresholds above 128) in this variant
+    compare([("m16q", 0, L, ref, rec)], dict(max_depth=100_000, min_base_quality=200, min_depth=1), tmp_path, "long16q")
+    compare([("m8", 0, L, ref, rec.slice(0, 300))], dict(max_depth=100_000, min_base_quality=21, min_depth=1), tmp_path, "long8")
     rec = _stacked_multi_op_reads(34_000, 3000, 4500, 43, long_every=11)
     assert rec.cigar.shape[0] >= 8 * rec.n
     o, _ = compare([("m32", 0, L, ref, rec)], dict(max_depth=1_000_000, min_depth_for_low_mapq=10), tmp_path, "long32")

@@ -152,23 +152,13 @@ def test_known_answer_report():
     C: derived 0, ancestral 1 -> a > d*3 -> 0.0 -> filtered (and ancestral 1 > 0*10 triggers the early return, score 0 as well).
     X: the call has depth 3 < 4 -> no_call, score 0 -> filtered.
     Order: top = B (cumulative 5); its path to the root is B, A, R -> B then A."""
-    def node(i, name, parent, variants, children):
-        d = {"haplogroupId": i, "name": name, "isRoot": parent == 0, "root": "R", "kitsCount": 0, "subBranches": 0, "bigYCount": 0,
-             "variants": [{"variant": v, "position": p, "ancestral": a, "derived": dd} for v, p, a, dd in variants], "children": children}
-        if parent: d["parentId"] = parent
-        return d
-    tree = {"allNodes": {"1": node(1, "R", 0, [], [2, 5]), "2": node(2, "A", 1, [("a1", 100, "A", "G"), ("a2", 110, "C", "T")], [3]),
-                         "3": node(3, "B", 2, [("b1", 200, "G", "A"), ("b2", 210, "T", "C"), ("b3", 220, "A", "C")], [4]),
-                         "4": node(4, "C", 3, [("c1", 300, "C", "G")], []), "5": node(5, "X", 1, [("x1", 400, "G", "T")], [])}}
-    calls = [H.SnpCall(100, "G", 20, 1.0), H.SnpCall(110, "T", 18, 0.9), H.SnpCall(200, "A", 25, 0.8), H.SnpCall(210, "T", 25, 1.0),
-             H.SnpCall(300, "C", 30, 1.0), H.SnpCall(400, "T", 3, 1.0)]
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "haplogroup_kat.json")))
+    tree = kat["tree"]
+    calls = [H.SnpCall(p, b, d, f) for p, b, d, f in kat["calls"]]
     t = H.HaplogroupTree(json.dumps(tree))
-    t.write_report("/tmp/_hap_kat.tsv", calls, "GRCh38", True)
-    assert open("/tmp/_hap_kat.tsv").read() == (
-        "Haplogroup\tScore\tMatching_SNPs\tMismatching_SNPs\tAncestral_Matches\tNo_Calls\tTotal_SNPs\tCumulative_SNPs\tDepth\t"
-        "Matching_SNP_Details\tMismatching_SNP_Details\tNo_Call_Details\n"
-        "B\t1.6500\t1\t0\t1\t1\t2\t5\t1\tb1:200\tb2:210\tb3:220\n"
-        "A\t3.3880\t2\t0\t0\t0\t0\t2\t0\ta1:100;a2:110\t\t\n")
+    t.write_report("/tmp/_hap_kat.tsv", calls, kat["build_id"], kat["show_snps"])
+    assert open("/tmp/_hap_kat.tsv").read() == kat["expected_tsv"]
     text, _ = O.report_text(O.load_tree(json.dumps(tree), "ftdna")[1], {c.position: (c.base, c.depth, c.freq) for c in calls}, "GRCh38", True)
     assert text == open("/tmp/_hap_kat.tsv").read()
 

@@ -2,6 +2,7 @@
 reference-build detection, serde_json-style f64 text and the CoverageOutput JSON (SURVEY.md 8f-2,
 8f-4).  Host-only: runs without a GPU."""
 import json
+import os
 import random
 import struct
 
@@ -334,53 +335,4 @@ def test_coverage_output_json_text():
     # a fixed small document, written out by hand from the structs (coverage.rs:26-45,113-248; api/coverage.rs:134-145)
     s = dict(length=20, n_covered_bases=12, summed_coverage=22, summed_baseq=420, summed_mapq=960, quality_bases=14, n_reads=3)   # KAT-1
     got = R.coverage_output_json([_as_obj(s)], ["chrT"], [[2, 2, 8, 6, 0, 2]], "Unknown", "Unknown", "Unknown", 8, "callable_regions.bed", "summary.html")
-    assert got == """{
-  "export": {
-    "summary": {
-      "aligner": "Unknown",
-      "reference_build": "Unknown",
-      "sequencing_platform": "Unknown",
-      "read_length": 8,
-      "total_bases": 20,
-      "callable_bases": 2,
-      "callable_percentage": 10.0,
-      "average_depth": 1.8333333333333333,
-      "contigs_analyzed": 1
-    },
-    "contigs": [
-      {
-        "name": "chrT",
-        "length": 20,
-        "unique_reads": 3,
-        "coverage_percent": 60.0,
-        "average_depth": 1.8333333333333333,
-        "covered_bases": 12,
-        "total_bases": 20,
-        "quality_stats": {
-          "average_mapq": 68.57142857142857,
-          "average_baseq": 30.0,
-          "q30_percentage": 100.0
-        },
-        "state_distribution": {
-          "ref_n": 2,
-          "callable": 2,
-          "no_coverage": 8,
-          "low_coverage": 6,
-          "excessive_coverage": 0,
-          "poor_mapping_quality": 2
-        }
-      }
-    ],
-    "quality_metrics": {
-      "average_mapq": 68.57142857142857,
-      "average_baseq": 30.0,
-      "q30_percentage": 100.0
-    },
-    "total_unique_reads": 3
-  },
-  "files": {
-    "bed_file": "callable_regions.bed",
-    "summary_html": "summary.html",
-    "coverage_plots": []
-  }
-}"""
+    assert got == open(os.path.join(os.path.dirname(__file__), "golden", "summary_kat1.json")).read()

@@ -125,6 +125,10 @@ SYMBOLS = [
     ("dut_process_single_contig", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(dut_contig_stats),
                                             C.POINTER(cl_options), C.c_char_p, C.c_int32, C.c_uint32,
                                             C.c_void_p, C.c_uint64, C.POINTER(dut_records)]),
+    ("dut_process_single_contig_runs", C.c_int, [C.c_void_p, C.POINTER(dut_contig_stats), C.POINTER(cl_options), C.c_int32,
+                                                 C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(dut_records),
+                                                 C.POINTER(C.c_uint64), C.POINTER(C.POINTER(cl_interval)),
+                                                 C.POINTER(C.c_size_t)]),
     ("dut_contig_derive", None, [C.POINTER(dut_contig_stats), C.POINTER(dut_contig_derived)]),
     ("dut_compare_contig_names", C.c_int, [C.c_char_p, C.c_char_p]),
     ("dut_genome_summary_build", None, [C.POINTER(dut_contig_stats), C.POINTER(C.c_uint64), C.c_size_t,
@@ -138,6 +142,7 @@ SYMBOLS = [
     ("dut_bam_ref_len", C.c_uint32, [C.c_void_p, C.c_int]),
     ("dut_bam_header_text", C.c_void_p, [C.c_void_p, C.POINTER(C.c_size_t)]),
     ("dut_bam_has_index", C.c_int, [C.c_void_p]),
+    ("dut_bam_ref_mapped", C.c_int64, [C.c_void_p, C.c_int]),
     ("dut_bam_read_contig", C.c_int, [C.c_void_p, C.c_int, C.POINTER(dut_records), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p)]),
     ("dut_fasta_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),

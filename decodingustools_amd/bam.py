@@ -33,6 +33,8 @@ class BamReader:
         p = self._lib.dut_bam_header_text(self._h, C.byref(ln))
         self.header_text = C.string_at(p, ln.value).decode(errors="replace") if ln.value else ""
         self.has_index = bool(self._lib.dut_bam_has_index(self._h))
+        # mapped reads per reference from the .bai metadata (-1 = not recorded): the balancing weight
+        self.target_mapped = [int(self._lib.dut_bam_ref_mapped(self._h, t)) for t in range(n)]
 
     def fetch_contig(self, tid: int, with_seq: bool = False) -> ContigRecords:
         r = _lib.dut_records()

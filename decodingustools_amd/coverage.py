@@ -31,8 +31,9 @@ class ApiError(RuntimeError):
 class ContigInput:
     name: str
     length: int
-    records: ContigRecords
+    records: Optional[ContigRecords]       # None for contigs that are read from a file when they are processed
     ref: Optional[np.ndarray] = None       # FASTA bytes of the contig, case preserved
+    weight: Optional[int] = None           # balancing weight; default: aligned bases + length
 
 
 @dataclass
@@ -212,7 +213,8 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
     stats = initialize_contig_stats(inp)
     validate_contig_selection(stats, inp)
     tids = sorted(stats)
-    weights = [int(inp.contigs[t].records.qual.shape[0]) + inp.contigs[t].length for t in tids]
+    weights = [inp.contigs[t].weight if inp.contigs[t].weight is not None
+               else int(inp.contigs[t].records.qual.shape[0]) + inp.contigs[t].length for t in tids]
     rank_of = lpt_assignment(weights, world)
     mine = [t for t, r in zip(tids, rank_of) if r == rank]
     local = {t: process_contig(t, inp.contigs[t]) for t in mine}
@@ -266,4 +268,66 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
                             n_reads=int(row[11]))
         outcomes.append(ContigOutcome(tid=t, stats=st, state_counts=[int(x) for x in row[:6]], intervals=iv))
     write_bed(outcomes, inp.output_bed)
-    return CoverageOutput(export=build_coverage_export(outcomes), bed_file=inp.output_bed)
+    out = CoverageOutput(export=build_coverage_export(outcomes), bed_file=inp.output_bed)
+    out.outcomes = outcomes
+    return out
+
+
+def engine_process_contig_runs(engine: Engine, options: CallableOptions, tid: int, name: str, length: int,
+                               rec: ContigRecords, ref: Optional[np.ndarray]) -> ContigOutcome:
+    """process_single_contig through the C driver (admission, one zero-copy tile, kernels), returning
+    the runs instead of writing them."""
+    import ctypes as C
+    from . import _lib
+    from .callable_loci import EngineError, _ptr, _records_c
+    lib = _lib.load()
+    ref = np.ascontiguousarray(ref, np.uint8) if ref is not None else np.zeros(0, np.uint8)
+    st = ContigProfiler(name, length)
+    oc = options.to_c(); rc = _records_c(rec); cs = st._c()
+    counts = (C.c_uint64 * 6)(); iv = C.POINTER(_lib.cl_interval)(); n = C.c_size_t()
+    status = lib.dut_process_single_contig_runs(engine._h, C.byref(cs), C.byref(oc), tid, length, _ptr(ref), ref.shape[0],
+                                                C.byref(rc), counts, C.byref(iv), C.byref(n))
+    if status != 0:
+        raise EngineError(status, lib.cl_last_error(engine._h).decode() or "admission failed")
+    st._load(cs)
+    runs = (np.ctypeslib.as_array(C.cast(iv, C.POINTER(C.c_uint32)), shape=(n.value, 3)).copy() if n.value
+            else np.zeros((0, 3), np.uint32))
+    return ContigOutcome(tid=tid, stats=st, state_counts=[int(x) for x in counts], intervals=runs)
+
+
+def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, summary_json: Optional[str],
+                           options: CallableOptions, contigs: Optional[List[str]], rank: int, world: int,
+                           device_id: int, coll_device="cpu", group=None, output_summary: str = "summary.html"):
+    """`coverage` on files over `world` processes, one GPU each (torch.distributed already initialised
+    when world > 1): every rank opens the BAM / FASTA itself and decodes only the contigs it is dealt
+    (LPT on the index's mapped-read counts, else on contig length); rank 0 writes the BED in tid order
+    and the summary.json of main.rs:68-69.  Returns the CoverageOutput on rank 0, None elsewhere."""
+    from .bam import BamReader, FastaReader
+    from .report import BamStats, coverage_output_json
+    bam = BamReader(bam_file)
+    fasta = FastaReader(reference_file)
+    try:
+        descr = []
+        for t, (nm, ln) in enumerate(zip(bam.target_names, bam.target_lens)):
+            w = bam.target_mapped[t]
+            descr.append(ContigInput(nm, ln, None, None, weight=(w * 160 + ln) if w >= 0 else ln))
+        inp = CoverageInput(contigs=descr, options=options, selected=contigs, output_bed=output_bed)
+        with Engine(options, device_id) as eng:
+            def run(tid, c):
+                rec = bam.fetch_contig(tid)
+                return engine_process_contig_runs(eng, options, tid, c.name, c.length, rec, fasta.fetch(c.name))
+            out = analyze_sharded(inp, rank, world, run, device=coll_device, group=group)
+        if rank != 0:
+            return None
+        if summary_json:
+            bs = BamStats(10000).collect_stats(bam_file)                       # api/coverage.rs:56-59
+            oc = out.outcomes
+            text = coverage_output_json([o.stats for o in oc], [o.stats.name for o in oc], [o.state_counts for o in oc],
+                                        bs.aligner(), bs.reference_build(), bs.infer_platform(), bs.average_read_length(),
+                                        output_bed, output_summary)
+            with open(summary_json, "w") as f:
+                f.write(text)
+        return out
+    finally:
+        bam.close()
+        fasta.close()

@@ -292,6 +292,7 @@ struct dut_bam {
     // .bai: smallest chunk start per reference
     bool has_index = false;
     std::vector<uint64_t> ref_start;         // UINT64_MAX = no records
+    std::vector<int64_t> ref_mapped;         // mapped reads per reference from the index metadata, -1 = not recorded
     // sequential state
     bool pending = false;                    // `rec` holds a record that was read but not consumed
     std::vector<uint8_t> rec;
@@ -336,6 +337,7 @@ bool load_bai(dut_bam *b)
     size_t o = 4;
     const uint32_t n_ref = rd32(&d[o]); o += 4;
     std::vector<uint64_t> start(n_ref, UINT64_MAX);
+    std::vector<int64_t> mapped(n_ref, -1);
     for (uint32_t r = 0; r < n_ref; ++r) {
         if (o + 4 > d.size()) return false;
         const uint32_t n_bin = rd32(&d[o]); o += 4;
@@ -345,6 +347,7 @@ bool load_bai(dut_bam *b)
             if (o + 16ull * n_chunk > d.size()) return false;
             if (bin != 37450)                                 // the metadata pseudo-bin
                 for (uint32_t c = 0; c < n_chunk; ++c) start[r] = std::min(start[r], rd64(&d[o + 16ull * c]));
+            else if (n_chunk >= 2) mapped[r] = (int64_t)rd64(&d[o + 16]);       // second pseudo-chunk: n_mapped, n_unmapped
             o += 16ull * n_chunk;
         }
         if (o + 4 > d.size()) return false;
@@ -354,6 +357,7 @@ bool load_bai(dut_bam *b)
     }
     if (n_ref != b->refs.size()) return false;
     b->ref_start.swap(start);
+    b->ref_mapped.swap(mapped);
     return true;
 }
 
@@ -402,6 +406,10 @@ const char *dut_bam_ref_name(const dut_bam *b, int tid) { return (b && tid >= 0 
 uint32_t dut_bam_ref_len(const dut_bam *b, int tid) { return (b && tid >= 0 && (size_t)tid < b->refs.size()) ? b->refs[tid].len : 0; }
 const char *dut_bam_header_text(const dut_bam *b, size_t *len) { if (len) *len = b ? b->text.size() : 0; return b ? b->text.data() : nullptr; }
 int dut_bam_has_index(const dut_bam *b) { return b && b->has_index ? 1 : 0; }
+int64_t dut_bam_ref_mapped(const dut_bam *b, int tid)
+{
+    return (b && b->has_index && tid >= 0 && (size_t)tid < b->ref_mapped.size()) ? b->ref_mapped[tid] : -1;
+}
 
 int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4)
 {

@@ -281,6 +281,20 @@ int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats 
                               uint64_t ref_len, const dut_records *rec)
 {
     if (!ctx || !prof || !stats || !opt || !contig_name || !rec) return CL_ERR_INVALID;
+    uint64_t counts[6]; const cl_interval *iv = nullptr; size_t niv = 0;
+    int rc = dut_process_single_contig_runs(ctx, stats, opt, tid, contig_len, ref, ref_len, rec, counts, &iv, &niv);
+    if (rc != CL_OK) return rc;
+    double tm = dut_now();
+    rc = dut_profiler_feed_contig(prof, contig_name, iv, niv, counts);
+    dut_stage_time("BED lines", tm);
+    return rc;
+}
+
+int dut_process_single_contig_runs(cl_ctx *ctx, dut_contig_stats *stats, const cl_options *opt, int32_t tid,
+                                   uint32_t contig_len, const uint8_t *ref, uint64_t ref_len, const dut_records *rec,
+                                   uint64_t state_counts[6], const cl_interval **intervals, size_t *n_intervals)
+{
+    if (!ctx || !stats || !opt || !rec || !state_counts || !intervals || !n_intervals) return CL_ERR_INVALID;
     double tm = dut_now();
     std::vector<uint8_t> acc(rec->n ? rec->n : 1);
     uint32_t n_names = 0; uint64_t n_acc = 0;
@@ -346,9 +360,8 @@ int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats 
     rc = cl_contig_finish(ctx, &sum, &iv, &niv);
     if (rc != CL_OK) return rc;
     dut_stage_time("upload + kernels + collect", tm);
-    rc = dut_profiler_feed_contig(prof, contig_name, iv, niv, sum.state_counts);
-    if (rc != CL_OK) return rc;
-    dut_stage_time("BED lines", tm);
+    for (int i = 0; i < 6; ++i) state_counts[i] = sum.state_counts[i];
+    *intervals = iv; *n_intervals = niv;
     stats->length = contig_len;
     stats->n_covered_bases = sum.n_covered_bases;
     stats->summed_coverage = sum.summed_coverage;

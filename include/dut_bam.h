@@ -32,6 +32,9 @@ const char *dut_bam_ref_name(const dut_bam *b, int tid);      /* header.tid2name
 uint32_t dut_bam_ref_len(const dut_bam *b, int tid);          /* header.target_len */
 const char *dut_bam_header_text(const dut_bam *b, size_t *len);
 int dut_bam_has_index(const dut_bam *b);
+/* Mapped reads of a reference as the .bai metadata pseudo-bin records them (samtools idxstats), -1 when
+ * there is no index or it carries no metadata.  Used to balance contigs over GPUs before decoding. */
+int64_t dut_bam_ref_mapped(const dut_bam *b, int tid);
 
 /* All records with refID == tid, file order, decoded into reader-owned SoA buffers that stay
  * valid until the next call on this reader.  seq_off (in bases) / seq4 (4-bit codes, two per

@@ -104,6 +104,14 @@ int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats 
                               uint32_t contig_len, const uint8_t *ref, uint64_t ref_len,
                               const dut_records *rec);
 
+/* The same without a BED writer: the contig's runs (context-owned, valid until the next contig of ctx)
+ * and state counts are handed back -- what a rank of a multi-GPU run sends to the rank that writes
+ * the BED (decodingustools_amd/coverage.py). */
+int dut_process_single_contig_runs(cl_ctx *ctx, dut_contig_stats *stats, const cl_options *opt, int32_t tid,
+                                   uint32_t contig_len, const uint8_t *ref, uint64_t ref_len,
+                                   const dut_records *rec, uint64_t state_counts[6],
+                                   const cl_interval **intervals, size_t *n_intervals);
+
 void dut_contig_derive(const dut_contig_stats *s, dut_contig_derived *out);
 int  dut_compare_contig_names(const char *a, const char *b);
 /* stats/callable for contigs already in dut_compare_contig_names order (report.rs:37-38) */

@@ -107,6 +107,11 @@ def write_bam(path, refs, per_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", w
             else: ch.append([v0, v1])
             for win in range(pos >> 14, ((end - 1) >> 14) + 1):
                 lin.setdefault(win, v0)
+        if rec.n:
+            # the metadata pseudo-bin (SAM spec 5.2): [begin, end) virtual offsets, then n_mapped, n_unmapped
+            n_unm = int(np.count_nonzero(rec.flag & 4))
+            first = min(c[0] for ch in bins.values() for c in ch); last = max(c[1] for ch in bins.values() for c in ch)
+            bins[37450] = [[first, last], [rec.n - n_unm, n_unm]]
         index[tid] = (bins, lin)
     for name, flag, l_seq, tl in unmapped_tail:
         nm = bytes(name) + b"\0"

@@ -193,3 +193,17 @@ def test_zlib_and_libdeflate_inflate_agree(tmp_path):
         assert r.returncode == 0, r.stderr
         outs.append(r.stdout.strip())
     assert outs[0] == outs[1] and outs[0].split()[0] == str(rec.n)
+
+
+def test_index_metadata_gives_mapped_read_counts(tmp_path):
+    refs, per = _dataset()
+    path = str(tmp_path / "m.bam")
+    write_bam(path, refs, per)
+    with BamReader(path) as r:
+        for tid in range(len(refs)):
+            want = int(np.count_nonzero((per[tid].flag & 4) == 0)) if tid in per and per[tid].n else -1
+            assert r.target_mapped[tid] == want
+    write_bam(path, refs, per, write_index=False)
+    os.remove(path + ".bai") if os.path.exists(path + ".bai") else None
+    with BamReader(path) as r:
+        assert r.target_mapped == [-1] * len(refs)

@@ -2,6 +2,7 @@
 the same inputs.  Integer / byte work: everything must be bit-exact."""
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -631,3 +632,41 @@ def test_operation_parallel_variant_with_16bit_and_32bit_counters(tmp_path):
     assert rec.cigar.shape[0] >= 8 * rec.n
     o, _ = compare([("m32", 0, L, ref, rec)], dict(max_depth=1_000_000, min_depth_for_low_mapq=10), tmp_path, "long32")
     assert o["m32"]["dumps"][0].max() > 3_000
+
+
+def _mgpu_worker(rank, world, port, args):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from decodingustools_amd import coverage_mgpu
+    sys.exit(coverage_mgpu.main(args))
+
+
+def test_coverage_on_files_over_two_processes(tmp_path):
+    """The multi-GPU file driver with two ranks (gloo; both on the one GPU of the test box): BED and
+    summary.json must equal the single-process `coverage` on the same files."""
+    import socket
+    import torch.multiprocessing as mp
+    from bamio import write_bam, write_fasta
+    from decodingustools_amd.bam import coverage_files
+    names = ["chr1", "chr2", "chr3", "chrX", "chrM"]
+    lens = [90_000, 60_000, 25_000, 30_000, 16_569]
+    recs = {0: synth.short_read_contig(lens[0], 30, 710), 1: synth.short_read_contig(lens[1], 12, 711),
+            3: synth.adversarial_contig(lens[3], 1500, 712), 4: synth.short_read_contig(lens[4], 20, 713)}
+    refs = [synth.make_reference(l, 820 + i, lowercase=(i == 4)) for i, l in enumerate(lens)]
+    bam = str(tmp_path / "t.bam"); fa = str(tmp_path / "t.fa")
+    write_bam(bam, list(zip(names, lens)), recs, block_every=2000)
+    write_fasta(fa, list(zip(names, refs)))
+    one = tmp_path / "one"; two = tmp_path / "two"; one.mkdir(); two.mkdir()
+    for sel, tag in ((None, "all"), (["chr2", "chrM", "chr3"], "sel")):
+        bed1 = str(one / f"{tag}.bed"); js1 = str(one / f"{tag}.json")
+        coverage_files(bam, fa, bed1, js1, CallableOptions(), contigs=sel)
+        bed2 = str(two / f"{tag}.bed"); js2 = str(two / f"{tag}.json")
+        args = [bam, "-r", fa, "-o", bed2, "--summary-json", js2, "--backend", "gloo"] + sum((["-L", c] for c in (sel or [])), [])
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=_mgpu_worker, args=(r, 2, port, args)) for r in range(2)]
+        for p in procs: p.start()
+        for p in procs: p.join(300)
+        assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+        assert open(bed2).read() == open(bed1).read()
+        j1 = open(js1).read().replace(bed1, "BED"); j2 = open(js2).read().replace(bed2, "BED")
+        assert j1 == j2

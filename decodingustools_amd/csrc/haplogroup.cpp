@@ -88,10 +88,10 @@ struct JParser {
             case 'b': o += '\b'; break; case 'f': o += '\f'; break; case 'n': o += '\n'; break;
             case 'r': o += '\r'; break; case 't': o += '\t'; break;
             case 'u': {
-                uint32_t v;
+                uint32_t v = 0;
                 if (!hex4(v)) return false;
                 if (v >= 0xD800 && v <= 0xDBFF) {
-                    uint32_t lo;
+                    uint32_t lo = 0;
                     if (e - p < 2 || p[0] != '\\' || p[1] != 'u') return fail("lone surrogate");
                     p += 2;
                     if (!hex4(lo) || lo < 0xDC00 || lo > 0xDFFF) return fail("lone surrogate");

@@ -182,16 +182,28 @@ struct BlockStream {
     RawBuf<uint8_t> cbuf;
     size_t batch = 32u << 20;         // compressed bytes per fill
     double t_read = 0, t_inflate = 0; // DUT_TIMING
+    // offsets in buf at which the inflated blocks begin (ascending; htslib never lets a record straddle
+    // two BGZF blocks, so in its files every block start is a record start and blocks can be walked
+    // independently); `aligned` is cleared the first time a record is seen to cross a block start
+    std::vector<size_t> bstart;
+    bool aligned = true;
 
     void reset(uint64_t voff)
     {
         next_coff = voff >> 16; skip = (size_t)(voff & 0xFFFF);
         buf.clear(); cur = 0; eof = false; err.clear(); valid = true;
+        bstart.clear(); aligned = true;
     }
     // appends the next batch of blocks to buf (after dropping the consumed prefix); false at EOF or on error
     bool fill()
     {
-        if (cur) { memmove(buf.p, buf.p + cur, buf.n - cur); buf.n -= cur; cur = 0; }
+        if (cur) {
+            memmove(buf.p, buf.p + cur, buf.n - cur); buf.n -= cur;
+            size_t k = 0;
+            for (size_t v : bstart) if (v >= cur) bstart[k++] = v - cur;
+            bstart.resize(k);
+            cur = 0;
+        }
         if (eof) return false;
         struct Blk { size_t in, clen, out; uint32_t isize, crc; };
         std::vector<Blk> blks;
@@ -234,6 +246,7 @@ struct BlockStream {
         const size_t base = buf.n;
         if (!buf.reserve(base + out_total)) { err = "out of memory"; return false; }
         buf.n = base + out_total;
+        for (const Blk &bk : blks) if (bk.isize) bstart.push_back(base + bk.out);
         std::atomic<int> bad{0};
         const uint8_t *cp = cbuf.p;
         uint8_t *op = buf.p + base;
@@ -432,6 +445,82 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
     st.t_read = st.t_inflate = 0;
     struct RecInfo { size_t off; uint32_t n_cigar, l_seq, l_name; size_t cig_off; uint64_t d_cig, d_qual, d_name, d_base; };
     std::vector<RecInfo> recs;
+    // the fields of one record the arrays need (r = first byte after block_size); false = malformed
+    auto decode = [](const uint8_t *r, uint32_t bs, RecInfo &x) -> bool {
+        const uint32_t l_read_name = r[8];
+        uint32_t n_cigar = rd16(r + 12);
+        const uint32_t l_seq = rd32(r + 16);
+        size_t q = 32;
+        if (q + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + (uint64_t)l_seq > bs || l_read_name == 0) return false;
+        size_t cig_off = q + l_read_name;
+        const uint8_t *cig = r + cig_off;
+        q = cig_off + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq;
+        // long CIGARs live in the CG:B,I tag behind a <l_seq>S<reflen>N placeholder
+        if (n_cigar == 2 && (rd32(cig) & 15u) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15u) == 3) {
+            size_t a = q;
+            while (a + 3 <= bs) {
+                const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
+                a += 3;
+                size_t len = 0;
+                auto elt = [](uint8_t c) -> size_t { switch (c) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
+                if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) ++len; len += 1; }
+                else if (ty == 'B') {
+                    if (a + 5 > bs) break;
+                    const uint8_t sub = r[a]; const uint32_t cnt = rd32(r + a + 1);
+                    if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= bs) { cig_off = a + 5; n_cigar = cnt; break; }
+                    len = 5 + elt(sub) * (size_t)cnt;
+                } else { len = elt(ty); if (!len) break; }
+                a += len;
+            }
+        }
+        x.n_cigar = n_cigar; x.l_seq = l_seq; x.l_name = l_read_name - 1; x.cig_off = cig_off;
+        return true;
+    };
+    int32_t *d_pos = nullptr; uint16_t *d_flag = nullptr; uint8_t *d_mapq = nullptr;
+    uint32_t *d_coff = nullptr, *d_cig = nullptr, *d_noff = nullptr;
+    uint64_t *d_qoff = nullptr, *d_soff = nullptr;
+    uint8_t *d_qual = nullptr, *d_name = nullptr, *d_seq = nullptr;
+    // room for the totals so far; the destination pointers are refreshed (the buffers may move)
+    auto make_room = [&]() -> bool {
+        const size_t seq_bytes_old = b->seq4.n, seq_bytes_new = want_seq ? (size_t)((n_bases + 1) / 2) : 0;
+        if (!b->pos.reserve(n) || !b->flag.reserve(n) || !b->mapq.reserve(n) || !b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) ||
+            !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) || !b->cigar.reserve(n_cig) || !b->qual.reserve(n_qual) ||
+            !b->qname.reserve(n_name) || !b->seq4.reserve(seq_bytes_new + 1)) { b->err = "out of memory"; return false; }
+        if (want_seq && seq_bytes_new > seq_bytes_old) memset(b->seq4.p + seq_bytes_old, 0, seq_bytes_new - seq_bytes_old);
+        b->seq4.n = seq_bytes_new;
+        d_pos = b->pos.p; d_flag = b->flag.p; d_mapq = b->mapq.p;
+        d_coff = b->cigar_off.p; d_cig = b->cigar.p; d_noff = b->qname_off.p;
+        d_qoff = b->qual_off.p; d_soff = b->seq_off.p;
+        d_qual = b->qual.p; d_name = b->qname.p; d_seq = b->seq4.p;
+        return true;
+    };
+    // one record into the arrays (idx = its ordinal in the contig, x.d_* = its offsets)
+    auto store = [&](const uint8_t *r, const RecInfo &x, uint64_t idx) {
+        d_pos[idx] = (int32_t)rd32(r + 4);
+        d_flag[idx] = rd16(r + 14);
+        d_mapq[idx] = r[9];
+        d_coff[idx] = (uint32_t)x.d_cig; d_qoff[idx] = x.d_qual; d_noff[idx] = (uint32_t)x.d_name; d_soff[idx] = x.d_base;
+        memcpy(d_cig + x.d_cig, r + x.cig_off, 4ull * x.n_cigar);
+        memcpy(d_name + x.d_name, r + 32, x.l_name);
+        const uint8_t *pk = r + 32 + x.l_name + 1 + 4ull * rd16(r + 12);
+        memcpy(d_qual + x.d_qual, pk + (x.l_seq + 1) / 2, x.l_seq);
+        if (want_seq && x.l_seq) {
+            // nibble-continuous store: bytes shared with the neighbouring records are OR-ed atomically
+            auto code = [&](uint32_t i) -> uint8_t { return (i & 1u) ? (uint8_t)(pk[i >> 1] & 15u) : (uint8_t)(pk[i >> 1] >> 4); };
+            const uint64_t B = x.d_base;
+            const uint32_t l = x.l_seq;
+            uint32_t i = 0;
+            if (B & 1u) { __atomic_fetch_or(&d_seq[B >> 1], code(0), __ATOMIC_RELAXED); i = 1; }
+            const uint64_t byte0 = (B + i) >> 1;
+            const uint32_t full = (l - i) >> 1;
+            if (i == 0) memcpy(d_seq + byte0, pk, full);
+            else for (uint32_t k2 = 0; k2 < full; ++k2) d_seq[byte0 + k2] = (uint8_t)((pk[k2] << 4) | (pk[k2 + 1] >> 4));
+            i += 2 * full;
+            if (i < l) __atomic_fetch_or(&d_seq[(B + i) >> 1], (uint8_t)(code(i) << 4), __ATOMIC_RELAXED);
+        }
+    };
+    struct Unit { size_t s, e, cut; uint64_t n, n_cig, n_qual, n_name; int status; };   // status: 0 ok, 1 crosses the block end, 2 malformed
+    std::vector<Unit> units;
     bool end = nothing;
     bool need_fill = st.cur >= st.buf.n;                                  // else: records left over from the previous contig's window
     while (!end) {
@@ -441,13 +530,88 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
             break;                                                        // clean EOF
         }
         need_fill = true;
-        // -- pass 1: record boundaries of this window, destination offsets --
-        const double ts0 = tnow();
-        recs.clear();
         const uint8_t *buf = st.buf.p;
         const size_t size = st.buf.n;
-        size_t o = st.cur;
         const uint64_t n0 = n;
+        bool done_parallel = false;
+        if (st.aligned && size > st.cur) {
+            // ---- blocks walked independently: count, place, store (all three in parallel over the blocks) ----
+            const double ts0 = tnow();
+            units.clear();
+            size_t s0 = st.cur;
+            for (size_t v : st.bstart) if (v > s0) { units.push_back({s0, v, SIZE_MAX, 0, 0, 0, 0, 0}); s0 = v; }
+            units.push_back({s0, size, SIZE_MAX, 0, 0, 0, 0, 0});
+            parallel_for(units.size(), 8, [&](size_t ui) {
+                Unit &u = units[ui];
+                size_t o = u.s;
+                while (o < u.e) {
+                    if (o + 4 > u.e) { u.status = 1; return; }
+                    const uint32_t bs = rd32(buf + o);
+                    if (bs < 32 || bs > (1u << 29)) { u.status = 2; return; }
+                    if (o + 4 + (size_t)bs > u.e) { u.status = 1; return; }
+                    const uint8_t *r = buf + o + 4;
+                    const int32_t ref_id = (int32_t)rd32(r);
+                    if (ref_id < 0 || ref_id > tid) { u.cut = o; return; }
+                    if (ref_id == tid) {
+                        RecInfo x;
+                        if (!decode(r, bs, x)) { u.status = 2; return; }
+                        u.n += 1; u.n_cig += x.n_cigar; u.n_qual += x.l_seq; u.n_name += x.l_name;
+                    }
+                    o += 4 + (size_t)bs;
+                }
+            });
+            // the units up to the first one that meets the next contig; a unit that is not a whole number of
+            // records before that point means this file lets records straddle blocks: the general walk takes over
+            size_t n_units = units.size();
+            bool straddle = false, malformed = false;
+            for (size_t ui = 0; ui < units.size(); ++ui) {
+                if (units[ui].status == 1) { straddle = true; break; }
+                if (units[ui].status == 2) { malformed = true; break; }
+                if (units[ui].cut != SIZE_MAX) { n_units = ui + 1; break; }
+            }
+            if (straddle || malformed) st.aligned = false;        // (a malformed record is reported by the general walk)
+            else {
+                std::vector<uint64_t> ub(4 * n_units);
+                for (size_t ui = 0; ui < n_units; ++ui) {
+                    ub[4 * ui] = n; ub[4 * ui + 1] = n_cig; ub[4 * ui + 2] = n_qual; ub[4 * ui + 3] = n_name;
+                    n += units[ui].n; n_cig += units[ui].n_cig; n_qual += units[ui].n_qual; n_name += units[ui].n_name;
+                }
+                n_bases = n_qual;
+                if (n_cig > 0xFFFFFFF0ull || n_name > 0xFFFFFFF0ull) { b->err = "contig too large for 32-bit offsets"; return CL_ERR_RANGE; }
+                t_scan += tnow() - ts0;
+                const double tp0 = tnow();
+                if (!make_room()) return CL_ERR_INVALID;
+                parallel_for(n_units, 8, [&](size_t ui) {
+                    const Unit &u = units[ui];
+                    const size_t stop = u.cut != SIZE_MAX ? u.cut : u.e;
+                    uint64_t idx = ub[4 * ui], c = ub[4 * ui + 1], q = ub[4 * ui + 2], nm = ub[4 * ui + 3];
+                    for (size_t o = u.s; o < stop;) {
+                        const uint32_t bs = rd32(buf + o);
+                        const uint8_t *r = buf + o + 4;
+                        if ((int32_t)rd32(r) == tid) {
+                            RecInfo x;
+                            decode(r, bs, x);
+                            x.d_cig = c; x.d_qual = q; x.d_name = nm; x.d_base = q;
+                            store(r, x, idx);
+                            idx += 1; c += x.n_cigar; q += x.l_seq; nm += x.l_name;
+                        }
+                        o += 4 + (size_t)bs;
+                    }
+                });
+                const Unit &last = units[n_units - 1];
+                if (last.cut != SIZE_MAX) { st.cur = last.cut; end = true; }
+                else st.cur = last.e;
+                b->pos.n = b->flag.n = b->mapq.n = n;
+                b->cigar.n = n_cig; b->qual.n = n_qual; b->qname.n = n_name;
+                t_parse += tnow() - tp0;
+                done_parallel = true;
+            }
+        }
+        if (done_parallel) continue;
+        // ---- general walk: pass 1, record boundaries of this window and destination offsets (sequential) ----
+        const double ts0 = tnow();
+        recs.clear();
+        size_t o = st.cur;
         while (o + 4 <= size) {
             const uint32_t bs = rd32(buf + o);
             if (bs < 32 || bs > (1u << 29)) { b->err = "bad BAM block_size"; return CL_ERR_INVALID; }
@@ -460,79 +624,21 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
             const int32_t ref_id = (int32_t)rd32(r);
             if (ref_id < 0 || ref_id > tid) { end = true; break; }        // sorted: past this contig (the record stays in the stream)
             if (ref_id == tid) {
-                const uint32_t l_read_name = r[8];
-                uint32_t n_cigar = rd16(r + 12);
-                const uint32_t l_seq = rd32(r + 16);
-                size_t q = 32;
-                if (q + l_read_name + 4ull * n_cigar + (l_seq + 1) / 2 + (uint64_t)l_seq > bs || l_read_name == 0) { b->err = "malformed BAM record"; return CL_ERR_INVALID; }
-                size_t cig_off = q + l_read_name;
-                const uint8_t *cig = r + cig_off;
-                q = cig_off + 4ull * n_cigar + (l_seq + 1) / 2 + l_seq;
-                // long CIGARs live in the CG:B,I tag behind a <l_seq>S<reflen>N placeholder
-                if (n_cigar == 2 && (rd32(cig) & 15u) == 4 && (rd32(cig) >> 4) == l_seq && (rd32(cig + 4) & 15u) == 3) {
-                    size_t a = q;
-                    while (a + 3 <= bs) {
-                        const uint8_t t0 = r[a], t1 = r[a + 1], ty = r[a + 2];
-                        a += 3;
-                        size_t len = 0;
-                        auto elt = [](uint8_t c) -> size_t { switch (c) { case 'c': case 'C': case 'A': return 1; case 's': case 'S': return 2; case 'i': case 'I': case 'f': return 4; default: return 0; } };
-                        if (ty == 'Z' || ty == 'H') { while (a + len < bs && r[a + len]) ++len; len += 1; }
-                        else if (ty == 'B') {
-                            if (a + 5 > bs) break;
-                            const uint8_t sub = r[a]; const uint32_t cnt = rd32(r + a + 1);
-                            if (t0 == 'C' && t1 == 'G' && sub == 'I' && a + 5 + 4ull * cnt <= bs) { cig_off = a + 5; n_cigar = cnt; break; }
-                            len = 5 + elt(sub) * (size_t)cnt;
-                        } else { len = elt(ty); if (!len) break; }
-                        a += len;
-                    }
-                }
-                recs.push_back({o + 4, n_cigar, l_seq, l_read_name - 1, cig_off, n_cig, n_qual, n_name, n_bases});
-                n += 1; n_cig += n_cigar; n_qual += l_seq; n_name += l_read_name - 1; n_bases += l_seq;
+                RecInfo x;
+                if (!decode(r, bs, x)) { b->err = "malformed BAM record"; return CL_ERR_INVALID; }
+                x.off = o + 4; x.d_cig = n_cig; x.d_qual = n_qual; x.d_name = n_name; x.d_base = n_bases;
+                recs.push_back(x);
+                n += 1; n_cig += x.n_cigar; n_qual += x.l_seq; n_name += x.l_name; n_bases += x.l_seq;
                 if (n_cig > 0xFFFFFFF0ull || n_name > 0xFFFFFFF0ull) { b->err = "contig too large for 32-bit offsets"; return CL_ERR_RANGE; }
             }
             o += 4 + (size_t)bs;
         }
         t_scan += tnow() - ts0;
         const double tp0 = tnow();
-        // -- pass 2: fill the arrays, records in parallel --
-        const size_t seq_bytes_old = b->seq4.n, seq_bytes_new = want_seq ? (size_t)((n_bases + 1) / 2) : 0;
-        if (!b->pos.reserve(n) || !b->flag.reserve(n) || !b->mapq.reserve(n) || !b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) ||
-            !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) || !b->cigar.reserve(n_cig) || !b->qual.reserve(n_qual) ||
-            !b->qname.reserve(n_name) || !b->seq4.reserve(seq_bytes_new + 1)) { b->err = "out of memory"; return CL_ERR_INVALID; }
-        if (want_seq && seq_bytes_new > seq_bytes_old) memset(b->seq4.p + seq_bytes_old, 0, seq_bytes_new - seq_bytes_old);
-        b->seq4.n = seq_bytes_new;
-        int32_t *d_pos = b->pos.p; uint16_t *d_flag = b->flag.p; uint8_t *d_mapq = b->mapq.p;
-        uint32_t *d_coff = b->cigar_off.p, *d_cig = b->cigar.p, *d_noff = b->qname_off.p;
-        uint64_t *d_qoff = b->qual_off.p, *d_soff = b->seq_off.p;
-        uint8_t *d_qual = b->qual.p, *d_name = b->qname.p, *d_seq = b->seq4.p;
+        // ---- pass 2: fill the arrays, records in parallel ----
+        if (!make_room()) return CL_ERR_INVALID;
         const RecInfo *ri = recs.data();
-        parallel_for(recs.size(), 8192, [&](size_t k) {
-            const RecInfo &x = ri[k];
-            const uint8_t *r = buf + x.off;
-            const uint64_t idx = n0 + k;
-            d_pos[idx] = (int32_t)rd32(r + 4);
-            d_flag[idx] = rd16(r + 14);
-            d_mapq[idx] = r[9];
-            d_coff[idx] = (uint32_t)x.d_cig; d_qoff[idx] = x.d_qual; d_noff[idx] = (uint32_t)x.d_name; d_soff[idx] = x.d_base;
-            memcpy(d_cig + x.d_cig, r + x.cig_off, 4ull * x.n_cigar);
-            memcpy(d_name + x.d_name, r + 32, x.l_name);
-            const uint8_t *pk = r + 32 + x.l_name + 1 + 4ull * rd16(r + 12);
-            memcpy(d_qual + x.d_qual, pk + (x.l_seq + 1) / 2, x.l_seq);
-            if (want_seq && x.l_seq) {
-                // nibble-continuous store: bytes shared with the neighbouring records are OR-ed atomically
-                auto code = [&](uint32_t i) -> uint8_t { return (i & 1u) ? (uint8_t)(pk[i >> 1] & 15u) : (uint8_t)(pk[i >> 1] >> 4); };
-                const uint64_t B = x.d_base;
-                const uint32_t l = x.l_seq;
-                uint32_t i = 0;
-                if (B & 1u) { __atomic_fetch_or(&d_seq[B >> 1], code(0), __ATOMIC_RELAXED); i = 1; }
-                const uint64_t byte0 = (B + i) >> 1;
-                const uint32_t full = (l - i) >> 1;
-                if (i == 0) memcpy(d_seq + byte0, pk, full);
-                else for (uint32_t k2 = 0; k2 < full; ++k2) d_seq[byte0 + k2] = (uint8_t)((pk[k2] << 4) | (pk[k2 + 1] >> 4));
-                i += 2 * full;
-                if (i < l) __atomic_fetch_or(&d_seq[(B + i) >> 1], (uint8_t)(code(i) << 4), __ATOMIC_RELAXED);
-            }
-        });
+        parallel_for(recs.size(), 8192, [&](size_t k) { store(buf + ri[k].off, ri[k], n0 + k); });
         b->pos.n = b->flag.n = b->mapq.n = n;
         b->cigar.n = n_cig; b->qual.n = n_qual; b->qname.n = n_name;
         st.cur = o;

@@ -1,9 +1,11 @@
 // Tooling only: a quick multi-threaded BAM writer for the end-to-end benchmark (one contig's decoded
 // records -> coordinate-sorted BAM, no index).  Built on demand by tools/e2e_bench.py with g++.
 #include <zlib.h>
+#include <algorithm>
 #include <atomic>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -56,15 +58,22 @@ extern "C" int tool_write_bam(const char *path, const char *header_text, const c
     put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
     put32(head, 1); put32(head, (uint32_t)strlen(ref_name) + 1); head.insert(head.end(), ref_name, ref_name + strlen(ref_name) + 1); put32(head, ref_len);
     { auto b = bgzf_block(head.data(), head.size(), level); fwrite(b.data(), 1, b.size(), f); }
+    // like htslib's bam_write1 (bgzf_flush_try): a record that does not fit into the current BGZF block
+    // starts a new one, so no record straddles two blocks (set TOOL_BAM_STRADDLE=1 for 0xFF00-byte cuts)
+    const bool straddle = getenv("TOOL_BAM_STRADDLE") && *getenv("TOOL_BAM_STRADDLE") == '1';
     const uint64_t kChunk = 200000;
     std::vector<uint8_t> carry;
     for (uint64_t a = 0; a < n; a += kChunk) {
         const uint64_t e = a + kChunk < n ? a + kChunk : n;
         std::vector<uint8_t> buf(std::move(carry));
         carry.clear();
+        std::vector<size_t> cuts{0};                       // block boundaries inside buf
+        size_t blk_begin = 0;
         for (uint64_t i = a; i < e; ++i) {
             const uint32_t nc = cigar_off[i + 1] - cigar_off[i], ln = qname_off[i + 1] - qname_off[i] + 1;
             const uint32_t ls = (uint32_t)(qual_off[i + 1] - qual_off[i]);
+            const size_t rec_bytes = 36 + ln + 4ull * nc + (ls + 1) / 2 + ls;
+            if (!straddle && buf.size() - blk_begin + rec_bytes > 0xFF00 && buf.size() > blk_begin) { cuts.push_back(buf.size()); blk_begin = buf.size(); }
             int64_t rlen = 0;
             for (uint32_t k = cigar_off[i]; k < cigar_off[i + 1]; ++k) { const uint32_t op = cigar[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cigar[k] >> 4; }
             put32(buf, 32 + ln + 4 * nc + (ls + 1) / 2 + ls);
@@ -77,16 +86,23 @@ extern "C" int tool_write_bam(const char *path, const char *header_text, const c
             buf.insert(buf.end(), (ls + 1) / 2, (uint8_t)0x11);
             buf.insert(buf.end(), qual + qual_off[i], qual + qual_off[i + 1]);
         }
-        const size_t kB = 0xFF00, nb = e == n ? (buf.size() + kB - 1) / kB : buf.size() / kB;
+        if (straddle) {
+            const size_t kB = 0xFF00, nbs = e == n ? (buf.size() + kB - 1) / kB : buf.size() / kB;
+            cuts.clear();
+            for (size_t b = 0; b <= nbs; ++b) cuts.push_back(std::min(b * kB, buf.size()));
+            if (e != n) cuts.back() = nbs * kB;
+        } else if (e == n) cuts.push_back(buf.size());   // the open block is closed at the end only
+        // blocks [cuts[b], cuts[b+1]) ; what follows the last cut is carried into the next chunk
+        const size_t nb = cuts.size() - 1;
         std::vector<std::vector<uint8_t>> outs(nb);
         std::atomic<size_t> next{0};
-        auto work = [&]() { for (;;) { const size_t b = next.fetch_add(1); if (b >= nb) break; const size_t o = b * kB; outs[b] = bgzf_block(buf.data() + o, std::min(kB, buf.size() - o), level); } };
+        auto work = [&]() { for (;;) { const size_t b = next.fetch_add(1); if (b >= nb) break; outs[b] = bgzf_block(buf.data() + cuts[b], cuts[b + 1] - cuts[b], level); } };
         std::vector<std::thread> th;
         for (int t = 1; t < threads; ++t) th.emplace_back(work);
         work();
         for (auto &t : th) t.join();
         for (auto &o : outs) fwrite(o.data(), 1, o.size(), f);
-        if (nb * kB < buf.size()) carry.assign(buf.begin() + (long)(nb * kB), buf.end());
+        if (cuts.back() < buf.size()) carry.assign(buf.begin() + (long)cuts.back(), buf.end());
     }
     { auto b = bgzf_block(nullptr, 0, level); fwrite(b.data(), 1, b.size(), f); }
     fclose(f);

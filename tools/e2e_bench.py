@@ -7,17 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from decodingustools_amd import synth, build as _b
-import ctypes as C
-
-def write_bam_native(path, name, L, rec, level=1, threads=16):
-    so = os.path.join(out, "bamwriter.so")
-    subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", os.path.join(ROOT, "tools", "bamwriter.cpp"), "-lz", "-lpthread", "-o", so])
-    lib = C.CDLL(so)
-    p = lambda a: a.ctypes.data_as(C.c_void_p)
-    lib.tool_write_bam.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_uint64] + [C.c_void_p] * 9 + [C.c_int, C.c_int]
-    rc = lib.tool_write_bam(path.encode(), b"@HD\tVN:1.6\tSO:coordinate\n@PG\tID:bwa\tPN:bwa\n", name.encode(), L, rec.n, p(rec.pos), p(rec.flag), p(rec.mapq),
-                            p(rec.cigar_off), p(rec.cigar), p(rec.qual_off), p(rec.qual), p(rec.qname_off), p(rec.qname), level, threads)
-    assert rc == 0
+import e2e_bench_lib as EL
 
 out = os.environ.get("E2E_DIR", "/tmp/e2e")
 os.makedirs(out, exist_ok=True)
@@ -30,14 +20,8 @@ rec = synth.short_read_contig(L, depth, seed)
 ref = synth.make_reference(L, seed)
 print(f"generated {rec.n} reads in {time.time() - t0:.1f} s", flush=True)
 t0 = time.time()
-write_bam_native(bam, "chr21", L, rec, threads=int(os.environ.get("E2E_WTHREADS", 16)))
-width = 60
-with open(fa, "wb") as f:
-    f.write(b">chr21\n")
-    full = (L // width) * width
-    body = np.empty((L // width, width + 1), np.uint8); body[:, :width] = ref[:full].reshape(-1, width); body[:, width] = 10
-    f.write(body.tobytes()); f.write(ref[full:].tobytes() + b"\n")
-open(fa + ".fai", "w").write(f"chr21\t{L}\t7\t{width}\t{width + 1}\n")
+EL.write_bam_native(out, bam, "chr21", L, rec, threads=int(os.environ.get("E2E_WTHREADS", 16)))
+EL.write_fasta(fa, "chr21", ref)
 print(f"wrote {os.path.getsize(bam) / 1e6:.0f} MB BAM in {time.time() - t0:.1f} s", flush=True)
 del rec
 for threads in os.environ.get("E2E_THREADS", "16,1").split(","):

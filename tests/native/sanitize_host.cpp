@@ -1,0 +1,96 @@
+// TEST INFRASTRUCTURE: drives the host-only parts of the library (BAM / FASTA reader, admission, BamStats,
+// JSON writer, tree parsing / scoring / report) under AddressSanitizer + UBSan or ThreadSanitizer on the CPU.
+// The device engine is not part of this binary: the few cl_* symbols the host sources reference are
+// defined below as failing stubs for the link only (nothing here reaches them).
+#include "../../include/dut_haplogroup.h"
+#include "../../include/dut_report.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" {
+cl_status cl_create(const cl_options *, int, void *, cl_ctx **) { return CL_ERR_DEVICE; }
+void cl_destroy(cl_ctx *) {}
+const char *cl_last_error(const cl_ctx *) { return "no device in the sanitizer build"; }
+cl_status cl_contig_begin(cl_ctx *, int32_t, uint32_t, const uint8_t *, uint64_t) { return CL_ERR_DEVICE; }
+cl_status cl_push_reads(cl_ctx *, const cl_read_tile *) { return CL_ERR_DEVICE; }
+cl_status cl_contig_finish(cl_ctx *, cl_contig_summary *, const cl_interval **, size_t *) { return CL_ERR_DEVICE; }
+cl_status cl_site_pileup(cl_ctx *, uint8_t, uint32_t, uint64_t, const cl_site_tile *, const uint32_t *, size_t, uint32_t *) { return CL_ERR_DEVICE; }
+}
+
+static unsigned long long checksum(const void *p, size_t n)
+{
+    unsigned long long h = 1469598103934665603ull;
+    const unsigned char *b = (const unsigned char *)p;
+    for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+    return h;
+}
+
+int main(int argc, char **argv)
+{
+    if (argc < 2) { fprintf(stderr, "usage: sanitize_host <bam> [tree.json]\n"); return 2; }
+    char err[512] = {0};
+    // BAM reader: every contig, with and without sequences, twice (buffer reuse), in reverse order too
+    dut_bam *b = dut_bam_open(argv[1], err, sizeof(err));
+    if (!b) { printf("open failed: %s\n", err); return 0; }           // corrupted inputs are allowed to fail cleanly
+    const int n_ref = dut_bam_n_ref(b);
+    cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int k = 0; k < n_ref; ++k) {
+            const int tid = pass ? n_ref - 1 - k : k;
+            dut_records rec; const uint64_t *so = nullptr; const uint8_t *sq = nullptr;
+            const int rc = dut_bam_read_contig(b, tid, &rec, pass ? &so : nullptr, pass ? &sq : nullptr);
+            if (rc != CL_OK) { printf("tid %d: %s\n", tid, dut_bam_error(b)); continue; }
+            unsigned long long h = checksum(rec.pos, rec.n * 4) ^ checksum(rec.qual, rec.qual_off[rec.n]) ^ checksum(rec.cigar, 4ull * rec.cigar_off[rec.n]) ^
+                                   checksum(rec.qname, rec.qname_off[rec.n]);
+            if (pass) h ^= checksum(sq, (so[rec.n] + 1) / 2);
+            std::vector<uint8_t> acc(rec.n + 1);
+            uint32_t names = 0; uint64_t nacc = 0;
+            const int ar = dut_admit_reads(&opt, tid, dut_bam_ref_len(b, tid), &rec, acc.data(), &names, &nacc);
+            printf("tid %d pass %d: n %llu hash %016llx admit rc %d accepted %llu names %u\n", tid, pass, (unsigned long long)rec.n, h, ar,
+                   (unsigned long long)nacc, names);
+        }
+    }
+    dut_bam_close(b);
+    dut_bam_stats *bs = dut_bam_stats_new(10000);
+    if (dut_bam_stats_collect(bs, argv[1], err, sizeof(err)) == CL_OK)
+        printf("stats: %s | %s | %s | %llu\n", dut_bam_stats_aligner(bs), dut_bam_stats_reference_build(bs), dut_bam_stats_infer_platform(bs),
+               (unsigned long long)dut_bam_stats_average_read_length(bs));
+    dut_bam_stats_free(bs);
+    if (argc > 2) {
+        dut_tree *t = dut_tree_load(argv[2], DUT_PROVIDER_FTDNA, DUT_TREE_YDNA, err, sizeof(err));
+        if (!t) { printf("tree failed: %s\n", err); return 0; }
+        uint32_t *sites = nullptr; uint8_t *rel = nullptr; size_t ns = 0;
+        dut_tree_collect_sites(t, "GRCh38", "chrY", &sites, &rel, &ns);
+        std::vector<uint32_t> hist(16 * (ns + 1), 0);
+        static const int kCode[4] = {1, 2, 4, 8};                         // A C G T
+        for (size_t i = 0; i < ns; ++i) { hist[16 * i + kCode[i % 4]] = 12 + (uint32_t)(i % 9); hist[16 * i + 15] += (uint32_t)(i % 3); }
+        dut_snp_call *calls = nullptr; size_t nc = 0;
+        dut_call_sites(sites, rel, hist.data(), ns, 10, &calls, &nc);
+        dut_haplogroup_result *res = nullptr; size_t nr = 0;
+        const int rc = dut_tree_score(t, calls, nc, "GRCh38", &res, &nr, err, sizeof(err));
+        printf("tree: %zu nodes, %zu sites, %zu calls, score rc %d, %zu rows\n", dut_tree_built_nodes(t), ns, nc, rc, nr);
+        if (rc == CL_OK) {
+            const std::string out = std::string(argv[2]) + ".tsv";
+            dut_write_haplogroup_report(out.c_str(), t, res, nr, calls, nc, "GRCh38", 1, err, sizeof(err));
+        }
+        dut_free(res); dut_free(calls); dut_free(sites); dut_free(rel);
+        dut_tree_free(t);
+    }
+    // summary JSON with awkward names
+    dut_contig_stats st[2]; memset(st, 0, sizeof(st));
+    st[0].length = 20; st[0].n_covered_bases = 12; st[0].summed_coverage = 22; st[0].summed_baseq = 420; st[0].summed_mapq = 960; st[0].quality_bases = 14; st[0].n_reads = 3;
+    st[1].length = 0;
+    const char *names[2] = {"chr\"T\\\x01", "chrUn_x"};
+    uint64_t counts[12] = {2, 2, 8, 6, 0, 2, 0, 0, 0, 0, 0, 0};
+    dut_export_meta meta; memset(&meta, 0, sizeof(meta));
+    meta.aligner = "BWA"; meta.reference_build = "GRCh38"; meta.sequencing_platform = "NovaSeq"; meta.read_length = 150;
+    meta.bed_file = "x.bed"; meta.summary_html = "s.html";
+    char *js = nullptr; size_t jl = 0;
+    if (dut_coverage_output_json(st, names, counts, 2, &meta, &js, &jl) == CL_OK) printf("json %zu bytes\n", jl);
+    dut_free(js);
+    return 0;
+}

@@ -7,6 +7,7 @@
 #include "host_parallel.h"
 
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -20,6 +21,30 @@
 using namespace clk;
 
 namespace {
+
+// rocTX ranges around the host-visible phases (rocprofv3 --marker-trace shows them); bound at run time so
+// that the library does not depend on the profiler's marker library being installed
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx()
+    {
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+            void *h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+            if (!h) continue;
+            push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+            pop = (int (*)())dlsym(h, "roctxRangePop");
+            if (push && pop) return;
+            push = nullptr; pop = nullptr;
+        }
+    }
+};
+struct Range {
+    static const Roctx &rt() { static const Roctx r; return r; }
+    explicit Range(const char *name) { if (rt().push) rt().push(name); }
+    ~Range() { if (rt().pop) rt().pop(); }
+};
+
 
 // window size (reference positions per workgroup).  2048 -> 24.9 KiB of LDS per workgroup,
 // six workgroups (24 waves) per CU.
@@ -506,6 +531,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
 
 cl_status cl_contig_upload(cl_ctx *c)
 {
+    Range rg("cl_contig_upload");
     if (!c || !c->in_contig) return fail(c, CL_ERR_INVALID, "cl_contig_upload without cl_contig_begin");
     HIP_TRY(c, hipSetDevice(c->device));
     c->n_reads = (uint32_t)c->h_pos.size();
@@ -561,6 +587,7 @@ cl_status cl_contig_upload(cl_ctx *c)
 
 cl_status cl_contig_run(cl_ctx *c)
 {
+    Range rg("cl_contig_run");
     if (!c || !c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_run before cl_contig_upload");
     HIP_TRY(c, hipSetDevice(c->device));
     cl_status s = enqueue(c, false, nullptr, nullptr, nullptr);
@@ -586,6 +613,7 @@ static cl_status check_summary(cl_ctx *c)
 
 cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
 {
+    Range rg("cl_contig_collect");
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
     HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 4; ++attempt) {

@@ -430,25 +430,32 @@ struct PileupArgs {
 // ---------------------------------------------------------------------------------------------
 // k_pileup: one workgroup per window of T reference positions.
 //
-// Pass over the window's reads, 256 at a time, one lane per read, waves never synchronising:
+// Pass over the window's candidate reads (the wide ones that start before the ordinary range first),
+// 256 at a time, one lane per read, waves never synchronising:
 //   * +1/-1 at the clipped span ends into raw / low-mapq difference arrays (mod.rs:22-28: every
 //     read covering a position counts, D/N included)
 //   * the lane walks its CIGAR and writes the window-clipped M/=/X segments of reads with
 //     mapq >= min_mapq into its wave's private LDS list (in lane = position order)
 //   * lane quads consume the list: a lane handles units of 16 reference positions = one unaligned
 //     16-byte load of quality bytes, a byte-parallel "quality >= min" test (mod.rs:30-37) and
-//     adds into packed 16-bit LDS counters (qc_depth); the sum of the passing qualities feeds
-//     summed_baseq (contig_profiler.rs:68-70)
+//     adds into packed 8-bit (two sets) or 16-bit LDS counters (qc_depth); the sum of the passing
+//     qualities feeds summed_baseq (contig_profiler.rs:68-70)
 // then one barrier and a final phase per position: prefix sums -> raw_depth / low_mapq_count,
-// the low-MAPQ rule and the state (callable_profiler.rs:100-116), run-boundary count, state byte.
-// None of the per-position counters ever exists in HBM.
+// the low-MAPQ rule and the state (callable_profiler.rs:100-116), the window's totals and its run
+// list (the positions inside the window where the state changes).
+// Neither the per-position counters nor the per-position states ever exist in HBM.
 //
-// Reads are dealt to waves round-robin (read = base + 4*lane + wave) so that the segments a
-// wave's 16 quads work on at the same time are ~16 reads apart and never share a counter word.
+// Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave) so that the segments a
+// wave's 16 quads work on at the same time are ~16 reads apart and rarely share a counter word.
 //
-// DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window is touched by <= 32767 reads (otherwise
-// k_window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one 32-bit
-// counter per position).
+// LONG = true (contigs with >= 8 CIGAR operations per read on average): the lane-serial CIGAR walk is
+// replaced by an operation-parallel one -- live reads are compacted, a wave takes 64 operations of a
+// read at a time, two DPP scans give every operation its reference / query start, each lane consumes
+// its own M/=/X run (runs longer than 64 bases go through the list and the quad loop).
+//
+// DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window has <= 32767 candidates
+// (otherwise k_window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one
+// 32-bit counter per position).
 // ---------------------------------------------------------------------------------------------
 template <bool ORF>
 __device__ __forceinline__ uint32_t pass_bytes(uint32_t xw, uint32_t vm, const Opts &o)

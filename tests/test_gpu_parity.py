@@ -670,3 +670,23 @@ def test_coverage_on_files_over_two_processes(tmp_path):
         assert open(bed2).read() == open(bed1).read()
         j1 = open(js1).read().replace(bed1, "BED"); j2 = open(js2).read().replace(bed2, "BED")
         assert j1 == j2
+
+
+def test_many_small_contigs_with_random_options(tmp_path):
+    """Differential sweep: small adversarial contigs, several per BED (the duplicated last line between
+    them), each round with its own random option set -- depth caps low enough to bite, thresholds on
+    both sides of 128, fractions incl. 0 and ~1, windows lengths around multiples of 2048."""
+    rng = np.random.default_rng(2024)
+    lens_pool = [1, 2047, 2048, 2049, 4096, 5000, 6145, 9000]
+    for rnd in range(30):
+        opt = dict(min_depth=int(rng.integers(0, 12)), max_depth=int(rng.choice([0, 3, 20, 150, 500, 100000])),
+                   min_mapping_quality=int(rng.choice([0, 1, 10, 30, 61])), min_base_quality=int(rng.choice([0, 1, 20, 40, 127, 128, 129, 200, 255])),
+                   min_depth_for_low_mapq=int(rng.integers(0, 15)), max_low_mapq=int(rng.choice([0, 1, 5, 60])),
+                   max_low_mapq_fraction=float(rng.choice([0.0, 0.05, 0.1, 0.5, 0.999])))
+        contigs = []
+        for t in range(3):
+            L = int(rng.choice(lens_pool))
+            n_reads = int(rng.integers(0, 700)) if L > 1 else int(rng.integers(0, 3))
+            rec = synth.adversarial_contig(L, n_reads, 5000 + 10 * rnd + t, deep=bool(rng.integers(0, 2)), overhang=bool(rng.integers(0, 2))) if n_reads else ContigRecords.empty()
+            contigs.append((f"c{rnd}_{t}", t, L, synth.make_reference(L, 7000 + 10 * rnd + t, lowercase=bool(t == 1)) if rng.random() < 0.9 else None, rec))
+        compare(contigs, opt, tmp_path, f"sweep{rnd}")

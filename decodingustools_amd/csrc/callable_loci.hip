@@ -98,6 +98,7 @@ struct cl_ctx {
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
     bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
+    bool no_opt8 = false;            // a position deeper than 255 was met: 8-bit counter sets only up to 510 candidates
     bool has_long = false;           // some read has more than kLongOps CIGAR ops (k_read_prep_long needed)
     int32_t tid = 0;
     uint32_t contig_len = 0;
@@ -310,6 +311,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
+    a.opt8 = c->no_opt8 ? 0u : 1u; a.err_flag = c->d_errflag.p;
     {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
         const char *ab = getenv("CL_ABLATE");
         a.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u;
@@ -581,7 +583,7 @@ cl_status cl_contig_upload(cl_ctx *c)
     std::vector<uint8_t>().swap(c->h_qual);
     std::vector<uint32_t>().swap(c->h_cigar_off);
     std::vector<unsigned long long>().swap(c->h_qual_off);
-    c->uploaded = true; c->ran = false; c->deep = false;
+    c->uploaded = true; c->ran = false; c->deep = false; c->no_opt8 = false;
     return CL_OK;
 }
 
@@ -616,7 +618,7 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
     Range rg("cl_contig_collect");
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
     HIP_TRY(c, hipSetDevice(c->device));
-    for (int attempt = 0; attempt < 4; ++attempt) {
+    for (int attempt = 0; attempt < 5; ++attempt) {
         HIP_TRY(c, hipMemcpyAsync(&c->h_sum, c->d_summary.p, sizeof(DevSummary), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         cl_status s = harvest_events(c);
@@ -626,6 +628,14 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
         // a window touched by more reads than the 16-bit counters hold: redo with 32-bit counters
         if ((c->h_sum.err & kNeedDeep) && !c->deep) {
             c->deep = true;
+            s = enqueue(c, false, nullptr, nullptr, nullptr);
+            if (s != CL_OK) return s;
+            continue;
+        }
+        // a position deeper than 255 in a window that used the 8-bit counter sets beyond their safe
+        // candidate count: redo with the 16-bit fields for such windows
+        if ((c->h_sum.err & kNeedWide8) && !c->no_opt8 && !c->deep) {
+            c->no_opt8 = true;
             s = enqueue(c, false, nullptr, nullptr, nullptr);
             if (s != CL_OK) return s;
             continue;

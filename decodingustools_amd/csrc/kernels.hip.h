@@ -33,7 +33,7 @@ constexpr uint32_t kWideSpan = 16384; // reads spanning more reference than this
                                       // in their own list instead of widening every window's candidate range
 constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
 
-enum : uint32_t { kErrCigar = 1u, kErrRange = 2u, kNeedDeep = 4u };
+enum : uint32_t { kErrCigar = 1u, kErrRange = 2u, kNeedDeep = 4u, kNeedWide8 = 8u };
 
 // per-block output of k_read_prep
 struct PrepPartial {
@@ -425,6 +425,8 @@ struct PileupArgs {
     // debug dumps (nullptr in production)
     uint32_t *dbg_raw, *dbg_qc, *dbg_low;
     uint32_t ablate;              // timing experiments only (env CL_ABLATE); 0 in production
+    uint32_t opt8;                // 1: 8-bit counter sets also for windows with more than 510 candidates (see k_pileup)
+    uint32_t *err_flag;           // kNeedWide8 is raised here
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -628,7 +630,12 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
 
     // qc_depth counters: two sets of bytes when the window is touched by <= 510 reads (the reads
     // alternate between the sets, so no byte can pass 255), else 16-bit fields (DEEP: 32-bit words)
-    const bool mode8 = !DEEP && n_cand <= 510u;
+    // The bytes cannot overflow with <= 510 candidates.  With more (deeper data: 36x of 150-base reads
+    // already has ~515 candidates per window) they still cannot while no position is covered by more than
+    // 255 reads -- a byte counts reads of one set covering its position -- so the 8-bit sets are used
+    // optimistically and the window's maximum raw depth, known in the final phase, is the check: beyond
+    // 255 the kernel raises kNeedWide8 and the host re-runs the contig with opt8 = 0.
+    const bool mode8 = !DEEP && (n_cand <= 510u || a.opt8 != 0u);
 
     // ---- the pass over the reads ----
     uint32_t sq32 = 0;                              // sum of passing qualities handled by this lane
@@ -1119,6 +1126,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
         wp.max_raw = m;
         a.winpart[w] = wp;
+        if (!DEEP && mode8 && n_cand > 510u && m > 255u) atomicOr(a.err_flag, kNeedWide8);
     }
 }
 

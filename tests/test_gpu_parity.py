@@ -690,3 +690,30 @@ def test_many_small_contigs_with_random_options(tmp_path):
             rec = synth.adversarial_contig(L, n_reads, 5000 + 10 * rnd + t, deep=bool(rng.integers(0, 2)), overhang=bool(rng.integers(0, 2))) if n_reads else ContigRecords.empty()
             contigs.append((f"c{rnd}_{t}", t, L, synth.make_reference(L, 7000 + 10 * rnd + t, lowercase=bool(t == 1)) if rng.random() < 0.9 else None, rec))
         compare(contigs, opt, tmp_path, f"sweep{rnd}")
+
+
+def test_deeper_short_read_data_keeps_the_8bit_counters(tmp_path):
+    """60x and 120x of 150-base reads: more than 510 candidates per window but no position deeper than 255,
+    so the 8-bit counter sets stay in use (checked by depth, not by candidate count); a pile deeper than
+    255 inside such a contig makes the engine redo it with 16-bit fields.  Results must not change."""
+    L = 150_000
+    ref = synth.make_reference(L, 61)
+    for depth, seed in ((60, 62), (120, 63)):
+        rec = synth.short_read_contig(L, depth, seed, max_live_assert=100_000)
+        o, _ = compare([(f"d{depth}", 0, L, ref, rec)], dict(max_depth=100_000), tmp_path, f"depth{depth}")
+        assert 40 < o[f"d{depth}"]["dumps"][0].max() <= 255 or depth == 120
+    # 60x plus a 700-deep pile: the optimistic mode is refused for this contig
+    base = synth.short_read_contig(L, 60, 64, max_live_assert=100_000)
+    rng = np.random.default_rng(65)
+    reads = [(int(p), "100M", 60, 30, 0, f"p{i}") for i, p in enumerate(np.sort(rng.integers(70_000, 70_050, size=700)))]
+    def rows(rec):
+        out = []
+        for i in range(rec.n):
+            cig = "".join(f"{int(c) >> 4}{'MIDNSHP=XB'[int(c) & 15]}" for c in rec.cigar[rec.cigar_off[i]:rec.cigar_off[i + 1]])
+            out.append((int(rec.pos[i]), cig, int(rec.mapq[i]), rec.qual[int(rec.qual_off[i]):int(rec.qual_off[i + 1])].tolist(), int(rec.flag[i]),
+                        bytes(rec.qname[rec.qname_off[i]:rec.qname_off[i + 1]]).decode()))
+        return out
+    sub = base.slice(int(np.searchsorted(base.pos, 60_000)), int(np.searchsorted(base.pos, 80_000)))
+    merged = sorted(rows(sub) + reads, key=lambda r: r[0])
+    o, _ = compare([("pile", 0, L, ref, ContigRecords.from_reads(merged))], dict(max_depth=100_000), tmp_path, "pile")
+    assert o["pile"]["dumps"][0].max() > 600

@@ -98,7 +98,6 @@ struct cl_ctx {
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
     bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
-    bool no_opt8 = false;            // a position deeper than 255 was met: 8-bit counter sets only up to 510 candidates
     bool has_long = false;           // some read has more than kLongOps CIGAR ops (k_read_prep_long needed)
     int32_t tid = 0;
     uint32_t contig_len = 0;
@@ -131,6 +130,7 @@ struct cl_ctx {
     DevBuf<uint8_t> d_state;         // per-position states: allocated and written for debug dumps only
     DevBuf<uint16_t> d_runs;         // per window kT entries: run starts inside the window
     DevBuf<uint8_t> d_first_state, d_last_state;
+    DevBuf<uint8_t> d_win_wide;      // per window: sticky "needs 16-bit counter fields" mark (k_pileup)
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
@@ -243,6 +243,8 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_runs.reserve(padded + 16));
     HIP_TRY(c, c->d_first_state.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_last_state.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win_wide.reserve(c->n_win + 1));
+    HIP_TRY(c, hipMemsetAsync(c->d_win_wide.p, 0, c->n_win + 1, c->stream));
     // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80)
     if (c->d_ref.cap < padded + 16 || c->ref_len_dev == UINT64_MAX) {
         HIP_TRY(c, c->d_ref.reserve(padded + 16));
@@ -311,7 +313,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
-    a.opt8 = c->no_opt8 ? 0u : 1u; a.err_flag = c->d_errflag.p;
+    a.win_wide = c->d_win_wide.p; a.err_flag = c->d_errflag.p;
     {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
         const char *ab = getenv("CL_ABLATE");
         a.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u;
@@ -393,7 +395,7 @@ void cl_destroy(cl_ctx *c)
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
     c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
     c->d_win_wlo.release(); c->d_win_wn.release(); c->d_wide_idx.release(); c->d_wide_pos.release();
-    c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release();
+    c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
     c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
     if (c->ev_made)
@@ -583,7 +585,7 @@ cl_status cl_contig_upload(cl_ctx *c)
     std::vector<uint8_t>().swap(c->h_qual);
     std::vector<uint32_t>().swap(c->h_cigar_off);
     std::vector<unsigned long long>().swap(c->h_qual_off);
-    c->uploaded = true; c->ran = false; c->deep = false; c->no_opt8 = false;
+    c->uploaded = true; c->ran = false; c->deep = false;
     return CL_OK;
 }
 
@@ -633,9 +635,8 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
             continue;
         }
         // a position deeper than 255 in a window that used the 8-bit counter sets beyond their safe
-        // candidate count: redo with the 16-bit fields for such windows
-        if ((c->h_sum.err & kNeedWide8) && !c->no_opt8 && !c->deep) {
-            c->no_opt8 = true;
+        // candidate count: the kernel marked those windows, run again (they now use 16-bit fields)
+        if ((c->h_sum.err & kNeedWide8) && !c->deep) {             // the marks are sticky: at most one more run raises it
             s = enqueue(c, false, nullptr, nullptr, nullptr);
             if (s != CL_OK) return s;
             continue;

@@ -425,7 +425,8 @@ struct PileupArgs {
     // debug dumps (nullptr in production)
     uint32_t *dbg_raw, *dbg_qc, *dbg_low;
     uint32_t ablate;              // timing experiments only (env CL_ABLATE); 0 in production
-    uint32_t opt8;                // 1: 8-bit counter sets also for windows with more than 510 candidates (see k_pileup)
+    uint8_t  *win_wide;           // per window: 1 = a position deeper than 255 was seen here, use 16-bit fields (sticky
+                                  // for the resident contig; set by k_pileup itself, see mode8 below)
     uint32_t *err_flag;           // kNeedWide8 is raised here
 };
 
@@ -634,8 +635,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     // already has ~515 candidates per window) they still cannot while no position is covered by more than
     // 255 reads -- a byte counts reads of one set covering its position -- so the 8-bit sets are used
     // optimistically and the window's maximum raw depth, known in the final phase, is the check: beyond
-    // 255 the kernel raises kNeedWide8 and the host re-runs the contig with opt8 = 0.
-    const bool mode8 = !DEEP && (n_cand <= 510u || a.opt8 != 0u);
+    // 255 the kernel marks the window in win_wide, raises kNeedWide8, and the host runs the contig again:
+    // marked windows then use the 16-bit fields.
+    const bool mode8 = !DEEP && (n_cand <= 510u || a.win_wide[w] == 0);
 
     // ---- the pass over the reads ----
     uint32_t sq32 = 0;                              // sum of passing qualities handled by this lane
@@ -1126,7 +1128,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
         wp.max_raw = m;
         a.winpart[w] = wp;
-        if (!DEEP && mode8 && n_cand > 510u && m > 255u) atomicOr(a.err_flag, kNeedWide8);
+        if (!DEEP && mode8 && n_cand > 510u && m > 255u) { a.win_wide[w] = 1; atomicOr(a.err_flag, kNeedWide8); }
     }
 }
 

@@ -314,6 +314,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
     a.win_wide = c->d_win_wide.p; a.err_flag = c->d_errflag.p;
+    a.upl = (c->n_reads && c->n_qual <= 128ull * c->n_reads) ? 2u : 3u;   // by the mean read length
     {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
         const char *ab = getenv("CL_ABLATE");
         a.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u;

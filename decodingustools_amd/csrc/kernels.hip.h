@@ -425,6 +425,7 @@ struct PileupArgs {
     // debug dumps (nullptr in production)
     uint32_t *dbg_raw, *dbg_qc, *dbg_low;
     uint32_t ablate;              // timing experiments only (env CL_ABLATE); 0 in production
+    uint32_t upl;                 // quality units per lane and trip in the consume loop: 2 for reads of up to ~128 bases, else 3
     uint8_t  *win_wide;           // per window: 1 = a position deeper than 255 was seen here, use 16-bit fields (sticky
                                   // for the resident contig; set by k_pileup itself, see mode8 below)
     uint32_t *err_flag;           // kNeedWide8 is raised here
@@ -649,25 +650,28 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     // up), i.e. concurrently active quads are Q entries (~4Q reads) apart.  Three units per lane and
     // trip: u, u+4, u+8; a unit past the end is clamped onto the last one and gets an empty mask.
     // MODE 0: 8-bit two-set counters, 1: 16-bit fields, 2: 32-bit words (DEEP)
-    auto consume = [&](auto mode_tag, uint32_t n_use) {
+    // UPL units per lane and trip: 3 (12 unit slots per quad: fits a 150-base read) or 2 (8 slots: reads of
+    // up to ~128 bases would leave a third of the 12 empty)
+    auto consume = [&](auto mode_tag, auto upl_tag, uint32_t n_use) {
         constexpr int MODE = decltype(mode_tag)::value;
+        constexpr int UPL = decltype(upl_tag)::value;
         const uint32_t Q = (n_use + 15u) >> 4;
         for (uint32_t i = 0; i < Q; ++i) {
             const uint32_t idx = quad * Q + i;
             uint2 d = make_uint2(0u, 0u);
             if (idx < n_use) d = list[idx];
             const SegView sv = seg_view(d, ql);
-            for (uint32_t u = sv.ub; u <= sv.u1; u += 12u) {
-                Q16 v[3];
-                uint32_t uu[3];
+            for (uint32_t u = sv.ub; u <= sv.u1; u += 4u * UPL) {
+                Q16 v[UPL];
+                uint32_t uu[UPL];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < UPL; ++j) {
                     const uint32_t un = u + 4u * j;
                     uu[j] = un < sv.u1 ? un : sv.u1;
                     __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
                 }
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
+                for (int j = 0; j < UPL; ++j) {
                     const uint32_t ps = uu[j] << 4;
                     const uint32_t vs = sv.srel > ps ? sv.srel - ps : 0u;
                     uint32_t ve = (sv.trel - ps) < 16u ? (sv.trel - ps) : 16u;
@@ -683,9 +687,10 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     };
     auto consume_list = [&](uint32_t n_use) {
         if (a.ablate & 1u) return;
-        if (DEEP) consume(std::integral_constant<int, 2>{}, n_use);
-        else if (mode8) consume(std::integral_constant<int, 0>{}, n_use);
-        else consume(std::integral_constant<int, 1>{}, n_use);
+        using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+        if (DEEP) consume(std::integral_constant<int, 2>{}, I3{}, n_use);
+        else if (mode8) { if (a.upl == 2u) consume(std::integral_constant<int, 0>{}, I2{}, n_use); else consume(std::integral_constant<int, 0>{}, I3{}, n_use); }
+        else consume(std::integral_constant<int, 1>{}, I3{}, n_use);
     };
     for (uint32_t base = 0; base < ((a.ablate & 2u) ? 0u : n_cand); base += kBlock) {
         const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets

@@ -12,7 +12,7 @@ depth = float(os.environ.get("KB_DEPTH", 30))
 ablates = [int(x, 0) for x in os.environ.get("KB_ABLATES", "0").split(",")]
 steps = int(os.environ.get("KB_STEPS", 10))
 seed = synth.seed_for(2, 20)
-rec = synth.short_read_contig(L, depth, seed)
+rec = synth.short_read_contig(L, depth, seed, read_len=int(os.environ.get('KB_READLEN', 150)))
 ref = synth.make_reference(L, seed)
 opt = CallableOptions()
 eng = Engine(opt, 0)

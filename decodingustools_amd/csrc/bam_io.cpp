@@ -180,7 +180,10 @@ struct BlockStream {
     RawBuf<uint8_t> buf;              // inflated bytes; [cur, buf.n) not yet consumed
     size_t cur = 0;
     RawBuf<uint8_t> cbuf;
-    size_t batch = 32u << 20;         // compressed bytes per fill
+    // compressed bytes per fill: small right after a seek (a contig of a few reads must not cost a 32 MB
+    // read + inflate), doubling up to 32 MB while the same stretch keeps being read
+    static constexpr size_t kBatchMin = 256u << 10, kBatchMax = 32u << 20;
+    size_t batch = kBatchMin;
     double t_read = 0, t_inflate = 0; // DUT_TIMING
     // offsets in buf at which the inflated blocks begin (ascending; htslib never lets a record straddle
     // two BGZF blocks, so in its files every block start is a record start and blocks can be walked
@@ -193,6 +196,7 @@ struct BlockStream {
         next_coff = voff >> 16; skip = (size_t)(voff & 0xFFFF);
         buf.clear(); cur = 0; eof = false; err.clear(); valid = true;
         bstart.clear(); aligned = true;
+        batch = kBatchMin;
     }
     // appends the next batch of blocks to buf (after dropping the consumed prefix); false at EOF or on error
     bool fill()
@@ -243,6 +247,7 @@ struct BlockStream {
             batch *= 2;                                   // a block larger than the batch cannot happen (<= 64 KiB); be safe
         }
         next_coff += used;
+        if (batch < kBatchMax) batch *= 2;
         const size_t base = buf.n;
         if (!buf.reserve(base + out_total)) { err = "out of memory"; return false; }
         buf.n = base + out_total;

@@ -621,10 +621,13 @@ def test_operation_parallel_variant_with_16bit_and_32bit_counters(tmp_path):
     fields) and with more than 32 767 (32-bit re-run)."""
     L = 12_000
     ref = synth.make_reference(L, 41)
-    rec = _stacked_multi_op_reads(2500, 3000, 5000, 42, long_every=7)
+    rec = _stacked_multi_op_reads(2500, 3000, 3900, 42, long_every=7)     # deeper than 255: the 16-bit fields are needed
     assert rec.cigar.shape[0] >= 8 * rec.n
     o, _ = compare([("m16", 0, L, ref, rec)], dict(max_depth=100_000, min_depth_for_low_mapq=10), tmp_path, "long16")
-    assert o["m16"]["dumps"][0].max() > 200
+    assert o["m16"]["dumps"][0].max() > 300
+    rec8 = _stacked_multi_op_reads(2500, 3000, 9000, 44, long_every=7)    # > 510 candidates per window, depth < 255: 8-bit sets
+    o, _ = compare([("m8w", 0, L, ref, rec8)], dict(max_depth=100_000), tmp_path, "long8w")
+    assert 60 < o["m8w"]["dumps"][0].max() < 255
     # the AND form of the byte-parallel quality test (thresholds above 128) in this variant
     compare([("m16q", 0, L, ref, rec)], dict(max_depth=100_000, min_base_quality=200, min_depth=1), tmp_path, "long16q")
     compare([("m8", 0, L, ref, rec.slice(0, 300))], dict(max_depth=100_000, min_base_quality=21, min_depth=1), tmp_path, "long8")

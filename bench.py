@@ -100,6 +100,11 @@ def main():
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
+    # the native pieces are (re)built before anything touches the GPU: a process that has initialised the
+    # GPU must not start compilers (normally nothing is stale and this returns at once; every rank checks)
+    import __graft_entry__ as ge
+    ge.build()
+
     import torch
     import torch.distributed as dist
     n_dev = torch.cuda.device_count()
@@ -113,11 +118,6 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    import __graft_entry__ as ge
-    if rank == 0:
-        ge.build()
-    if world > 1:
-        dist.barrier()
     from decodingustools_amd import (CallableOptions, CallableProfiler, ContigProfiler, Engine,
                                      process_single_contig, synth)
 

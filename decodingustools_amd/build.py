@@ -40,20 +40,21 @@ def build(force=False, verbose=False):
     if not os.path.exists(hipcc):
         raise RuntimeError("hipcc not found: cannot build libcallable_hip.so")
     os.makedirs(LIBDIR, exist_ok=True)
+    tmp = f".tmp{os.getpid()}"                    # several ranks may find the library stale at once
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-Wall", "-Wno-unused-function"] + SOURCES + ["-lz", "-ldl", "-o", LIB + ".tmp"]
+           "-Wall", "-Wno-unused-function"] + SOURCES + ["-lz", "-ldl", "-o", LIB + tmp]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
-    os.replace(LIB + ".tmp", LIB)
+    os.replace(LIB + tmp, LIB)
     # the `coverage` command line tool, linked against the library beside it
-    cmd = [hipcc, "-O2", "-std=c++17", CLI_SRC, "-L" + LIBDIR, "-lcallable_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI + ".tmp"]
+    cmd = [hipcc, "-O2", "-std=c++17", CLI_SRC, "-L" + LIBDIR, "-lcallable_hip", "-Wl,-rpath,$ORIGIN", "-o", CLI + tmp]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building dut-coverage failed:\n" + r.stdout + r.stderr)
-    os.replace(CLI + ".tmp", CLI)
+    os.replace(CLI + tmp, CLI)
     return LIB
 
 

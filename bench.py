@@ -100,13 +100,17 @@ def main():
         log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-    # the native pieces are (re)built before anything touches the GPU: a process that has initialised the
-    # GPU must not start compilers (normally nothing is stale and this returns at once; every rank checks)
-    import __graft_entry__ as ge
-    ge.build()
-
+    # torch first: it brings its own HIP runtime, and the engine's library must resolve against that one
+    # (loading the engine before torch leaves the process with two runtimes and no usable device)
     import torch
     import torch.distributed as dist
+    # the native pieces are (re)built before anything initialises the GPU: a process that has must not
+    # start compilers (normally nothing is stale and this returns at once; every rank checks).  Compile
+    # only -- the library itself is loaded further down, after the device is set.
+    from decodingustools_amd import build as _native_build
+    _native_build.build()
+    import oracle
+    oracle.build()
     n_dev = torch.cuda.device_count()
     dev_id = local_rank % max(n_dev, 1)          # one GPU per rank on a real node
     torch.cuda.set_device(dev_id)

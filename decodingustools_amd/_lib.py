@@ -210,6 +210,15 @@ def load():
     global _LIB
     if _LIB is not None:
         return _LIB
+    # PyTorch ships its own HIP runtime; whichever of two runtimes initialises second in a process finds
+    # no device.  With torch imported first this library resolves against torch's runtime and both work,
+    # in either order of use -- so import it here when it is installed (DUT_NO_TORCH_PRELOAD=1 skips this).
+    import sys
+    if "torch" not in sys.modules and os.environ.get("DUT_NO_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
     path = lib_path()
     if not os.path.exists(path):
         raise RuntimeError(

@@ -106,24 +106,8 @@ __device__ __forceinline__ bool op_del(uint32_t op) { return op == 2u || op == 3
 __device__ __forceinline__ bool op_ins(uint32_t op) { return op == 1u || op == 4u; }
 
 // ---------------------------------------------------------------------------------------------
-// wave / block reductions (wave64)
+// wave / block reductions and scans (wave64)
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
-{
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v)
-{
-    for (int o = 32; o > 0; o >>= 1) { uint32_t t = __shfl_down(v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
-{
-    for (int o = 32; o > 0; o >>= 1) v |= __shfl_down(v, o, 64);
-    return v;
-}
-
 // Inclusive prefix sum over the 64 lanes with DPP row shifts / row broadcasts (VALU only; __shfl_up
 // compiles to ds_bpermute_b32, an LDS-pipe instruction with far higher latency).
 //   row_shr:1,2,4,8 (0x111..0x118, zero fill) scan each row of 16 lanes,
@@ -155,6 +139,26 @@ __device__ __forceinline__ uint32_t dpp_wave_max_u32(uint32_t v)
 __device__ __forceinline__ uint32_t dpp_wave_sum_u32(uint32_t v)
 {
     return (uint32_t)__builtin_amdgcn_readlane((int)dpp_incl_scan_u32(v), 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) { return dpp_wave_max_u32(v); }
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit sum over the wave, in every lane: three exact 32-bit DPP sums over 24/24/16-bit limbs
+// (64 lanes x 2^24 < 2^32), instead of twelve ds_bpermute round trips
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+    const unsigned long long a = dpp_wave_sum_u32((uint32_t)v & 0xFFFFFFu);
+    const unsigned long long b = dpp_wave_sum_u32((uint32_t)(v >> 24) & 0xFFFFFFu);
+    const unsigned long long c = dpp_wave_sum_u32((uint32_t)(v >> 48));
+    return a + (b << 24) + (c << 48);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1172,8 +1176,7 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
         acc[6] = wp.n_cov; acc[7] = wp.sum_qc; acc[8] = wp.sum_q;
         maxraw = wp.max_raw;
     }
-    uint32_t inc = c;
-    for (int o = 1; o < 64; o <<= 1) { uint32_t t = __shfl_up(inc, o, 64); if (lane >= o) inc += t; }
+    const uint32_t inc = dpp_incl_scan_u32(c);
     if (lane == 63) s_w[wv] = inc;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {

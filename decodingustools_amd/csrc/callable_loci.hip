@@ -124,9 +124,9 @@ struct cl_ctx {
     DevBuf<uint8_t> d_qual;
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
-    DevBuf<uint32_t> d_win_lo, d_win_hi, d_win_off, d_win_wlo, d_win_wn, d_wide_idx;
+    DevBuf<uint32_t> d_win_off, d_wide_idx;
+    DevBuf<WinMeta> d_win;
     DevBuf<int32_t> d_wide_pos;
-    DevBuf<unsigned long long> d_win_q0;
     DevBuf<uint8_t> d_state;         // per-position states: allocated and written for debug dumps only
     DevBuf<uint16_t> d_runs;         // per window kT entries: run starts inside the window
     DevBuf<uint8_t> d_first_state, d_last_state;
@@ -134,7 +134,7 @@ struct cl_ctx {
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
-    DevBuf<uint32_t> d_errflag;        // [0] error bits of k_window_bounds, [1] number of long reads
+    DevBuf<uint32_t> d_errflag;        // [0] error bits of window_bounds, [1] number of long reads
     DevBuf<uint32_t> d_long_list, d_ck_x, d_ck_y;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
@@ -215,9 +215,12 @@ cl_status harvest_events(cl_ctx *c)
 {
     for (int s = 0; s < c->ev_pending; ++s) {
         HIP_TRY(c, hipEventSynchronize(c->ev[s][CL_K_COUNT]));
+        // events 0,1,3,4: the window bounds run inside the prep launch (CL_K_BOUNDS stays 0; ev[2] is unused)
+        static const int from[CL_K_COUNT] = {0, -1, 1, 3}, to[CL_K_COUNT] = {1, -1, 3, 4};
         for (int i = 0; i < CL_K_COUNT; ++i) {
+            if (from[i] < 0) continue;
             float t = 0.f;
-            HIP_TRY(c, hipEventElapsedTime(&t, c->ev[s][i], c->ev[s][i + 1]));
+            HIP_TRY(c, hipEventElapsedTime(&t, c->ev[s][from[i]], c->ev[s][to[i]]));
             c->ms[i] += t;
         }
         c->n_runs += 1;
@@ -232,12 +235,8 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     c->extent = extent;
     c->n_win = (uint32_t)(((uint64_t)extent + kT - 1) / kT);
     const size_t padded = (size_t)c->n_win * kT;
-    HIP_TRY(c, c->d_win_lo.reserve(c->n_win + 1));
-    HIP_TRY(c, c->d_win_hi.reserve(c->n_win + 1));
-    HIP_TRY(c, c->d_win_wlo.reserve(c->n_win + 1));
-    HIP_TRY(c, c->d_win_wn.reserve(c->n_win + 1));
+    HIP_TRY(c, c->d_win.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_off.reserve(c->n_win + 1));
-    HIP_TRY(c, c->d_win_q0.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_winpart.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_fin.reserve(c->n_win / kFinBlock + 2));
     HIP_TRY(c, c->d_runs.reserve(padded + 16));
@@ -261,7 +260,7 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     const uint32_t grid = a.n_win8 * 8u;
     if (grid == 0) return;
     // the byte-parallel threshold test has a shorter form when min_base_quality <= 128;
-    // the 32-bit counter variant is used only after k_window_bounds asked for it (kNeedDeep)
+    // the 32-bit counter variant is used only after window_bounds asked for it (kNeedDeep)
     const bool orf = c->opt.min_base_quality <= 128;
     // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel variant
     const bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
@@ -292,22 +291,22 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
 
     HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
-                       c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p);
+    // the window bounds (binary searches, latency bound) ride in the first workgroups of the prep launch
+    BoundsArgs B;
+    B.span_n = c->span_n; B.span_w = c->span_w; B.wide_pos = c->d_wide_pos.p; B.wide_idx = c->d_wide_idx.p;
+    B.n_wide = c->n_wide; B.T = kT; B.n_win = c->n_win;
+    B.win = c->d_win.p; B.err_flag = c->d_errflag.p;
+    B.n_blocks = (c->n_win + kBlock - 1) / kBlock;
+    hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks + B.n_blocks), dim3(kBlock), 0, c->stream, R, c->dopt,
+                       c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p, B);
     if (c->has_long)
         hipLaunchKernelGGL(k_read_prep_long, dim3(kLongBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
                            c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p, c->d_ck_x.p, c->d_ck_y.p);
     const uint32_t n_parts = c->has_long ? (uint32_t)kPrepParts : (uint32_t)kPrepBlocks;
     if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-    if (c->n_win) {
-        hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0,
-                           c->stream, R, c->span_n, c->span_w, c->d_wide_pos.p, c->d_wide_idx.p, c->n_wide, kT, c->n_win,
-                           c->d_win_lo.p, c->d_win_hi.p, c->d_win_wlo.p, c->d_win_wn.p, c->d_win_q0.p, c->d_errflag.p);
-    }
-    if (prof) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     PileupArgs a;
-    a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win_lo = c->d_win_lo.p; a.win_hi = c->d_win_hi.p; a.win_q0 = c->d_win_q0.p;
-    a.win_wlo = c->d_win_wlo.p; a.win_wn = c->d_win_wn.p; a.wide_idx = c->d_wide_idx.p;
+    a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win = c->d_win.p;
+    a.wide_idx = c->d_wide_idx.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
     if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
@@ -394,8 +393,8 @@ void cl_destroy(cl_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
-    c->d_win_q0.release(); c->d_win_lo.release(); c->d_win_hi.release(); c->d_win_off.release(); c->d_state.release();
-    c->d_win_wlo.release(); c->d_win_wn.release(); c->d_wide_idx.release(); c->d_wide_pos.release();
+    c->d_win.release(); c->d_win_off.release(); c->d_state.release();
+    c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
     c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();

@@ -4,7 +4,7 @@
 //
 //   k_read_prep      per read: CIGAR walk -> end[r]; block partials of the per-read separable
 //                    sums (contig_profiler.rs:74,79-82 via SURVEY 8a-7), max span, max end
-//   k_window_bounds  per window of T reference positions: [lo,hi) range of reads that can touch it
+//   window_bounds    per window of T reference positions: [lo,hi) range of reads that can touch it
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
 //                    (callable_profiler.rs:100-116) and reduced to the window's run list (the
@@ -162,6 +162,66 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 }
 
 // ---------------------------------------------------------------------------------------------
+// window_bounds: thread per window (the first workgroups of the k_read_prep launch: the searches are
+// latency bound and hide under the bandwidth-bound CIGAR pass); the candidate reads of every window (binary searches over the
+// sorted positions).
+// ---------------------------------------------------------------------------------------------
+// (A K-ary search that loads K-1 pivots per round was tried for fewer dependent loads: K = 4 and 16 were
+// both slower than this binary search, whose first dozen levels hit the same few lines for every thread.)
+__device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t n, long long key)
+{
+    uint32_t lo = 0, hi = n;                       // first r with pos[r] >= key
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// what k_pileup needs to start on a window: one 32-byte record, one scalar load
+struct __attribute__((aligned(32))) WinMeta {
+    uint32_t lo, hi;                   // ordinary candidates: reads [lo, hi)
+    uint32_t wlo, wn;                  // wide candidates: wide_idx[wlo .. wlo+wn)
+    unsigned long long q0;             // qual_off of the window's first candidate read
+    uint32_t pad[2];
+};
+
+struct BoundsArgs {
+    uint32_t span_n, span_w;
+    const int32_t *wide_pos;
+    const uint32_t *wide_idx;
+    uint32_t n_wide, T, n_win;
+    WinMeta *win;
+    uint32_t *err_flag;
+    uint32_t n_blocks;                 // the first n_blocks workgroups of the k_read_prep launch do the bounds
+};
+
+__device__ __forceinline__ void window_bounds(const Reads &R, const BoundsArgs &B, uint32_t w)
+{
+    const uint32_t span_n = B.span_n, span_w = B.span_w, n_wide = B.n_wide, T = B.T, n_win = B.n_win;
+    const int32_t *__restrict__ wide_pos = B.wide_pos;
+    const uint32_t *__restrict__ wide_idx = B.wide_idx;
+    uint32_t *__restrict__ err_flag = B.err_flag;
+    if (w >= n_win) return;
+    const long long W = (long long)w * T;
+    const uint32_t lo = lower_bound_pos(R.pos, R.n, W - (long long)span_n + 1);
+    const uint32_t hi = lower_bound_pos(R.pos, R.n, W + (long long)T);
+    uint32_t wlo = 0, wn = 0;
+    if (n_wide) {
+        wlo = lower_bound_pos(wide_pos, n_wide, W - (long long)span_w + 1);
+        wn = lower_bound_pos(wide_pos, n_wide, W - (long long)span_n + 1) - wlo;
+    }
+    const uint32_t first = wn ? wide_idx[wlo] : lo;     // lo <= n: the offsets array has n+1 entries
+    WinMeta m;
+    m.lo = lo; m.hi = hi; m.wlo = wlo; m.wn = wn; m.q0 = R.qual_off[first]; m.pad[0] = 0; m.pad[1] = 0;
+    B.win[w] = m;
+    // k_pileup addresses the quality bytes of a window with 32-bit offsets
+    if (hi > first && R.qual_off[hi] - R.qual_off[first] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
+    // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
+    if ((hi - lo) + wn > 32767u) atomicOr(err_flag, kNeedDeep);
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_read_prep: one thread per read (grid-stride).
 //   end[r] = pos + bam_cigar2rlen  (the pileup node span)
 //   sum_reflen       = sum over reads of reflen                 == summed_coverage
@@ -171,16 +231,20 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t *__restrict__ end_out,
                                                        PrepPartial *__restrict__ part,
                                                        uint32_t *__restrict__ long_cnt,
-                                                       uint32_t *__restrict__ long_list)
+                                                       uint32_t *__restrict__ long_list, BoundsArgs B)
 {
+    // (measured on one box: bounds as its own kernel after this one 0.489 ms per step, as the last
+    // workgroups 0.488, as the first 0.479)
+    if (blockIdx.x < B.n_blocks) { window_bounds(R, B, blockIdx.x * kBlock + threadIdx.x); return; }
+    const uint32_t bid = blockIdx.x - B.n_blocks;
     __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
     __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
     unsigned long long sum_len = 0, sum_mq = 0;
     uint32_t max_span = 0, max_end = 0, err = 0;
     // four reads per thread and trip: all their loads are issued before any is used
     constexpr int U = 4;
-    const uint32_t stride = gridDim.x * kBlock;
-    for (uint32_t r0 = blockIdx.x * kBlock + threadIdx.x; r0 < R.n; r0 += U * stride) {
+    const uint32_t stride = kPrepBlocks * kBlock;
+    for (uint32_t r0 = bid * kBlock + threadIdx.x; r0 < R.n; r0 += U * stride) {
         uint32_t k0[U], k1[U], ps[U], mq[U], c0[U];
         Q16 cw[U];                                   // the first four CIGAR words of each read, one 16-byte load
         bool in[U];
@@ -246,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
             p.max_end = s_d[i] > p.max_end ? s_d[i] : p.max_end;
             p.err |= s_e[i];
         }
-        part[blockIdx.x] = p;
+        part[bid] = p;
     }
 }
 
@@ -333,60 +397,6 @@ __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_window_bounds: thread per window; the candidate reads of every window (binary searches over the
-// sorted positions).
-// ---------------------------------------------------------------------------------------------
-// (A K-ary search that loads K-1 pivots per round was tried for fewer dependent loads: K = 4 and 16 were
-// both slower than this binary search, whose first dozen levels hit the same few lines for every thread.)
-__device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t n, long long key)
-{
-    uint32_t lo = 0, hi = n;                       // first r with pos[r] >= key
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-__global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, uint32_t span_n, uint32_t span_w,
-                                                           const int32_t *__restrict__ wide_pos,
-                                                           const uint32_t *__restrict__ wide_idx, uint32_t n_wide,
-                                                           uint32_t T, uint32_t n_win,
-                                                           uint32_t *__restrict__ win_lo,
-                                                           uint32_t *__restrict__ win_hi,
-                                                           uint32_t *__restrict__ win_wlo,
-                                                           uint32_t *__restrict__ win_wn,
-                                                           unsigned long long *__restrict__ win_q0,
-                                                           uint32_t *__restrict__ err_flag)
-{
-    // span_n: longest reference span among the reads of ordinary span (<= kWideSpan), span_w: among the
-    // wide ones (both from the host, which sees every CIGAR at cl_push_reads).  A read can touch window
-    // [W, W+T) only if pos < W+T and pos + span > W: the ordinary candidates are the reads [lo, hi) with
-    // pos in (W - span_n, W + T); wide reads that start before that range are looked up in the (short)
-    // list of wide reads, pos in (W - span_w, W - span_n].
-    const uint32_t w = blockIdx.x * kBlock + threadIdx.x;
-    if (w >= n_win) return;
-    const long long W = (long long)w * T;
-    const uint32_t lo = lower_bound_pos(R.pos, R.n, W - (long long)span_n + 1);
-    const uint32_t hi = lower_bound_pos(R.pos, R.n, W + (long long)T);
-    uint32_t wlo = 0, wn = 0;
-    if (n_wide) {
-        wlo = lower_bound_pos(wide_pos, n_wide, W - (long long)span_w + 1);
-        wn = lower_bound_pos(wide_pos, n_wide, W - (long long)span_n + 1) - wlo;
-    }
-    win_lo[w] = lo;
-    win_hi[w] = hi;
-    win_wlo[w] = wlo;
-    win_wn[w] = wn;
-    const uint32_t first = wn ? wide_idx[wlo] : lo;     // lo <= n: the offsets array has n+1 entries
-    win_q0[w] = R.qual_off[first];
-    // k_pileup addresses the quality bytes of a window with 32-bit offsets
-    if (hi > first && R.qual_off[hi] - R.qual_off[first] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
-    // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
-    if ((hi - lo) + wn > 32767u) atomicOr(err_flag, kNeedDeep);
-}
-
-// ---------------------------------------------------------------------------------------------
 // byte-parallel threshold test.  x holds 4 quality bytes; returns 0x80 in each byte with
 // quality >= min_base_quality (mod.rs:33).  Constants from make_ge_consts():
 //   T == 0        : always                   ge_add = 0x80.., OR form
@@ -412,10 +422,8 @@ struct PileupArgs {
     Reads R;
     Opts o;
     const uint32_t *end;          // per read
-    const uint32_t *win_lo, *win_hi;
-    const uint32_t *win_wlo, *win_wn;   // the window's wide candidates: wide_idx[wlo .. wlo+wn)
+    const WinMeta *win;
     const uint32_t *wide_idx;           // read indices of the wide reads, ascending
-    const unsigned long long *win_q0;   // qual_off of the window's first candidate read
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (k_read_prep_long)
@@ -462,7 +470,7 @@ struct PileupArgs {
 // its own M/=/X run (runs longer than 64 bases go through the list and the quad loop).
 //
 // DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window has <= 32767 candidates
-// (otherwise k_window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one
+// (otherwise window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one
 // 32-bit counter per position).
 // ---------------------------------------------------------------------------------------------
 template <bool ORF>
@@ -564,7 +572,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
     // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
     // subtraction of 1 from the whole word) never borrows from the high half; exact while the window
-    // is touched by < 32768 reads (k_window_bounds raises kNeedDeep beyond that).
+    // is touched by < 32768 reads (window_bounds raises kNeedDeep beyond that).
     constexpr int kDiffWords = DEEP ? T : T / 2;
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_low[kDiffWords];
@@ -593,14 +601,15 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     const uint32_t lane = tid & 63u, wv = tid >> 6;
     const uint32_t p0 = W + tid * PER;
 
-    const uint32_t lo = a.win_lo[w], hi = a.win_hi[w];
+    const WinMeta wm = a.win[w];
+    const uint32_t lo = wm.lo, hi = wm.hi;
     // candidates: first the wn wide reads that start before read lo, then the reads [lo, hi)
-    const uint32_t wlo = a.win_wlo[w], wn = a.win_wn[w];
+    const uint32_t wlo = wm.wlo, wn = wm.wn;
     const uint32_t n_cand = wn + (hi - lo);
     // all quality bytes of the candidates lie within 2^32 of the first one's (checked by
-    // k_window_bounds), so they are addressed by 32-bit offsets from a uniform base.  The base
+    // window_bounds), so they are addressed by 32-bit offsets from a uniform base.  The base
     // sits kQualPad bytes low so that the offset of a unit start never goes negative.
-    const unsigned long long qwin = a.win_q0[w];
+    const unsigned long long qwin = wm.q0;
     const uint8_t *qbase = a.R.qual + qwin - kQualPad;
 
     // reference bytes of this thread's positions: needed last, requested first

@@ -148,7 +148,8 @@ cl_status cl_device_summary(cl_ctx *ctx, void **dev_ptr, size_t *bytes);
 enum { CL_K_PREP = 0, CL_K_BOUNDS = 1, CL_K_PILEUP = 2, CL_K_RLE = 3, CL_K_COUNT = 4 };
 /* When on, every cl_contig_run brackets each kernel group with hipEvents on the stream. */
 cl_status cl_set_profiling(cl_ctx *ctx, int on);
-/* Accumulated milliseconds per kernel group and number of runs since the last reset. */
+/* Accumulated milliseconds per kernel group and number of runs since the last reset.  The window
+ * bounds ride in the prep launch: their time is part of CL_K_PREP and CL_K_BOUNDS reads 0. */
 cl_status cl_get_kernel_ms(cl_ctx *ctx, double ms[CL_K_COUNT], uint64_t *n_runs);
 cl_status cl_reset_kernel_ms(cl_ctx *ctx);
 /* Bytes of the resident inputs the pileup kernel must read at least once and of the state

@@ -289,7 +289,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
     R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
 
-    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
+    // d_errflag is zero here: cleared at upload, and by the summary workgroup at the end of every run
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     // the window bounds (binary searches, latency bound) ride in the first workgroups of the prep launch
     BoundsArgs B;
@@ -572,6 +572,7 @@ cl_status cl_contig_upload(cl_ctx *c)
     }
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_len_dev = UINT64_MAX;            // force the reference to be re-laid out
     cl_status s = size_for_extent(c, c->contig_len);

@@ -1211,7 +1211,7 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
 // one workgroup of kBlock threads (the extra, last workgroup of k_rle_write).
 __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
                                             const PrepPartial *__restrict__ prep, uint32_t n_prep,
-                                            uint32_t extent, const uint32_t *__restrict__ err_flag,
+                                            uint32_t extent, uint32_t *__restrict__ err_flag,
                                             DevSummary *__restrict__ out)
 {
     __shared__ unsigned long long s_red[12][kBlock / 64];
@@ -1252,7 +1252,9 @@ __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, 
         out->max_raw_depth = mr;
         out->n_intervals = tot[11];
         out->max_end = me;
-        out->err = er | *err_flag;
+        out->err = er | err_flag[0];
+        // every kernel of the run is done with the flags: clear them for the next run (saves a memset launch)
+        err_flag[0] = 0; err_flag[1] = 0;
     }
 }
 
@@ -1268,7 +1270,7 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
                                                        const uint32_t *__restrict__ win_off,
                                                        const FinPartial *__restrict__ fin, uint32_t n_fin,
                                                        const PrepPartial *__restrict__ prep, uint32_t n_prep,
-                                                       const uint32_t *__restrict__ err_flag,
+                                                       uint32_t *__restrict__ err_flag,
                                                        DevSummary *__restrict__ summary,
                                                        uint32_t n_win, uint32_t extent,
                                                        Interval *__restrict__ iv, uint32_t iv_cap)

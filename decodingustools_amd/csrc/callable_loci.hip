@@ -264,14 +264,13 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     const bool orf = c->opt.min_base_quality <= 128;
     // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel variant
     const bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
+    // ... with short runs (operations average < 32 bases: an indel every few bases): four operations per lane
+    const bool lng4 = lng && c->n_qual < 32ull * c->n_cigar;
 #define CL_LAUNCH(ORF_, DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, ORF_, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
-    if (!c->deep) {
-        if (lng) { if (orf) CL_LAUNCH(true, false, true); else CL_LAUNCH(false, false, true); }
-        else { if (orf) CL_LAUNCH(true, false, false); else CL_LAUNCH(false, false, false); }
-    } else {
-        if (lng) { if (orf) CL_LAUNCH(true, true, true); else CL_LAUNCH(false, true, true); }
-        else { if (orf) CL_LAUNCH(true, true, false); else CL_LAUNCH(false, true, false); }
-    }
+#define CL_LAUNCH_L(ORF_, DEEP_) do { if (lng4) CL_LAUNCH(ORF_, DEEP_, 4); else if (lng) CL_LAUNCH(ORF_, DEEP_, 1); else CL_LAUNCH(ORF_, DEEP_, 0); } while (0)
+    if (!c->deep) { if (orf) CL_LAUNCH_L(true, false); else CL_LAUNCH_L(false, false); }
+    else { if (orf) CL_LAUNCH_L(true, true); else CL_LAUNCH_L(false, true); }
+#undef CL_LAUNCH_L
 #undef CL_LAUNCH
 }
 

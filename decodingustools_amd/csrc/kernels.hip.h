@@ -464,7 +464,7 @@ struct PileupArgs {
 // Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave) so that the segments a
 // wave's 16 quads work on at the same time are ~16 reads apart and rarely share a counter word.
 //
-// LONG = true (contigs with >= 8 CIGAR operations per read on average): the lane-serial CIGAR walk is
+// LONG = 1 or 4 (contigs with >= 8 CIGAR operations per read on average): the lane-serial CIGAR walk is
 // replaced by an operation-parallel one -- live reads are compacted, a wave takes 64 operations of a
 // read at a time, two DPP scans give every operation its reference / query start, each lane consumes
 // its own M/=/X run (runs longer than 64 bases go through the list and the quad loop).
@@ -560,7 +560,7 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 #ifndef CL_MINWAVES
 #define CL_MINWAVES 8
 #endif
-template <int T, bool DEBUG, bool ORF, bool DEEP, bool LONG>
+template <int T, bool DEBUG, bool ORF, bool DEEP, int LONG>
 __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
@@ -776,76 +776,143 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 uint32_t rk = A.y, rx = A.z, ry = A.w;
                 const uint32_t rk1 = B.x, rqrel = B.y, rqlen = B.z;
                 const uint32_t rset = (A.x & 1u) << 30;
-                uint32_t cw_next = (rk + lane) < rk1 ? a.R.cigar[rk + lane] : 5u;   // beyond the read: H, advances nothing
+                // kOpl = LONG consecutive operations per lane and trip.  4 (one 16-byte load) for contigs whose
+                // operations average < 32 bases: with an indel every ~15 bases half the operations carry no
+                // bases, so a lane's four hold about two runs; all their quality loads are issued before the
+                // first is consumed, and a trip covers 256 operations (fewer trips = fewer exposed load
+                // latencies, the limiter of that shape).  1 for long match runs (HiFi: every run goes through
+                // the list anyway, and the 4-op form costs a wave of occupancy).
+                constexpr uint32_t kOpl = LONG ? (uint32_t)LONG : 1u;
+                auto load_ops = [&](uint32_t kb, uint32_t (&wd)[kOpl]) {
+                    const uint32_t kl = kb + kOpl * lane;
+                    if constexpr (kOpl == 1u) {
+                        wd[0] = kl < rk1 ? a.R.cigar[kl] : 5u;               // beyond the read: H, advances nothing
+                    } else {
+                        Q16 t;
+                        t.w[0] = 5u; t.w[1] = 5u; t.w[2] = 5u; t.w[3] = 5u;
+                        if (kl < rk1) __builtin_memcpy(&t, a.R.cigar + kl, 16);  // at most 12 bytes past the read's words
+#pragma unroll
+                        for (uint32_t j = 0; j < kOpl; ++j) wd[j] = (kl + j) < rk1 ? t.w[j] : 5u;
+                    }
+                };
+                auto unit = [&](const Q16 &v, uint32_t u, uint32_t srel, uint32_t trel) {
+                    const uint32_t ps = u << 4;
+                    const uint32_t vs = srel > ps ? srel - ps : 0u;
+                    const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                    const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                    const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                    if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
+                    else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                    else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                };
+                uint32_t cw_next[kOpl];
+                load_ops(rk, cw_next);
                 while (rk < rk1 && rx < Wend) {                      // wave-uniform
-                    const uint32_t cwl = cw_next;
-                    {   // the next 64 operations are requested before this block is scanned
-                        const uint32_t kn = rk + 64u + lane;
-                        cw_next = kn < rk1 ? a.R.cigar[kn] : 5u;
+                    uint32_t cwl[kOpl];
+#pragma unroll
+                    for (uint32_t j = 0; j < kOpl; ++j) cwl[j] = cw_next[j];
+                    load_ops(rk + 64u * kOpl, cw_next);              // the next block is requested before this one is scanned
+                    uint32_t ax[kOpl], ay[kOpl], tx = 0, ty = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < kOpl; ++j) {
+                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
+                        ax[j] = ((0x18Du >> op) & 1u) ? l : 0u;
+                        ay[j] = ((0x193u >> op) & 1u) ? l : 0u;
+                        tx += ax[j]; ty += ay[j];
                     }
-                    const uint32_t op = cwl & 15u, l = cwl >> 4;
-                    const bool ism = ((0x181u >> op) & 1u) != 0u;
-                    const uint32_t ax = ((0x18Du >> op) & 1u) ? l : 0u;
-                    const uint32_t ay = ((0x193u >> op) & 1u) ? l : 0u;
-                    const uint32_t ix = dpp_incl_scan_u32(ax), iy = dpp_incl_scan_u32(ay);
-                    const uint32_t xs = rx + (ix - ax), ys = ry + (iy - ay);
-                    const uint32_t xe = xs + ax;
-                    const uint32_t sp = xs > W ? xs : W;
-                    const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
-                    uint32_t tp = xe < Wend ? xe : Wend;
-                    tp = (xs + lq) < tp ? (xs + lq) : tp;
-                    const bool valid = ism && sp < tp && !(a.ablate & 1u);
-                    const uint32_t srel = sp - W, trel = tp - W;
-                    const bool big = valid && (trel - srel) > 64u;
-                    if (valid && !big) {
-                        const uint32_t qo = rqrel + ys + (sp - xs) + (uint32_t)kQualPad - srel;
-                        const uint32_t u0 = srel >> 4, u1 = (trel - 1u) >> 4;
-                        auto unit = [&](const Q16 &v, uint32_t u) {
-                            const uint32_t ps = u << 4;
-                            const uint32_t vs = srel > ps ? srel - ps : 0u;
-                            const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
-                            const uint4 ms = s_mstart[vs], me = s_mend[ve];
-                            const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
-                            if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
-                            else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                            else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                        };
-                        // the first two units of the run are requested together (a ~15-base run covers one or two)
-                        Q16 v0, v1;
-                        __builtin_memcpy(&v0, qbase + (qo + (u0 << 4)), 16);
-                        const uint32_t ub = u0 + 1u <= u1 ? u0 + 1u : u0;
-                        __builtin_memcpy(&v1, qbase + (qo + (ub << 4)), 16);
-                        unit(v0, u0);
-                        if (u0 + 1u <= u1) unit(v1, u0 + 1u);
-                        for (uint32_t u = u0 + 2u; u <= u1; ++u) {
+                    const uint32_t ix = dpp_incl_scan_u32(tx), iy = dpp_incl_scan_u32(ty);
+                    uint32_t xs = rx + (ix - tx), ys = ry + (iy - ty);
+                    // the lane's first two short runs (A, B) are consumed together below; a third or fourth
+                    // (rare: two indels in a row are rarer than M-indel-M) and runs > 64 bases at once
+                    uint32_t a_st = 0, a_q = 0, b_st = 0, b_q = 0, ns = 0;
+                    auto run_direct = [&](uint32_t sr, uint32_t tr, uint32_t q) {
+                        const uint32_t qb = q + (uint32_t)kQualPad - sr;
+                        for (uint32_t u = sr >> 4; u <= (tr - 1u) >> 4; ++u) {
                             Q16 v;
-                            __builtin_memcpy(&v, qbase + (qo + (u << 4)), 16);
-                            unit(v, u);
+                            __builtin_memcpy(&v, qbase + (qb + (u << 4)), 16);
+                            unit(v, u, sr, tr);
+                        }
+                    };
+#pragma unroll
+                    for (uint32_t j = 0; j < kOpl; ++j) {
+                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
+                        const bool ism = ((0x181u >> op) & 1u) != 0u;
+                        const uint32_t xe = xs + ax[j];
+                        const uint32_t sp = xs > W ? xs : W;
+                        const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
+                        uint32_t tp = xe < Wend ? xe : Wend;
+                        tp = (xs + lq) < tp ? (xs + lq) : tp;
+                        const bool valid = ism && sp < tp && !(a.ablate & 1u);
+                        const uint32_t sr = sp - W, tr = tp - W;
+                        const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
+                        const bool big = valid && (tr - sr) > 64u;
+                        xs = xe; ys += ay[j];
+                        if (valid && !big) {
+                            if (ns == 0u) { a_st = sr | (tr << 16); a_q = q; }
+                            else if (ns == 1u) { b_st = sr | (tr << 16); b_q = q; }
+                            else run_direct(sr, tr, q);
+                            ns += 1u;
+                        }
+                        const unsigned long long bm = __ballot(big);
+                        if (bm) {                                    // wave-uniform: long runs go through the list
+                            if (big) {
+                                const uint32_t idx = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                                list[idx] = make_uint2(q, sr | ((tr - sr - 1u) << 16) | rset | 0x80000000u);
+                            }
+                            const uint32_t n_list = n_keep + (uint32_t)__popcll(bm);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const uint32_t n_full = n_list & ~15u;
+                            if (n_full) consume_list(n_full);
+                            n_keep = n_list - n_full;
+                            uint2 carry = make_uint2(0u, 0u);
+                            if (n_full && lane < n_keep) carry = list[n_full + lane];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (n_full && lane < n_keep) list[lane] = carry;
                         }
                     }
-                    const unsigned long long bm = __ballot(big);
-                    if (bm) {                                        // wave-uniform: long runs go through the list
-                        if (big) {
-                            const uint32_t idx = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                            list[idx] = make_uint2(rqrel + ys + (sp - xs), srel | ((trel - srel - 1u) << 16) | rset | 0x80000000u);
+                    // the first two units of A and of B are requested together (a ~15-base run covers one or two)
+                    {
+                        const uint32_t a_sr = a_st & 0xFFFFu, a_tr = a_st >> 16, b_sr = b_st & 0xFFFFu, b_tr = b_st >> 16;
+                        const uint32_t a_qb = a_q + (uint32_t)kQualPad - a_sr, b_qb = b_q + (uint32_t)kQualPad - b_sr;
+                        const uint32_t a_u0 = a_sr >> 4, a_u1 = ns >= 1u ? (a_tr - 1u) >> 4 : 0u;
+                        const uint32_t b_u0 = b_sr >> 4, b_u1 = ns >= 2u ? (b_tr - 1u) >> 4 : 0u;
+                        Q16 va0, va1, vb0, vb1;
+                        if (ns >= 1u) {
+                            __builtin_memcpy(&va0, qbase + (a_qb + (a_u0 << 4)), 16);
+                            __builtin_memcpy(&va1, qbase + (a_qb + ((a_u0 + 1u <= a_u1 ? a_u0 + 1u : a_u0) << 4)), 16);
                         }
-                        const uint32_t n_list = n_keep + (uint32_t)__popcll(bm);
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        const uint32_t n_full = n_list & ~15u;
-                        if (n_full) consume_list(n_full);
-                        n_keep = n_list - n_full;
-                        uint2 carry = make_uint2(0u, 0u);
-                        if (n_full && lane < n_keep) carry = list[n_full + lane];
-                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                        __builtin_amdgcn_wave_barrier();
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (n_full && lane < n_keep) list[lane] = carry;
+                        if (ns >= 2u) {
+                            __builtin_memcpy(&vb0, qbase + (b_qb + (b_u0 << 4)), 16);
+                            __builtin_memcpy(&vb1, qbase + (b_qb + ((b_u0 + 1u <= b_u1 ? b_u0 + 1u : b_u0) << 4)), 16);
+                        }
+                        if (ns >= 1u) {
+                            unit(va0, a_u0, a_sr, a_tr);
+                            if (a_u0 + 1u <= a_u1) unit(va1, a_u0 + 1u, a_sr, a_tr);
+                        }
+                        if (ns >= 2u) {
+                            unit(vb0, b_u0, b_sr, b_tr);
+                            if (b_u0 + 1u <= b_u1) unit(vb1, b_u0 + 1u, b_sr, b_tr);
+                        }
+                        if (ns >= 1u)
+                            for (uint32_t u = a_u0 + 2u; u <= a_u1; ++u) {
+                                Q16 v;
+                                __builtin_memcpy(&v, qbase + (a_qb + (u << 4)), 16);
+                                unit(v, u, a_sr, a_tr);
+                            }
+                        if (ns >= 2u)
+                            for (uint32_t u = b_u0 + 2u; u <= b_u1; ++u) {
+                                Q16 v;
+                                __builtin_memcpy(&v, qbase + (b_qb + (u << 4)), 16);
+                                unit(v, u, b_sr, b_tr);
+                            }
                     }
                     rx += (uint32_t)__builtin_amdgcn_readlane((int)ix, 63);
                     ry += (uint32_t)__builtin_amdgcn_readlane((int)iy, 63);
-                    rk += 64u;
+                    rk += 64u * kOpl;
                 }
             }
             __syncthreads();                                         // s_live is rewritten by the next pass

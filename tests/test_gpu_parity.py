@@ -720,3 +720,38 @@ def test_deeper_short_read_data_keeps_the_8bit_counters(tmp_path):
     merged = sorted(rows(sub) + reads, key=lambda r: r[0])
     o, _ = compare([("pile", 0, L, ref, ContigRecords.from_reads(merged))], dict(max_depth=100_000), tmp_path, "pile")
     assert o["pile"]["dumps"][0].max() > 600
+
+
+def _eqx_split(rec, seed):
+    """Every M run of >= 3 bases becomes '=' 'X'(1) '=' at a random cut (the --eqx style of CIGAR): the same
+    alignment with three match-type operations in a row."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    cig = rec.cigar
+    op, ln = cig & 15, cig >> 4
+    split = (op == 0) & (ln >= 3)
+    cnt = np.where(split, 3, 1)
+    start = np.concatenate([[0], np.cumsum(cnt)])
+    out = np.empty(int(start[-1]), dtype=np.uint32)
+    keep = ~split
+    out[start[:-1][keep]] = np.where(op[keep] == 0, (ln[keep] << 4) | 7, cig[keep])      # short M -> '='
+    a = (rng.random(int(split.sum())) * (ln[split] - 2)).astype(np.uint32) + 1           # 1 .. len-2
+    s0 = start[:-1][split]
+    out[s0] = (a << 4) | 7
+    out[s0 + 1] = (1 << 4) | 8
+    out[s0 + 2] = ((ln[split] - a - 1) << 4) | 7
+    off = start[rec.cigar_off.astype(np.int64)].astype(np.uint32)
+    return dataclasses.replace(rec, cigar=out, cigar_off=off)
+
+
+def test_long_reads_with_eqx_cigars(tmp_path):
+    """Three or four match-type runs among a lane's four operations (the paths behind the first two runs
+    of the four-operations-per-lane variant), '=' and 'X' operations throughout."""
+    L = 200_000
+    rec = _eqx_split(synth.long_read_contig(L, 40, synth.seed_for(3, 29)), 5)
+    rec.validate()
+    assert rec.cigar.shape[0] >= 8 * rec.n and rec.qual.shape[0] < 32 * rec.cigar.shape[0]
+    assert ((rec.cigar & 15) == 8).sum() > 10_000
+    ref = synth.make_reference(L, synth.seed_for(3, 29))
+    compare([("chrE", 3, L, ref, rec)], dict(), tmp_path, "eqx")
+    compare([("chrE", 3, L, ref, rec)], dict(min_base_quality=25, min_mapping_quality=30, max_depth=30), tmp_path, "eqx2")

@@ -804,26 +804,55 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
     if (rc != CL_OK) { set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)"); goto out; }
     prof = dut_profiler_new(bed_path);
     if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; goto out; }
-    for (int t : tids) {                                          // ascending tid, api/coverage.rs:229-234
-        dut_records rec;
-        io_stage_time("(before contig)", tm);
-        rc = dut_bam_read_contig(bam, t, &rec, nullptr, nullptr);
-        if (rc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_bam_error(bam)); goto out; }
-        io_stage_time("BAM read + decode", tm);
-        const uint8_t *bases = nullptr; uint64_t blen = 0;
-        dut_fasta_fetch(fa, dut_bam_ref_name(bam, t), &bases, &blen);
-        io_stage_time("FASTA fetch", tm);
-        dut_contig_stats st;
-        memset(&st, 0, sizeof(st));
-        rc = dut_process_single_contig(ctx, prof, &st, opt, dut_bam_ref_name(bam, t), t, dut_bam_ref_len(bam, t), bases, blen, &rec);
-        if (rc != CL_OK) {
-            const char *m = cl_last_error(ctx);
-            set_err(err, err_len, std::string("Error processing contig: ") + ((m && *m) ? m : (rc == CL_ERR_UNSORTED ? "the input is not sorted" : "failed")));
-            goto out;
+    {
+        // Contigs are processed in ascending tid order (api/coverage.rs:229-234).  With an index and more
+        // than one contig, the records and reference bases of contig i+1 are read by a second reader on
+        // its own thread while contig i is admitted, pushed, run and written (DUT_PIPELINE=0: off).
+        struct Slot { dut_bam *bam = nullptr; dut_fasta *fa = nullptr; dut_records rec; const uint8_t *bases = nullptr; uint64_t blen = 0; int rc = CL_OK; };
+        Slot slot[2];
+        slot[0].bam = bam; slot[0].fa = fa;
+        const char *pe = getenv("DUT_PIPELINE");
+        bool pipeline = tids.size() > 1 && dut_bam_has_index(bam) && !(pe && *pe == '0');
+        if (pipeline) {
+            slot[1].bam = dut_bam_open(bam_path, e, sizeof(e));
+            slot[1].fa = slot[1].bam ? dut_fasta_open(fasta_path, e, sizeof(e)) : nullptr;
+            if (!slot[1].bam || !slot[1].fa) {                 // e.g. out of file handles: read in line instead
+                if (slot[1].bam) dut_bam_close(slot[1].bam);
+                slot[1].bam = nullptr; pipeline = false;
+            }
         }
-        uint64_t c6[6];
-        dut_profiler_contig_counts(prof, dut_bam_ref_name(bam, t), c6);
-        stats.push_back(st); names.push_back(dut_bam_ref_name(bam, t)); counts.push_back(std::vector<uint64_t>(c6, c6 + 6));
+        auto fetch = [&](Slot &s, int t) {
+            s.rc = dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
+            s.bases = nullptr; s.blen = 0;
+            if (s.rc == CL_OK) dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen);
+        };
+        std::thread ahead;
+        io_stage_time("(before contigs)", tm);
+        if (!tids.empty()) fetch(slot[0], tids[0]);
+        for (size_t i = 0; i < tids.size(); ++i) {
+            const int t = tids[i];
+            Slot &cur = pipeline ? slot[i & 1] : slot[0];
+            if (i > 0 && !pipeline) fetch(cur, t);
+            io_stage_time(pipeline && i > 0 ? "wait for the read-ahead" : "BAM read + decode, FASTA fetch", tm);
+            if (pipeline && i + 1 < tids.size()) ahead = std::thread(fetch, std::ref(slot[(i + 1) & 1]), tids[i + 1]);
+            if (cur.rc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_bam_error(cur.bam)); rc = cur.rc; }
+            dut_contig_stats st;
+            memset(&st, 0, sizeof(st));
+            if (rc == CL_OK) {
+                rc = dut_process_single_contig(ctx, prof, &st, opt, dut_bam_ref_name(bam, t), t, dut_bam_ref_len(bam, t), cur.bases, cur.blen, &cur.rec);
+                if (rc != CL_OK) {
+                    const char *m = cl_last_error(ctx);
+                    set_err(err, err_len, std::string("Error processing contig: ") + ((m && *m) ? m : (rc == CL_ERR_UNSORTED ? "the input is not sorted" : "failed")));
+                }
+            }
+            if (ahead.joinable()) ahead.join();
+            if (rc != CL_OK) break;
+            uint64_t c6[6];
+            dut_profiler_contig_counts(prof, dut_bam_ref_name(bam, t), c6);
+            stats.push_back(st); names.push_back(dut_bam_ref_name(bam, t)); counts.push_back(std::vector<uint64_t>(c6, c6 + 6));
+        }
+        if (slot[1].bam) { dut_fasta_close(slot[1].fa); dut_bam_close(slot[1].bam); }
+        if (rc != CL_OK) goto out;
     }
     if (summary_json) {
         // CoverageOutput as main.rs:68-69 serialises it (the HTML report and the SVG plots are not produced)

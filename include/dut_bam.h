@@ -60,7 +60,9 @@ int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint6
  * lines; then write the CoverageOutput JSON (dut_report.h, what main.rs:68-69 puts in
  * ./summary.json) to summary_json (may be NULL).  summary_html is only named in that JSON -- the
  * HTML report itself is presentation and is not produced (NULL = "summary.html").
- * contigs == NULL selects every header contig.
+ * contigs == NULL selects every header contig.  With a .bai and more than one selected contig the next
+ * contig's records and bases are read ahead on a second reader while the current one is processed
+ * (environment DUT_PIPELINE=0 turns that off; the output is the same either way).
  * Errors: negative cl_status, message in err ("None of the specified contigs (...) were found in
  * the BAM file" for an -L list that matches nothing, api/coverage.rs:187-204). */
 int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,

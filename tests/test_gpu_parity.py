@@ -377,8 +377,20 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     contigs = [(n, t, lens[t], refs[t], recs.get(t, ContigRecords.empty())) for t, n in enumerate(names)]
     o_res, o_bed = oracle_run(contigs, make_options({}), str(tmp_path / "o.bed"))
     bed = str(tmp_path / "g.bed"); js = str(tmp_path / "summary.json")
-    coverage_files(bam, fa, bed, js, CallableOptions(), output_summary="rep.html")
+    coverage_files(bam, fa, bed, js, CallableOptions(), output_summary="rep.html")     # indexed, 4 contigs: contig i+1 is read ahead
     assert open(bed).read() == o_bed
+    # the same without the read-ahead thread, and without an index (one sequential pass over the file)
+    import shutil
+    os.environ["DUT_PIPELINE"] = "0"
+    try:
+        coverage_files(bam, fa, str(tmp_path / "g0.bed"), str(tmp_path / "s0.json"), CallableOptions(), output_summary="rep.html")
+    finally:
+        del os.environ["DUT_PIPELINE"]
+    assert open(tmp_path / "g0.bed").read() == o_bed
+    bam_ni = str(tmp_path / "noindex.bam")
+    shutil.copy(bam, bam_ni)
+    coverage_files(bam_ni, fa, str(tmp_path / "g1.bed"), str(tmp_path / "s1.json"), CallableOptions(), output_summary="rep.html")
+    assert open(tmp_path / "g1.bed").read() == o_bed
     # summary.json: the CoverageOutput text, byte for byte (oracle: report.rs:15-134 + serde_json pretty)
     from oracle import report_oracle as RO
     hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(names, lens))

@@ -45,6 +45,11 @@ static std::vector<uint8_t> bgzf_block(const uint8_t *d, size_t n, int level)
     return out;
 }
 
+static void write_records(FILE *f, int32_t ref_id, uint64_t n,
+                          const int32_t *pos, const uint16_t *flag, const uint8_t *mapq, const uint32_t *cigar_off,
+                          const uint32_t *cigar, const uint64_t *qual_off, const uint8_t *qual, const uint32_t *qname_off,
+                          const uint8_t *qname, int level, int threads);
+
 extern "C" int tool_write_bam(const char *path, const char *header_text, const char *ref_name, uint32_t ref_len, uint64_t n,
                               const int32_t *pos, const uint16_t *flag, const uint8_t *mapq, const uint32_t *cigar_off,
                               const uint32_t *cigar, const uint64_t *qual_off, const uint8_t *qual, const uint32_t *qname_off,
@@ -58,6 +63,57 @@ extern "C" int tool_write_bam(const char *path, const char *header_text, const c
     put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
     put32(head, 1); put32(head, (uint32_t)strlen(ref_name) + 1); head.insert(head.end(), ref_name, ref_name + strlen(ref_name) + 1); put32(head, ref_len);
     { auto b = bgzf_block(head.data(), head.size(), level); fwrite(b.data(), 1, b.size(), f); }
+    write_records(f, 0, n, pos, flag, mapq, cigar_off, cigar, qual_off, qual, qname_off, qname, level, threads);
+    { auto b = bgzf_block(nullptr, 0, level); fwrite(b.data(), 1, b.size(), f); }
+    fclose(f);
+    return 0;
+}
+
+// Multi-contig files are assembled by the caller: tool_write_bam_head (header block), then one
+// tool_write_bam_body per reference in tid order (appends the reference's record blocks; the file
+// size before the call << 16 is the reference's first virtual offset for the .bai), then tool_write_bam_eof.
+extern "C" int tool_write_bam_head(const char *path, const char *header_text, int n_ref, const char *const *names, const uint32_t *lens, int level)
+{
+    FILE *f = fopen(path, "wb");
+    if (!f) return -1;
+    std::string text = header_text;
+    for (int i = 0; i < n_ref; ++i) text += std::string("@SQ\tSN:") + names[i] + "\tLN:" + std::to_string(lens[i]) + "\n";
+    std::vector<uint8_t> head;
+    head.insert(head.end(), {'B', 'A', 'M', 1});
+    put32(head, (uint32_t)text.size()); head.insert(head.end(), text.begin(), text.end());
+    put32(head, (uint32_t)n_ref);
+    for (int i = 0; i < n_ref; ++i) { put32(head, (uint32_t)strlen(names[i]) + 1); head.insert(head.end(), names[i], names[i] + strlen(names[i]) + 1); put32(head, lens[i]); }
+    for (size_t a = 0; a < head.size(); a += 0xFF00) { auto b = bgzf_block(head.data() + a, std::min<size_t>(0xFF00, head.size() - a), level); fwrite(b.data(), 1, b.size(), f); }
+    fclose(f);
+    return 0;
+}
+
+extern "C" int tool_write_bam_body(const char *path, int32_t ref_id, uint64_t n,
+                                   const int32_t *pos, const uint16_t *flag, const uint8_t *mapq, const uint32_t *cigar_off,
+                                   const uint32_t *cigar, const uint64_t *qual_off, const uint8_t *qual, const uint32_t *qname_off,
+                                   const uint8_t *qname, int level, int threads)
+{
+    FILE *f = fopen(path, "ab");
+    if (!f) return -1;
+    write_records(f, ref_id, n, pos, flag, mapq, cigar_off, cigar, qual_off, qual, qname_off, qname, level, threads);
+    fclose(f);
+    return 0;
+}
+
+extern "C" int tool_write_bam_eof(const char *path)
+{
+    FILE *f = fopen(path, "ab");
+    if (!f) return -1;
+    { auto b = bgzf_block(nullptr, 0, 1); fwrite(b.data(), 1, b.size(), f); }
+    fclose(f);
+    return 0;
+}
+
+static void write_records(FILE *f, int32_t ref_id, uint64_t n,
+                          const int32_t *pos, const uint16_t *flag, const uint8_t *mapq, const uint32_t *cigar_off,
+                          const uint32_t *cigar, const uint64_t *qual_off, const uint8_t *qual, const uint32_t *qname_off,
+                          const uint8_t *qname, int level, int threads)
+{
     // like htslib's bam_write1 (bgzf_flush_try): a record that does not fit into the current BGZF block
     // starts a new one, so no record straddles two blocks (set TOOL_BAM_STRADDLE=1 for 0xFF00-byte cuts)
     const bool straddle = getenv("TOOL_BAM_STRADDLE") && *getenv("TOOL_BAM_STRADDLE") == '1';
@@ -77,7 +133,7 @@ extern "C" int tool_write_bam(const char *path, const char *header_text, const c
             int64_t rlen = 0;
             for (uint32_t k = cigar_off[i]; k < cigar_off[i + 1]; ++k) { const uint32_t op = cigar[k] & 15; if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) rlen += cigar[k] >> 4; }
             put32(buf, 32 + ln + 4 * nc + (ls + 1) / 2 + ls);
-            put32(buf, 0); put32(buf, (uint32_t)pos[i]);
+            put32(buf, (uint32_t)ref_id); put32(buf, (uint32_t)pos[i]);
             buf.push_back((uint8_t)ln); buf.push_back(mapq[i]); put16(buf, (uint16_t)reg2bin(pos[i], pos[i] + (rlen ? rlen : 1)));
             put16(buf, (uint16_t)nc); put16(buf, flag[i]); put32(buf, ls); put32(buf, 0xFFFFFFFFu); put32(buf, 0xFFFFFFFFu); put32(buf, 0);
             buf.insert(buf.end(), qname + qname_off[i], qname + qname_off[i + 1]); buf.push_back(0);
@@ -104,7 +160,4 @@ extern "C" int tool_write_bam(const char *path, const char *header_text, const c
         for (auto &o : outs) fwrite(o.data(), 1, o.size(), f);
         if (cuts.back() < buf.size()) carry.assign(buf.begin() + (long)cuts.back(), buf.end());
     }
-    { auto b = bgzf_block(nullptr, 0, level); fwrite(b.data(), 1, b.size(), f); }
-    fclose(f);
-    return 0;
 }

@@ -203,7 +203,7 @@ def _outcome_row(o: ContigOutcome) -> List[int]:
 
 
 def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: Callable[[int, ContigInput], ContigOutcome],
-                    device="cpu", group=None) -> Optional[CoverageOutput]:
+                    device="cpu", group=None, on_assignment: Optional[Callable[[List[int]], None]] = None) -> Optional[CoverageOutput]:
     """Every rank calls this with the same `inp` description (it only touches the contigs it is
     assigned).  `process_contig(tid, contig)` runs one contig on this rank's GPU
     (engine_process_contig bound to the rank's Engine).  Returns the output on rank 0, None elsewhere.
@@ -217,6 +217,8 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
                else int(inp.contigs[t].records.qual.shape[0]) + inp.contigs[t].length for t in tids]
     rank_of = lpt_assignment(weights, world)
     mine = [t for t, r in zip(tids, rank_of) if r == rank]
+    if on_assignment is not None:
+        on_assignment(list(mine))                      # the order process_contig will be called in (read-ahead hook)
     local = {t: process_contig(t, inp.contigs[t]) for t in mine}
 
     # --- summaries: fixed-size rows, one all_gather ---
@@ -302,10 +304,25 @@ def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, 
     when world > 1): every rank opens the BAM / FASTA itself and decodes only the contigs it is dealt
     (LPT on the index's mapped-read counts, else on contig length); rank 0 writes the BED in tid order
     and the summary.json of main.rs:68-69.  Returns the CoverageOutput on rank 0, None elsewhere."""
+    import os
+    from concurrent.futures import ThreadPoolExecutor
     from .bam import BamReader, FastaReader
     from .report import BamStats, coverage_output_json
     bam = BamReader(bam_file)
     fasta = FastaReader(reference_file)
+    # with an index, the rank's next contig is read on a second reader (its own thread; the library calls
+    # release the GIL) while the current one runs -- as dut_coverage_files does (DUT_PIPELINE=0: off)
+    readers = [(bam, fasta)]
+    pool = None
+    if bam.has_index and os.environ.get("DUT_PIPELINE", "1") != "0":
+        readers.append((BamReader(bam_file), FastaReader(reference_file)))
+        pool = ThreadPoolExecutor(1)
+    order: List[int] = []
+    pending = {}
+
+    def fetch(slot, tid, name):
+        b, f = readers[slot]
+        return b.fetch_contig(tid), f.fetch(name)
     try:
         descr = []
         for t, (nm, ln) in enumerate(zip(bam.target_names, bam.target_lens)):
@@ -314,9 +331,14 @@ def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, 
         inp = CoverageInput(contigs=descr, options=options, selected=contigs, output_bed=output_bed)
         with Engine(options, device_id) as eng:
             def run(tid, c):
-                rec = bam.fetch_contig(tid)
-                return engine_process_contig_runs(eng, options, tid, c.name, c.length, rec, fasta.fetch(c.name))
-            out = analyze_sharded(inp, rank, world, run, device=coll_device, group=group)
+                i = order.index(tid)
+                # a reader's arrays stay valid until its next fetch: contigs alternate between the two readers
+                rec, bases = pending.pop(tid).result() if tid in pending else fetch(i & 1 if pool else 0, tid, c.name)
+                if pool and i + 1 < len(order):
+                    nt = order[i + 1]
+                    pending[nt] = pool.submit(fetch, (i + 1) & 1, nt, descr[nt].name)
+                return engine_process_contig_runs(eng, options, tid, c.name, c.length, rec, bases)
+            out = analyze_sharded(inp, rank, world, run, device=coll_device, group=group, on_assignment=order.extend)
         if rank != 0:
             return None
         if summary_json:
@@ -329,5 +351,8 @@ def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, 
                 f.write(text)
         return out
     finally:
-        bam.close()
-        fasta.close()
+        if pool:
+            pool.shutdown(wait=True)
+        for b, f in readers:
+            b.close()
+            f.close()

@@ -121,6 +121,10 @@ struct RefSeq { std::string name; uint32_t len; };
 inline double tnow() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 inline bool timing_on() { static const bool on = getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1'; return on; }
 
+// (Giving back a chr21-sized contig's ~2.7 GB of decode buffers costs ~0.25 s of page-table work at close.
+// Tried and dropped: transparent huge pages for these buffers -- with the usual `defrag = madvise` the
+// first-touch faults compact synchronously and the parallel parse went from 0.14 to 0.73 s; dropping the
+// pages with MADV_DONTNEED in slices on all threads before free() -- 0.34 s, the threads contend.)
 // grow-only buffer without value initialisation (the decoded arrays are written exactly once)
 template <class T>
 struct RawBuf {
@@ -800,11 +804,9 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         set_err(err, err_len, "None of the specified contigs (" + list + ") were found in the BAM file");
         rc = CL_ERR_INVALID; goto out;
     }
-    rc = cl_create(opt, device_id, nullptr, &ctx);
-    if (rc != CL_OK) { set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)"); goto out; }
-    prof = dut_profiler_new(bed_path);
-    if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; goto out; }
     {
+        // the HIP runtime and the engine context come up on their own thread while the first contig is decoded
+        std::thread init([&]() { rc = cl_create(opt, device_id, nullptr, &ctx); });
         // Contigs are processed in ascending tid order (api/coverage.rs:229-234).  With an index and more
         // than one contig, the records and reference bases of contig i+1 are read by a second reader on
         // its own thread while contig i is admitted, pushed, run and written (DUT_PIPELINE=0: off).
@@ -829,7 +831,13 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         std::thread ahead;
         io_stage_time("(before contigs)", tm);
         if (!tids.empty()) fetch(slot[0], tids[0]);
-        for (size_t i = 0; i < tids.size(); ++i) {
+        init.join();
+        if (rc != CL_OK) set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)");
+        else {
+            prof = dut_profiler_new(bed_path);
+            if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; }
+        }
+        for (size_t i = 0; rc == CL_OK && i < tids.size(); ++i) {
             const int t = tids[i];
             Slot &cur = pipeline ? slot[i & 1] : slot[0];
             if (i > 0 && !pipeline) fetch(cur, t);
@@ -877,10 +885,17 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         dut_free(js);
     }
 out:
+    io_stage_time("(since the last decode) + summary", tm);
     dut_bam_stats_free(bstats);
     if (prof) dut_profiler_free(prof);
-    if (ctx) cl_destroy(ctx);
-    dut_fasta_close(fa);
-    dut_bam_close(bam);
+    {
+        // giving the device memory back and unmapping the decode buffers take a few hundred ms at chr21 size: side by side
+        std::thread td([&]() { if (ctx) cl_destroy(ctx); });
+        dut_fasta_close(fa);
+        dut_bam_close(bam);
+        io_stage_time("readers closed", tm);
+        td.join();
+    }
+    io_stage_time("engine destroyed", tm);
     return rc;
 }

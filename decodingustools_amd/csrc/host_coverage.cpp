@@ -181,10 +181,22 @@ int dut_profiler_feed_contig(dut_profiler *p, const char *contig, const cl_inter
     return CL_OK;
 }
 
+// DUT_TIMING=1: wall-clock of the host stages on stderr (tooling; off by default)
+static double dut_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool dut_timing_on() { static const bool on = getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1'; return on; }
+static void dut_stage_time(const char *what, double &t0)
+{
+    if (!dut_timing_on()) return;
+    const double t1 = dut_now();
+    fprintf(stderr, "[dut-timing] %-28s %8.1f ms\n", what, (t1 - t0) * 1e3);
+    t0 = t1;
+}
+
 int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, const dut_records *rec,
                     uint8_t *accepted, uint32_t *n_unique_names, uint64_t *n_accepted)
 {
     if (!opt || !rec || (!accepted && rec->n)) return CL_ERR_INVALID;
+    if (rec->n >= (1ull << 32)) return CL_ERR_RANGE;          // read indices are kept in 32 bits below (the engine stops at 2^29 reads)
     const uint64_t maxcnt = opt->max_depth > 0 ? opt->max_depth : 500;   // mod.rs:56-60
     // Ends of the reads the pileup list holds.  When the cursor sits on start position s the
     // list holds exactly the appended reads with end >= s (reads that ended earlier were freed
@@ -207,12 +219,68 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
         ++cnt;
     };
     // reference spans of all reads up front, in parallel (the sequential rule below only compares numbers)
+    double tm = dut_now();
     std::vector<uint64_t> rlen(rec->n);
     dut::parallel_for(rec->n, 65536, [&](size_t i) { rlen[i] = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]); });
+    dut_stage_time("  admit: spans", tm);
     bool any_pushed = false;
     int64_t cur_start = -1;
     uint64_t nacc = 0;
-    for (uint64_t i = 0; i < rec->n; ++i) {
+    // Fast path.  The list never holds more reads than have started within the longest span before the
+    // cursor: when the records are sorted and fewer than maxcnt records start within max_span of any
+    // record, the cap cannot bite, and what is left of the rule is independent per read: kept iff it
+    // is yielded by the fetch, mapped, and spans reference positions (a spanless read is appended or not
+    // depending on the branch, but never counted).  Checked and applied in parallel.
+    bool fast = rec->n > 0;
+    if (fast) {
+        const size_t grain = 65536, nchunk = (rec->n + grain - 1) / grain;
+        std::vector<uint64_t> c_maxrl(nchunk, 0);
+        std::vector<uint8_t> c_sorted(nchunk, 1);
+        dut::parallel_for(nchunk, 1, [&](size_t c) {
+            const size_t a = c * grain, b = std::min<size_t>(rec->n, a + grain);
+            uint64_t m = 0; bool ok = true;
+            for (size_t i = a; i < b; ++i) {
+                m = std::max(m, rlen[i]);
+                if (i + 1 < rec->n && rec->pos[i + 1] < rec->pos[i]) ok = false;
+                if (rec->pos[i] < 0) ok = false;
+            }
+            c_maxrl[c] = m; c_sorted[c] = ok;
+        });
+        uint64_t max_rl = 0;
+        for (size_t c = 0; c < nchunk; ++c) { max_rl = std::max(max_rl, c_maxrl[c]); fast = fast && c_sorted[c]; }
+        if (fast) {
+            std::vector<uint8_t> c_ok(nchunk, 1);
+            dut::parallel_for(nchunk, 1, [&](size_t c) {
+                const size_t a = c * grain, b = std::min<size_t>(rec->n, a + grain);
+                // j: first record that starts at or after pos[i] - max_rl
+                const int64_t key0 = (int64_t)rec->pos[a] - (int64_t)max_rl;
+                size_t j = (size_t)(std::lower_bound(rec->pos, rec->pos + a, key0, [](int32_t v, int64_t k) { return (int64_t)v < k; }) - rec->pos);
+                bool ok = true;
+                for (size_t i = a; i < b && ok; ++i) {
+                    const int64_t key = (int64_t)rec->pos[i] - (int64_t)max_rl;
+                    while ((int64_t)rec->pos[j] < key) ++j;
+                    if (i - j + 1 >= maxcnt) ok = false;          // i - j records before this one could still be listed
+                }
+                c_ok[c] = ok;
+            });
+            for (size_t c = 0; c < nchunk; ++c) fast = fast && c_ok[c];
+        }
+        if (fast) {
+            std::vector<uint64_t> c_acc(nchunk, 0);
+            dut::parallel_for(nchunk, 1, [&](size_t c) {
+                const size_t a = c * grain, b = std::min<size_t>(rec->n, a + grain);
+                uint64_t k = 0;
+                for (size_t i = a; i < b; ++i) {
+                    const bool keep = (int64_t)rec->pos[i] < (int64_t)contig_len && !(rec->flag[i] & 0x4) && rlen[i] > 0;
+                    accepted[i] = keep ? 1 : 0;
+                    k += keep;
+                }
+                c_acc[c] = k;
+            });
+            for (size_t c = 0; c < nchunk; ++c) nacc += c_acc[c];
+        }
+    }
+    for (uint64_t i = 0; !fast && i < rec->n; ++i) {
         accepted[i] = 0;
         const int64_t p = rec->pos[i];
         if (p >= (int64_t)contig_len) continue;              // not yielded by fetch((tid,0,len))
@@ -239,6 +307,7 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
         live_push(end);
         if (rl > 0) { accepted[i] = 1; ++nacc; }
     }
+    dut_stage_time("  admit: cap rule", tm);
     if (n_accepted) *n_accepted = nacc;
     if (n_unique_names) {
         // distinct names among the accepted reads, exactly: the reads are split into 64 classes by the
@@ -249,32 +318,51 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
             std::vector<uint64_t> h(rec->n);
             NameSet hasher; hasher.rec = rec;
             dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = accepted[i] ? hasher.hash_of(i) : 0; });
-            constexpr int kClasses = 64;
-            std::vector<uint64_t> per(kClasses, 0), cnt(kClasses, 0);
-            for (uint64_t i = 0; i < rec->n; ++i) if (accepted[i]) cnt[h[i] >> 58] += 1;
-            dut::parallel_for(kClasses, 1, [&](size_t c) {
-                if (!cnt[c]) return;
-                NameSet set; set.rec = rec; set.presize(cnt[c]);
-                for (uint64_t i = 0; i < rec->n; ++i) if (accepted[i] && (h[i] >> 58) == c) set.insert_hashed(i, h[i]);
-                per[c] = set.count;
+            dut_stage_time("  admit: name hashes", tm);
+            // the accepted reads are bucketed by the top bits of their hash (counting sort: per-chunk histograms,
+            // offsets, scatter -- all parallel); every class then has a few thousand names and a table that
+            // stays in cache
+            const int bits = nacc > (1u << 22) ? 12 : (nacc > (1u << 16) ? 8 : 0);
+            const size_t kClasses = (size_t)1 << bits;
+            const size_t grain = 1u << 18, nchunk = (rec->n + grain - 1) / grain;
+            auto cls = [&](uint64_t hv) -> size_t { return bits ? (size_t)(hv >> (64 - bits)) : 0; };
+            std::vector<uint32_t> hist(nchunk * kClasses, 0);
+            dut::parallel_for(nchunk, 1, [&](size_t c) {
+                uint32_t *hc = hist.data() + c * kClasses;
+                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
+                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) hc[cls(h[i])] += 1;
+            });
+            std::vector<uint64_t> cstart(kClasses + 1, 0);
+            {   // class-major, chunk-minor exclusive prefix: hist[c][k] becomes the write offset of chunk c in class k
+                uint64_t run = 0;
+                for (size_t k = 0; k < kClasses; ++k) {
+                    cstart[k] = run;
+                    for (size_t c = 0; c < nchunk; ++c) { const uint32_t v = hist[c * kClasses + k]; hist[c * kClasses + k] = (uint32_t)(run - cstart[k]); run += v; }
+                }
+                cstart[kClasses] = run;
+            }
+            std::vector<uint32_t> order(nacc);                // read indices, class by class (the host refuses >= 2^29 reads per contig)
+            dut::parallel_for(nchunk, 1, [&](size_t c) {
+                uint32_t *hc = hist.data() + c * kClasses;
+                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
+                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) { const size_t k = cls(h[i]); order[cstart[k] + hc[k]++] = (uint32_t)i; }
+            });
+            std::vector<uint64_t> per(kClasses, 0);
+            dut::parallel_for(kClasses, 16, [&](size_t k) {
+                const uint64_t a = cstart[k], b = cstart[k + 1];
+                if (a == b) return;
+                NameSet set; set.rec = rec; set.presize(b - a);
+                for (uint64_t q = a; q < b; ++q) set.insert_hashed(order[q], h[order[q]]);
+                per[k] = set.count;
             });
             for (uint64_t v : per) total += v;
+            dut_stage_time("  admit: name sets", tm);
         }
         *n_unique_names = (uint32_t)total;
     }
     return CL_OK;
 }
 
-// DUT_TIMING=1: wall-clock of the host stages on stderr (tooling; off by default)
-static double dut_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
-static bool dut_timing_on() { static const bool on = getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1'; return on; }
-static void dut_stage_time(const char *what, double &t0)
-{
-    if (!dut_timing_on()) return;
-    const double t1 = dut_now();
-    fprintf(stderr, "[dut-timing] %-28s %8.1f ms\n", what, (t1 - t0) * 1e3);
-    t0 = t1;
-}
 
 int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats *stats, const cl_options *opt,
                               const char *contig_name, int32_t tid, uint32_t contig_len, const uint8_t *ref,

@@ -199,3 +199,21 @@ def test_derived_stats_and_genome_summary_match_oracle():
     og = oracle.genome_summary([ostats[i] for i in order], [call[i] for i in order])
     for k, v in og.items():
         assert g[k] == v, k
+
+
+@pytest.mark.parametrize("max_depth", [30, 40, 50, 70, 200])
+def test_admission_fast_path_threshold_matches_the_oracle(max_depth):
+    """30x short reads: about 30-45 records start within one read length of any record, so these caps sit on
+    both sides of the point where the host may skip the sequential cap rule (it may only when the cap cannot bite)."""
+    L = 20_000
+    rec = synth.short_read_contig(L, 30, 77)
+    opt = make_options(dict(max_depth=max_depth))
+    acc_o = oracle.accepted_reads(opt, 1, L, rec)
+    acc_h, _ = admit_reads(CallableOptions(max_depth=max_depth), 1, L, rec)
+    ops = rec.cigar & 15
+    lens = (rec.cigar >> 4).astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(np.where(np.isin(ops, [0, 2, 3, 7, 8]), lens, 0))])
+    rl = cs[rec.cigar_off[1:].astype(np.int64)] - cs[rec.cigar_off[:-1].astype(np.int64)]
+    assert np.array_equal(acc_h, acc_o & (rl > 0))
+    if max_depth <= 30:
+        assert (acc_o & (rl > 0)).sum() < ((rec.flag & 4) == 0).sum()      # the cap did drop reads here

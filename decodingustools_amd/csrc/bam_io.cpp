@@ -6,6 +6,7 @@
 #include "host_parallel.h"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -184,6 +185,13 @@ struct BlockStream {
     RawBuf<uint8_t> buf;              // inflated bytes; [cur, buf.n) not yet consumed
     size_t cur = 0;
     RawBuf<uint8_t> cbuf;
+    // read-ahead: while a batch is inflated the next one is read (pread, own thread) into cbuf_next
+    RawBuf<uint8_t> cbuf_next;
+    std::thread ahead;
+    uint64_t ahead_off = 0;
+    size_t ahead_want = 0, ahead_got = 0;
+    void drop_ahead() { if (ahead.joinable()) ahead.join(); ahead_want = 0; }
+    ~BlockStream() { drop_ahead(); }
     // compressed bytes per fill: small right after a seek (a contig of a few reads must not cost a 32 MB
     // read + inflate), doubling up to 32 MB while the same stretch keeps being read
     static constexpr size_t kBatchMin = 256u << 10, kBatchMax = 32u << 20;
@@ -197,6 +205,7 @@ struct BlockStream {
 
     void reset(uint64_t voff)
     {
+        drop_ahead();
         next_coff = voff >> 16; skip = (size_t)(voff & 0xFFFF);
         buf.clear(); cur = 0; eof = false; err.clear(); valid = true;
         bstart.clear(); aligned = true;
@@ -217,10 +226,18 @@ struct BlockStream {
         std::vector<Blk> blks;
         size_t got = 0, used = 0, out_total = 0;
         for (;;) {
-            if (!cbuf.reserve(batch)) { err = "out of memory"; return false; }
-            if (fseeko(fp, (off_t)next_coff, SEEK_SET) != 0) { err = "seek failed"; return false; }
             const double tr0 = tnow();
-            got = fread(cbuf.p, 1, batch, fp);
+            if (ahead.joinable()) ahead.join();
+            if (ahead_want && ahead_off == next_coff && ahead_want == batch) {
+                std::swap(cbuf.p, cbuf_next.p); std::swap(cbuf.cap, cbuf_next.cap);
+                got = ahead_got;
+                ahead_want = 0;
+            } else {
+                ahead_want = 0;
+                if (!cbuf.reserve(batch)) { err = "out of memory"; return false; }
+                if (fseeko(fp, (off_t)next_coff, SEEK_SET) != 0) { err = "seek failed"; return false; }
+                got = fread(cbuf.p, 1, batch, fp);
+            }
             t_read += tnow() - tr0;
             if (got == 0) { eof = true; return false; }
             blks.clear(); used = 0; out_total = 0;
@@ -252,6 +269,19 @@ struct BlockStream {
         }
         next_coff += used;
         if (batch < kBatchMax) batch *= 2;
+        if (got >= used + 28 && cbuf_next.reserve(batch)) {            // more than the EOF marker follows: read on while this batch inflates
+            ahead_off = next_coff; ahead_want = batch; ahead_got = 0;
+            const int fd = fileno(fp);
+            ahead = std::thread([this, fd]() {
+                size_t n = 0;
+                while (n < ahead_want) {
+                    const ssize_t r = pread(fd, cbuf_next.p + n, ahead_want - n, (off_t)(ahead_off + n));
+                    if (r <= 0) break;
+                    n += (size_t)r;
+                }
+                ahead_got = n;
+            });
+        }
         const size_t base = buf.n;
         if (!buf.reserve(base + out_total)) { err = "out of memory"; return false; }
         buf.n = base + out_total;
@@ -418,6 +448,7 @@ dut_bam *dut_bam_open(const char *path, char *err, size_t err_len)
 void dut_bam_close(dut_bam *b)
 {
     if (!b) return;
+    b->st.drop_ahead();                      // a read-ahead may still be using the descriptor
     if (b->z.fp) fclose(b->z.fp);
     delete b;
 }
@@ -824,9 +855,11 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
             }
         }
         auto fetch = [&](Slot &s, int t) {
-            s.rc = dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
+            // the reference bases (one thread: read + strip the line ends) beside the record decode (all threads)
             s.bases = nullptr; s.blen = 0;
-            if (s.rc == CL_OK) dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen);
+            std::thread fb([&]() { dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen); });
+            s.rc = dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
+            fb.join();
         };
         std::thread ahead;
         io_stage_time("(before contigs)", tm);

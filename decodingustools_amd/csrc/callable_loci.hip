@@ -16,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 using namespace clk;
@@ -91,6 +92,8 @@ struct cl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    static constexpr int kCopyStreams = 4;
+    hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};   // large pageable H2D copies, one host thread each (created on first use)
     cl_options opt{};
     Opts dopt{};
     std::string err;
@@ -400,6 +403,7 @@ void cl_destroy(cl_ctx *c)
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
+    for (int i = 0; i < cl_ctx::kCopyStreams; ++i) if (c->copy_stream[i]) (void)hipStreamDestroy(c->copy_stream[i]);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -463,72 +467,113 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     if (n == 0) return CL_OK;
     if (!t->pos || !t->mapq || !t->cigar_off || !t->qual_off) return fail(c, CL_ERR_INVALID, "null tile array");
     if (c->h_pos.size() + n >= (1ull << 29)) return fail(c, CL_ERR_RANGE, "more than 2^29 reads in one contig");
-    // validation that protects the kernels' indexing
-    int32_t last = c->h_pos.empty() ? 0 : c->h_pos.back();
-    for (uint64_t i = 0; i < n; ++i) {
-        const int32_t p = t->pos[i];
-        if (p < 0 || (uint32_t)p >= c->contig_len)
-            return fail(c, CL_ERR_INVALID, "read position outside [0, contig_len): the region fetch (mod.rs:53) never yields it");
-        if (p < last) return fail(c, CL_ERR_UNSORTED, "reads are not coordinate sorted");
-        last = p;
-        if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i])
-            return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
-        if (t->cigar_off[i + 1] - t->cigar_off[i] > kLongOps) c->has_long = true;
-    }
     const uint32_t cig0 = t->cigar_off[0];
-    const uint64_t ncig = (uint64_t)t->cigar_off[n] - cig0;
-    if (ncig && !t->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
-    {
-        // reference span of every read (what k_read_prep computes as end - pos): the longest ordinary
-        // span bounds every window's candidate range, reads wider than kWideSpan get their own list
-        std::vector<uint32_t> span(n);
-        const uint64_t rbase = c->h_pos.size();
-        dut::parallel_for(n, 16384, [&](size_t i) {
-            unsigned long long l = 0;
-            for (uint32_t k = t->cigar_off[i]; k < t->cigar_off[i + 1]; ++k) {
-                const uint32_t op = t->cigar[k] & 15u;
-                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += t->cigar[k] >> 4;
-            }
-            span[i] = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;     // k_read_prep flags spans beyond the 32-bit range
-        });
-        for (uint64_t i = 0; i < n; ++i) {
-            if (span[i] > kWideSpan) {
-                c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]);
-                c->span_w = std::max(c->span_w, span[i]);
-            } else c->span_n = std::max(c->span_n, span[i]);
-        }
-    }
     const uint64_t q0 = t->qual_off[0];
+    if (t->cigar_off[n] < cig0 || t->qual_off[n] < q0) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    const uint64_t ncig = (uint64_t)t->cigar_off[n] - cig0;
     const uint64_t nq = t->qual_off[n] - q0;
+    if (ncig && !t->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
     if (nq && !t->qual) return fail(c, CL_ERR_INVALID, "null qual array");
     if (c->h_cigar.size() + ncig > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 CIGAR operations in one contig");
     if (c->q_dev + c->h_qual.size() + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality bytes in one contig");
     const uint32_t cbase = (uint32_t)c->h_cigar.size();
-    const unsigned long long qbase = c->q_dev + c->h_qual.size();
-    if (nq >= kDirectQual) {
-        // a large tile: its quality bytes go from the caller's buffer straight to the device
+    const uint64_t rbase = c->h_pos.size();
+
+    // ---- a large tile: its quality bytes go from the caller's buffer straight to the device, and they start
+    //      now.  A copy from pageable memory is staged by the runtime on the calling thread: the tile is cut into
+    //      slices that go down side by side, one host thread and stream each, while this thread validates the
+    //      tile and stages the small arrays.  All are joined before the call returns (the caller's buffer is
+    //      free again then); nothing of the context changes if the tile turns out to be invalid. ----
+    std::vector<std::thread> copiers;
+    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{copiers};
+    hipError_t copy_err[cl_ctx::kCopyStreams] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
+    const bool direct = nq >= kDirectQual;
+    if (direct) {
         cl_status fs = flush_staged_qual(c);
         if (fs != CL_OK) return fs;
         HIP_TRY(c, hipSetDevice(c->device));
         HIP_TRY(c, c->d_qual.grow_keep(c->q_dev + nq + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_qual.p + kQualPad + c->q_dev, t->qual + q0, nq, hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the caller's buffer is free again on return
-        c->q_dev += nq;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the (re)allocation above is done
+        uint8_t *dst = c->d_qual.p + kQualPad + c->q_dev;
+        const uint8_t *src = t->qual + q0;
+        const int nsl = nq >= (64ull << 20) ? cl_ctx::kCopyStreams : 1;
+        for (int i = 0; i < nsl; ++i)
+            if (!c->copy_stream[i]) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking));
+        const uint64_t per = ((nq + nsl - 1) / nsl + 4095ull) & ~4095ull;
+        for (int i = 0; i < nsl; ++i) {
+            const uint64_t a = std::min<uint64_t>(nq, per * i), b = std::min<uint64_t>(nq, per * (i + 1));
+            if (b <= a) continue;
+            copiers.emplace_back([c, dst, src, a, b, i, &copy_err]() {
+                hipError_t e = hipSetDevice(c->device);
+                if (e == hipSuccess) e = hipMemcpyAsync(dst + a, src + a, b - a, hipMemcpyHostToDevice, c->copy_stream[i]);
+                if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream[i]);
+                copy_err[i] = e;
+            });
+        }
     }
+    const unsigned long long qbase = c->q_dev + c->h_qual.size();
+
+    // ---- validation that protects the kernels' indexing, and the reference span of every read (what
+    //      k_read_prep computes as end - pos): the longest ordinary span bounds every window's candidate
+    //      range, reads wider than kWideSpan get their own list.  In chunks, on all host threads. ----
+    const size_t grain = 65536, nchunk = (n + grain - 1) / grain;
+    struct Chunk { int bad = 0; bool has_long = false; uint32_t span_n = 0, span_w = 0; std::vector<uint32_t> wide; };
+    std::vector<Chunk> ch(nchunk);
+    const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        Chunk &o = ch[k];
+        const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
+        int32_t last = a ? t->pos[a - 1] : last0;
+        for (size_t i = a; i < b; ++i) {
+            const int32_t p = t->pos[i];
+            if (p < 0 || (uint32_t)p >= c->contig_len) { if (!o.bad) o.bad = 1; }
+            else if (p < last) { if (!o.bad) o.bad = 2; }
+            last = p;
+            if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i]) { if (!o.bad) o.bad = 3; continue; }
+            if (t->cigar_off[i + 1] - t->cigar_off[i] > kLongOps) o.has_long = true;
+            if (t->cigar_off[i] < cig0 || t->cigar_off[i + 1] > cig0 + ncig) { if (!o.bad) o.bad = 3; continue; }
+            unsigned long long l = 0;
+            for (uint32_t q = t->cigar_off[i]; q < t->cigar_off[i + 1]; ++q) {
+                const uint32_t op = t->cigar[q] & 15u;
+                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += t->cigar[q] >> 4;
+            }
+            const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;      // k_read_prep flags spans beyond the 32-bit range
+            if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
+            else o.span_n = std::max(o.span_n, sp);
+        }
+    });
+    for (const Chunk &o : ch) {                                // the first offence in tile order decides the message
+        if (o.bad == 1) return fail(c, CL_ERR_INVALID, "read position outside [0, contig_len): the region fetch (mod.rs:53) never yields it");
+        if (o.bad == 2) return fail(c, CL_ERR_UNSORTED, "reads are not coordinate sorted");
+        if (o.bad == 3) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    }
+
+    // ---- staging of the small arrays (offsets rebased onto the contig's) ----
     try {
+        for (const Chunk &o : ch) {
+            if (o.has_long) c->has_long = true;
+            c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
+            for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
+        }
         c->h_pos.insert(c->h_pos.end(), t->pos, t->pos + n);
         c->h_mapq.insert(c->h_mapq.end(), t->mapq, t->mapq + n);
         c->h_cigar.insert(c->h_cigar.end(), t->cigar + cig0, t->cigar + cig0 + ncig);
-        if (nq < kDirectQual) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
-        c->h_cigar_off.reserve(c->h_cigar_off.size() + n);
-        c->h_qual_off.reserve(c->h_qual_off.size() + n);
-        for (uint64_t i = 1; i <= n; ++i) {
-            c->h_cigar_off.push_back(cbase + (t->cigar_off[i] - cig0));
-            c->h_qual_off.push_back(qbase + (t->qual_off[i] - q0));
-        }
+        if (!direct) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
+        const size_t o0 = c->h_cigar_off.size();               // == rbase + 1: entry r+1 closes read r
+        c->h_cigar_off.resize(o0 + n);
+        c->h_qual_off.resize(o0 + n);
+        uint32_t *co = c->h_cigar_off.data() + o0 - 1;
+        unsigned long long *qo = c->h_qual_off.data() + o0 - 1;
+        dut::parallel_for(n, 262144, [&](size_t i) {
+            co[i + 1] = cbase + (t->cigar_off[i + 1] - cig0);
+            qo[i + 1] = qbase + (t->qual_off[i + 1] - q0);
+        });
     } catch (const std::bad_alloc &) {
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
+    for (auto &x : copiers) x.join();
+    for (int i = 0; i < cl_ctx::kCopyStreams; ++i) HIP_TRY(c, copy_err[i]);
+    if (direct) c->q_dev += nq;
     return CL_OK;
 }
 

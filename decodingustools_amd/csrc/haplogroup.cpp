@@ -13,6 +13,7 @@
 #include <string>
 #include <unordered_map>
 #include <utility>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -713,20 +714,29 @@ int dut_find_branch_files(const char *bam_path, const char *fasta_path, const ch
         rc = dut_validate_reference(text, tl, names.data(), names.size(), tree_type, build, sizeof(build), chrom, sizeof(chrom), err, err_len);
         if (rc != CL_OK) goto out;
     }
-    tree = dut_tree_load(tree_json_path, provider, tree_type, err, err_len);
-    if (!tree) { rc = CL_ERR_INVALID; goto out; }
     for (size_t i = 0; i < names.size(); ++i) if (strcmp(names[i], chrom) == 0) { tid = (int)i; break; }
-    rc = dut_tree_collect_sites(tree, build, chrom, &sites, &rel, &n_sites);
-    if (rc != CL_OK) { set_err(err, err_len, "collect_snps failed"); goto out; }
     {
+        // Three independent pieces of work side by side: the tree JSON (one thread: parse + collect the sites),
+        // the HIP runtime + engine context (one thread), and the contig's records with their 4-bit sequences
+        // (this thread and the decode pool).  Errors are reported in the reference's order: tree, then BAM.
+        char terr[512] = {0};
+        int trc = CL_OK, crc = CL_OK;
+        cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};
+        std::thread tt([&]() {
+            tree = dut_tree_load(tree_json_path, provider, tree_type, terr, sizeof(terr));
+            if (!tree) { trc = CL_ERR_INVALID; return; }
+            trc = dut_tree_collect_sites(tree, build, chrom, &sites, &rel, &n_sites);
+            if (trc != CL_OK) snprintf(terr, sizeof(terr), "collect_snps failed");
+        });
+        std::thread ct([&]() { crc = cl_create(&opt, device_id, nullptr, &ctx); });
         dut_records rec; const uint64_t *seq_off = nullptr; const uint8_t *seq4 = nullptr;
-        rc = dut_bam_read_contig(bam, tid, &rec, &seq_off, &seq4);
-        if (rc != CL_OK) { set_err(err, err_len, dut_bam_error(bam)); goto out; }
+        const int brc = dut_bam_read_contig(bam, tid, &rec, &seq_off, &seq4);
         const uint8_t *bases = nullptr; uint64_t blen = 0;
         dut_fasta_fetch(fa, chrom, &bases, &blen);
-        cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};
-        rc = cl_create(&opt, device_id, nullptr, &ctx);
-        if (rc != CL_OK) { set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)"); goto out; }
+        tt.join(); ct.join();
+        if (trc != CL_OK) { set_err(err, err_len, terr); rc = trc; goto out; }
+        if (brc != CL_OK) { set_err(err, err_len, dut_bam_error(bam)); rc = brc; goto out; }
+        if (crc != CL_OK) { set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)"); rc = crc; goto out; }
         cl_site_tile tile;
         tile.n_reads = rec.n; tile.pos = rec.pos; tile.mapq = rec.mapq; tile.cigar_off = rec.cigar_off; tile.cigar = rec.cigar;
         tile.seq_off = seq_off; tile.seq4 = seq4;

@@ -248,7 +248,7 @@ def long_read_contig(L, depth, seed, median_len=10_000, max_reads=None):
         big = rng.random(n_runs) < 0.002
         g = np.where(big & isdel, rng.integers(50, 501, size=n_runs), g)
         refadv = m + np.where(isdel, g, 0)
-        cut = int(np.searchsorted(np.cumsum(refadv), tl)) + 1
+        cut = min(int(np.searchsorted(np.cumsum(refadv), tl)) + 1, n_runs)
         m, g, isdel = m[:cut], g[:cut], isdel[:cut]
         ops = np.empty(2 * cut, dtype=np.uint32)
         ops[0::2] = (m.astype(np.uint32) << 4) | 0
@@ -299,7 +299,7 @@ def adversarial_contig(L, n_reads, seed, max_len=300, same_start_bursts=True, de
             j = int(rng.integers(0, n_reads - 12))
             starts[j:j + 12] = starts[j]
         starts = np.sort(starts)
-    if deep:
+    if deep and n_reads > 1:
         j = n_reads // 3
         cnt = min(n_reads - j - 1, 400)
         starts[j:j + cnt] = starts[j] + rng.integers(0, 30, size=cnt)

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Tooling: time-boxed differential fuzz of the device path against the CPU oracle (the GPU tests' `compare`:
+per-position counters, states, sums, BED bytes), with seeds and shapes beyond the fixed ones of tests/.
+    python tools/fuzz_parity.py [seconds] [first_seed]
+Prints one line per round; stops at the first mismatch (the assertion names the round)."""
+import os, sys, time, tempfile, pathlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import test_gpu_parity as T
+from decodingustools_amd import synth
+from decodingustools_amd.records import ContigRecords
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
+t_end = time.time() + budget
+rnd = 0
+while time.time() < t_end:
+    seed = seed0 + rnd
+    rng = np.random.default_rng(seed)
+    opt = dict(min_depth=int(rng.integers(0, 12)), max_depth=int(rng.choice([0, 3, 20, 60, 150, 500, 100000])),
+               min_mapping_quality=int(rng.choice([0, 1, 10, 30, 61])), min_base_quality=int(rng.choice([0, 1, 13, 20, 40, 127, 128, 129, 200, 255])),
+               min_depth_for_low_mapq=int(rng.integers(0, 15)), max_low_mapq=int(rng.choice([0, 1, 5, 60])),
+               max_low_mapq_fraction=float(rng.choice([0.0, 0.05, 0.1, 0.5, 0.999])))
+    kind = int(rng.integers(0, 6))
+    L = int(rng.choice([1, 300, 2047, 2048, 2049, 4097, 10_000, 40_000, 100_000]))
+    if kind == 0:
+        rec = synth.adversarial_contig(L, int(rng.integers(0, 1500)), seed, max_len=int(rng.choice([2, 50, 300, 3000])) if L > 1 else 1,
+                                       deep=bool(rng.integers(0, 2)), overhang=bool(rng.integers(0, 2))) if L > 1 else ContigRecords.empty()
+    elif kind == 1:
+        L = max(L, 2048)
+        rec = synth.short_read_contig(L, float(rng.choice([1, 8, 30, 70])), seed, max_live_assert=100_000)
+    elif kind == 2:
+        L = max(L, 10_000)
+        rec = synth.long_read_contig(L, float(rng.choice([5, 30, 60])), seed)
+    elif kind == 3:
+        L = max(L, 10_000)
+        rec = T._eqx_split(synth.long_read_contig(L, float(rng.choice([5, 40])), seed), seed)
+    elif kind == 4:
+        L = max(L, 10_000)
+        rec = T._stacked_multi_op_reads(int(rng.integers(50, 2500)), min(3000, L // 3), min(9000, L - 200), seed, long_every=int(rng.integers(3, 15)))
+    else:
+        L = max(L, 2048)
+        a = synth.short_read_contig(L, 20, seed, max_live_assert=100_000)
+        rec = a
+    ref = synth.make_reference(L, seed + 1, lowercase=bool(rng.integers(0, 2))) if rng.random() < 0.9 else None
+    with tempfile.TemporaryDirectory() as d:
+        T.compare([(f"f{seed}", int(rng.integers(0, 3)), L, ref, rec)], opt, pathlib.Path(d), f"fuzz{seed}")
+    print(f"round {rnd} seed {seed} kind {kind} L {L} reads {rec.n} ok", flush=True)
+    rnd += 1
+print(f"{rnd} rounds, no mismatch")

@@ -316,8 +316,8 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
 
 // ---------------------------------------------------------------------------------------------
 // k_read_prep_long: the reads k_read_prep diverted (more than kLongOps CIGAR ops, e.g. long reads
-// with an indel every ~15 bases), one wave per read.  The wave scans the CIGAR in aligned chunks
-// of 64 ops (one op per lane, wave prefix sums of the reference / query advance) and stores, for
+// with an indel every ~15 bases), one wave per read.  The wave scans the CIGAR 256 ops at a time
+// (four consecutive ops per lane, wave prefix sums of the reference / query advance) and stores, for
 // every op index k that is a multiple of 64 inside the read, the reference and query position
 // before op k: ck_x[k/64], ck_y[k/64].  k_pileup starts its walk at the checkpoint nearest to the
 // window instead of at the read's first op.  Same outputs as k_read_prep otherwise.
@@ -340,33 +340,44 @@ __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint
         const uint32_t ps = (uint32_t)R.pos[r];
         unsigned long long xc = 0;                       // reference / query advance before the chunk
         uint32_t yc = 0;
-        // two chunks of 64 ops per trip: both loads are issued before the first scan
-        for (uint32_t kb = k0 & ~63u; kb < k1; kb += 128u) {
-            uint32_t c2[2];
+        // 256 ops per trip: four consecutive ops per lane (one 16-byte load; the next trip's is issued before
+        // this one is summed), lane-local sums, three DPP scans; the four checkpoints of the trip are the
+        // scan values in front of lanes 0, 16, 32, 48.  Lengths are 28-bit: their low 16 and high 12 bits are
+        // summed separately (a trip's sums stay below 2^24 / 2^20), exactly.
+        auto load4 = [&](uint32_t kb, Q16 &t) {
+            const uint32_t kl = kb + 4u * lane;
+            t.w[0] = 5u; t.w[1] = 5u; t.w[2] = 5u; t.w[3] = 5u;          // outside the read: H, advances nothing
+            if (kl < k1 && kl + 4u > k0) __builtin_memcpy(&t, R.cigar + kl, 16);   // at most 12 bytes past the read's words
+        };
+        const uint32_t kb0 = k0 & ~63u;
+        Q16 nxt;
+        load4(kb0, nxt);
+        for (uint32_t kb = kb0; kb < k1; kb += 256u) {
+            const Q16 cur = nxt;
+            if (kb + 256u < k1) load4(kb + 256u, nxt);
+            const uint32_t kl = kb + 4u * lane;
+            uint32_t s_lo = 0, s_hi = 0, s_q = 0;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t k = kb + 64u * h + lane;
-                c2[h] = (k >= k0 && k < k1) ? R.cigar[k] : 5u;       // outside the read: H, advances nothing
-            }
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const uint32_t kc = kb + 64u * h;
-                if (kc >= k1) break;
-                const uint32_t c = c2[h], op = c & 15u, l = c >> 4;
+            for (uint32_t j = 0; j < 4u; ++j) {
+                const bool in = (kl + j) >= k0 && (kl + j) < k1;
+                const uint32_t c = in ? cur.w[j] : 5u, op = c & 15u, l = c >> 4;
                 const bool radv = ((0x18Du >> op) & 1u) != 0u, qadv = ((0x193u >> op) & 1u) != 0u;
-                if (radv && l == 0 && (kc + lane) >= k0 && (kc + lane) < k1) err |= kErrCigar;   // zero-length reference-consuming op
+                if (radv && l == 0 && in) err |= kErrCigar;               // zero-length reference-consuming op
                 const uint32_t rl = radv ? l : 0u;
-                // sum of up to 64 28-bit lengths, exactly: low 16 and high 12 bits separately
-                const unsigned long long tot_r = ((unsigned long long)dpp_wave_sum_u32(rl >> 16) << 16) + dpp_wave_sum_u32(rl & 0xFFFFu);
-                const uint32_t tot_q = dpp_wave_sum_u32(qadv ? l : 0u);
-                if (lane == 0 && kc >= k0) {
-                    const unsigned long long cx = (unsigned long long)ps + xc;
-                    ck_x[kc >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
-                    ck_y[kc >> 6] = yc;
-                }
-                xc += tot_r;
-                yc += tot_q;
+                s_lo += rl & 0xFFFFu; s_hi += rl >> 16; s_q += qadv ? l : 0u;
             }
+            const uint32_t i_lo = dpp_incl_scan_u32(s_lo), i_hi = dpp_incl_scan_u32(s_hi), i_q = dpp_incl_scan_u32(s_q);
+            // lanes 0, 16, 32, 48 hold the sums in front of the trip's four 64-op chunks
+            if ((lane & 15u) == 0u) {
+                const uint32_t kc = kb + 4u * lane;
+                if (kc >= k0 && kc < k1) {
+                    const unsigned long long cx = (unsigned long long)ps + xc + (((unsigned long long)(i_hi - s_hi) << 16) + (i_lo - s_lo));
+                    ck_x[kc >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
+                    ck_y[kc >> 6] = yc + (i_q - s_q);
+                }
+            }
+            xc += ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)i_hi, 63) << 16) + (uint32_t)__builtin_amdgcn_readlane((int)i_lo, 63);
+            yc += (uint32_t)__builtin_amdgcn_readlane((int)i_q, 63);
         }
         if (lane == 0) {
             const unsigned long long e = (unsigned long long)ps + xc;

@@ -391,6 +391,15 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     shutil.copy(bam, bam_ni)
     coverage_files(bam_ni, fa, str(tmp_path / "g1.bed"), str(tmp_path / "s1.json"), CallableOptions(), output_summary="rep.html")
     assert open(tmp_path / "g1.bed").read() == o_bed
+    # a file cut off inside a later contig: the error comes back from the read-ahead thread, nothing hangs
+    from decodingustools_amd import EngineError
+    bam_cut = str(tmp_path / "cut.bam")
+    data = open(bam, "rb").read()
+    open(bam_cut, "wb").write(data[:int(len(data) * 0.8)])
+    shutil.copy(bam + ".bai", bam_cut + ".bai")
+    with pytest.raises(EngineError) as ei:
+        coverage_files(bam_cut, fa, str(tmp_path / "g2.bed"), None, CallableOptions())
+    assert "Error processing contig" in str(ei.value) or "BAM" in str(ei.value)
     # summary.json: the CoverageOutput text, byte for byte (oracle: report.rs:15-134 + serde_json pretty)
     from oracle import report_oracle as RO
     hdr = "@HD\tVN:1.6\tSO:coordinate\n" + "".join(f"@SQ\tSN:{n}\tLN:{l}\n" for n, l in zip(names, lens))

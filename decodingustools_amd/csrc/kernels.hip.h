@@ -123,6 +123,15 @@ __device__ __forceinline__ uint32_t dpp_incl_scan_u32(uint32_t v)
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);
     return v;
 }
+// inclusive prefix sum within each row of 16 lanes (the first four steps of the above)
+__device__ __forceinline__ uint32_t dpp_row_incl_scan_u32(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);
+    return v;
+}
 // the maximum over the wave, in every lane (same DPP pattern; the zero fill is the identity of an unsigned max)
 __device__ __forceinline__ uint32_t dpp_wave_max_u32(uint32_t v)
 {
@@ -476,9 +485,12 @@ struct PileupArgs {
 // wave's 16 quads work on at the same time are ~16 reads apart and rarely share a counter word.
 //
 // LONG = 1 or 4 (contigs with >= 8 CIGAR operations per read on average): the lane-serial CIGAR walk is
-// replaced by an operation-parallel one -- live reads are compacted, a wave takes 64 operations of a
-// read at a time, two DPP scans give every operation its reference / query start, each lane consumes
-// its own M/=/X run (runs longer than 64 bases go through the list and the quad loop).
+// replaced by an operation-parallel one -- live reads are compacted; LONG = 1: a wave takes 64 operations
+// of a read at a time, two DPP scans give every operation its reference / query start, each lane consumes
+// its own M/=/X run (runs longer than 64 bases go through the list and the quad loop); LONG = 4 (operations
+// average < 32 bases): the (read, 64-operation block) pairs that can touch the window form one flat list,
+// a wave trip takes four of them, one per row of 16 lanes, four operations per lane, starting from the
+// blocks' checkpoints.
 //
 // DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window has <= 32767 candidates
 // (otherwise window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one
@@ -601,6 +613,8 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     // LONG: the live reads of a pass, two entries each: {candidate number, op index, x, y}, {op end, quality offset, quality length, -}
     __shared__ __attribute__((aligned(16))) uint4 s_live[LONG ? 2 * kBlock : 1];
     __shared__ uint32_t s_nlive;
+    // LONG = 4: first block number of every live read of the pass (+ the total at [n])
+    __shared__ uint32_t s_blk[LONG == 4 ? kBlock + 1 : 1];
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
     // each XCD one contiguous range of windows so neighbouring windows share its L2.
@@ -723,10 +737,12 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
         bool live = false;
         uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
+        uint32_t nblk = 0, lim0 = 0, k0r = 0;        // LONG = 4
         if (v < n_cand) {
             x = (uint32_t)a.R.pos[r];
             const uint32_t e = a.end[r], mq = a.R.mapq[r];
             k = a.R.cigar_off[r];
+            k0r = k;
             k1 = a.R.cigar_off[r + 1];
             const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
             qrel = (uint32_t)(q0 - qwin);
@@ -760,6 +776,24 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 }
             }
             if (!LONG && live) cw = a.R.cigar[k];    // invariant: cw == cigar[k] while live
+            if constexpr (LONG == 4) {
+                // blocks of the read that can touch the window: the one the walk starts in (it ends at the next
+                // multiple of 64 in the contig's operation numbering, where the next checkpoint sits), then one
+                // per checkpoint in front of the window's end
+                nblk = 1u; lim0 = k1;
+                if (live && k1 - k0r > kLongOps) {
+                    const uint32_t jn = (k >> 6) + 1u, jmax = (k1 - 1u) >> 6;
+                    lim0 = (jn << 6) < k1 ? (jn << 6) : k1;
+                    if (jn <= jmax) {
+                        uint32_t lo_j = jn, hi_j = jmax + 1u;           // first j in [jn, jmax] with ck_x[j] >= Wend (jmax + 1: none)
+                        while (lo_j < hi_j) {
+                            const uint32_t mid = lo_j + ((hi_j - lo_j) >> 1);
+                            if (a.ck_x[mid] < Wend) lo_j = mid + 1u; else hi_j = mid;
+                        }
+                        nblk += lo_j - jn;
+                    }
+                }
+            }
         }
         if constexpr (LONG) {
             // ---- long-read shape: CIGAR operations in parallel.  The live reads of the pass are
@@ -776,24 +810,192 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 wb = __shfl(wb, 0, 64);
                 if (live) {
                     const uint32_t idx = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    s_live[2u * idx] = make_uint4(v, k, x, y);
-                    s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
+                    if constexpr (LONG == 4) {
+                        s_live[2u * idx] = make_uint4(k, x, y, nblk | ((v & 1u) << 31));
+                        s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, lim0);
+                    } else {
+                        s_live[2u * idx] = make_uint4(v, k, x, y);
+                        s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
+                    }
                 }
             }
             __syncthreads();
             const uint32_t nl = s_nlive;
+            if constexpr (LONG == 4) {
+                // ---- short runs (an indel every few bases): blocks of <= 64 operations are independent once the
+                //      checkpoints give their reference / query start, so the pass's work is the flat list of
+                //      (read, block) pairs that can touch the window.  A wave trip takes four blocks, one per row of
+                //      16 lanes, four operations per lane (one 16-byte load): the blocks of one trip may belong to
+                //      different reads, every trip is full, nothing is carried from trip to trip, and the next
+                //      trip's operations and checkpoints are requested before this one is consumed. ----
+                {   // exclusive prefix of the block counts over the live reads
+                    uint32_t n = 0;
+                    if (tid < nl) n = s_live[2u * tid].w & 0x7FFFFFFFu;
+                    const uint32_t inc = dpp_incl_scan_u32(n);
+                    if (lane == 63) s_wraw[wv] = inc;
+                    __syncthreads();
+                    uint32_t off = 0;
+                    for (uint32_t i = 0; i < wv; ++i) off += s_wraw[i];
+                    if (tid < nl) s_blk[tid] = off + inc - n;
+                    if (tid == kBlock - 1) s_blk[nl] = off + inc;
+                    __syncthreads();
+                }
+                const uint32_t nb = s_blk[nl];
+                const uint32_t g = lane >> 4, li = lane & 15u;
+                uint32_t ri = 0;                                      // the row's position in the read list (monotone)
+                struct Blk { uint32_t i, base_k, lim, d; };
+                auto locate = [&](uint32_t b, Blk &o) {               // b < nb
+                    while (ri + 1u < nl && s_blk[ri + 1u] <= b) ++ri;
+                    const uint4 A = s_live[2u * ri], B = s_live[2u * ri + 1u];
+                    o.i = ri; o.d = b - s_blk[ri];
+                    o.base_k = o.d ? (((A.x >> 6) + o.d) << 6) : A.x;
+                    o.lim = o.d ? ((o.base_k + 64u) < B.x ? (o.base_k + 64u) : B.x) : B.w;
+                };
+                auto request = [&](const Blk &o, bool on, Q16 &cw4, uint32_t &cx, uint32_t &cy) {
+                    const uint32_t kl = o.base_k + 4u * li;
+                    cw4.w[0] = 5u; cw4.w[1] = 5u; cw4.w[2] = 5u; cw4.w[3] = 5u;      // beyond the block: H, advances nothing
+                    cx = 0u; cy = 0u;
+                    if (on && kl < o.lim) __builtin_memcpy(&cw4, a.R.cigar + kl, 16);   // at most 12 bytes past the read's words
+                    if (on && o.d) { cx = a.ck_x[o.base_k >> 6]; cy = a.ck_y[o.base_k >> 6]; }
+                };
+                Blk cur, nxt;
+                cur.i = 0; cur.base_k = 0; cur.lim = 0; cur.d = 0; nxt = cur;
+                Q16 cw_c, cw_n;
+                uint32_t cx_c = 0, cy_c = 0, cx_n = 0, cy_n = 0;
+                uint32_t tb = 4u * wv;                                // first block of the wave's current trip
+                bool on = tb + g < nb;
+                if (on) locate(tb + g, cur);
+                request(cur, on, cw_c, cx_c, cy_c);
+                while (tb < nb) {                                     // wave-uniform
+                    const uint32_t tbn = tb + 4u * (uint32_t)kWaves;
+                    const bool on_n = tbn + g < nb;
+                    if (on_n) locate(tbn + g, nxt);
+                    request(nxt, on_n, cw_n, cx_n, cy_n);
+                    // ---- this trip ----
+                    const uint4 A = s_live[2u * cur.i], B = s_live[2u * cur.i + 1u];
+                    const uint32_t rqrel = B.y, rqlen = B.z, rset = (A.w >> 31) << 30;
+                    const uint32_t kl = cur.base_k + 4u * li;
+                    uint32_t cwl[4], ax[4], ay[4], tx = 0, ty = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        cwl[j] = (on && (kl + j) < cur.lim) ? cw_c.w[j] : 5u;
+                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
+                        ax[j] = ((0x18Du >> op) & 1u) ? l : 0u;
+                        ay[j] = ((0x193u >> op) & 1u) ? l : 0u;
+                        tx += ax[j]; ty += ay[j];
+                    }
+                    const uint32_t ix = dpp_row_incl_scan_u32(tx), iy = dpp_row_incl_scan_u32(ty);
+                    uint32_t xs = (cur.d ? cx_c : A.y) + (ix - tx), ys = (cur.d ? cy_c : A.z) + (iy - ty);
+                    auto unit = [&](const Q16 &v, uint32_t u, uint32_t srel, uint32_t trel) {
+                        const uint32_t ps = u << 4;
+                        const uint32_t vs = srel > ps ? srel - ps : 0u;
+                        const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                        const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                        const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                        if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
+                        else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                        else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                    };
+                    auto run_direct = [&](uint32_t sr, uint32_t tr, uint32_t q) {
+                        const uint32_t qb = q + (uint32_t)kQualPad - sr;
+                        for (uint32_t u = sr >> 4; u <= (tr - 1u) >> 4; ++u) {
+                            Q16 v;
+                            __builtin_memcpy(&v, qbase + (qb + (u << 4)), 16);
+                            unit(v, u, sr, tr);
+                        }
+                    };
+                    // the lane's first two short runs (A, B) are consumed together below; a third or fourth
+                    // (=/X strings) and runs > 64 bases at once
+                    uint32_t a_st = 0, a_q = 0, b_st = 0, b_q = 0, ns = 0;
+#pragma unroll
+                    for (uint32_t j = 0; j < 4u; ++j) {
+                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
+                        const bool ism = ((0x181u >> op) & 1u) != 0u;
+                        const uint32_t xe = xs + ax[j];
+                        const uint32_t sp = xs > W ? xs : W;
+                        const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
+                        uint32_t tp = xe < Wend ? xe : Wend;
+                        tp = (xs + lq) < tp ? (xs + lq) : tp;
+                        const bool valid = ism && sp < tp && !(a.ablate & 1u);
+                        const uint32_t sr = sp - W, tr = tp - W;
+                        const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
+                        const bool big = valid && (tr - sr) > 64u;
+                        xs = xe; ys += ay[j];
+                        if (valid && !big) {
+                            if (ns == 0u) { a_st = sr | (tr << 16); a_q = q; }
+                            else if (ns == 1u) { b_st = sr | (tr << 16); b_q = q; }
+                            else run_direct(sr, tr, q);
+                            ns += 1u;
+                        }
+                        const unsigned long long bm = __ballot(big);
+                        if (bm) {                                    // wave-uniform: long runs go through the list
+                            if (big) {
+                                const uint32_t idx = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
+                                list[idx] = make_uint2(q, sr | ((tr - sr - 1u) << 16) | rset | 0x80000000u);
+                            }
+                            const uint32_t n_list = n_keep + (uint32_t)__popcll(bm);
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            const uint32_t n_full = n_list & ~15u;
+                            if (n_full) consume_list(n_full);
+                            n_keep = n_list - n_full;
+                            uint2 carry = make_uint2(0u, 0u);
+                            if (n_full && lane < n_keep) carry = list[n_full + lane];
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                            if (n_full && lane < n_keep) list[lane] = carry;
+                        }
+                    }
+                    {   // the first two units of A and of B are requested together (a ~15-base run covers one or two)
+                        const uint32_t a_sr = a_st & 0xFFFFu, a_tr = a_st >> 16, b_sr = b_st & 0xFFFFu, b_tr = b_st >> 16;
+                        const uint32_t a_qb = a_q + (uint32_t)kQualPad - a_sr, b_qb = b_q + (uint32_t)kQualPad - b_sr;
+                        const uint32_t a_u0 = a_sr >> 4, a_u1 = ns >= 1u ? (a_tr - 1u) >> 4 : 0u;
+                        const uint32_t b_u0 = b_sr >> 4, b_u1 = ns >= 2u ? (b_tr - 1u) >> 4 : 0u;
+                        Q16 va0, va1, vb0, vb1;
+                        if (ns >= 1u) {
+                            __builtin_memcpy(&va0, qbase + (a_qb + (a_u0 << 4)), 16);
+                            __builtin_memcpy(&va1, qbase + (a_qb + ((a_u0 + 1u <= a_u1 ? a_u0 + 1u : a_u0) << 4)), 16);
+                        }
+                        if (ns >= 2u) {
+                            __builtin_memcpy(&vb0, qbase + (b_qb + (b_u0 << 4)), 16);
+                            __builtin_memcpy(&vb1, qbase + (b_qb + ((b_u0 + 1u <= b_u1 ? b_u0 + 1u : b_u0) << 4)), 16);
+                        }
+                        if (ns >= 1u) {
+                            unit(va0, a_u0, a_sr, a_tr);
+                            if (a_u0 + 1u <= a_u1) unit(va1, a_u0 + 1u, a_sr, a_tr);
+                        }
+                        if (ns >= 2u) {
+                            unit(vb0, b_u0, b_sr, b_tr);
+                            if (b_u0 + 1u <= b_u1) unit(vb1, b_u0 + 1u, b_sr, b_tr);
+                        }
+                        if (ns >= 1u)
+                            for (uint32_t u = a_u0 + 2u; u <= a_u1; ++u) {
+                                Q16 v;
+                                __builtin_memcpy(&v, qbase + (a_qb + (u << 4)), 16);
+                                unit(v, u, a_sr, a_tr);
+                            }
+                        if (ns >= 2u)
+                            for (uint32_t u = b_u0 + 2u; u <= b_u1; ++u) {
+                                Q16 v;
+                                __builtin_memcpy(&v, qbase + (b_qb + (u << 4)), 16);
+                                unit(v, u, b_sr, b_tr);
+                            }
+                    }
+                    cur = nxt; on = on_n; cw_c = cw_n; cx_c = cx_n; cy_c = cy_n;
+                    tb = tbn;
+                }
+            } else
             for (uint32_t it = wv; it < nl; it += (uint32_t)kWaves) {
                 const uint4 A = s_live[2u * it], B = s_live[2u * it + 1u];
                 uint32_t rk = A.y, rx = A.z, ry = A.w;
                 const uint32_t rk1 = B.x, rqrel = B.y, rqlen = B.z;
                 const uint32_t rset = (A.x & 1u) << 30;
-                // kOpl = LONG consecutive operations per lane and trip.  4 (one 16-byte load) for contigs whose
-                // operations average < 32 bases: with an indel every ~15 bases half the operations carry no
-                // bases, so a lane's four hold about two runs; all their quality loads are issued before the
-                // first is consumed, and a trip covers 256 operations (fewer trips = fewer exposed load
-                // latencies, the limiter of that shape).  1 for long match runs (HiFi: every run goes through
-                // the list anyway, and the 4-op form costs a wave of occupancy).
-                constexpr uint32_t kOpl = LONG ? (uint32_t)LONG : 1u;
+                // LONG = 1 (long match runs, HiFi): a wave takes a read and 64 of its operations at a time, one per
+                // lane; every run goes through the list anyway, and the four-operation form above costs a wave of
+                // occupancy.  (The loop is written for kOpl operations per lane; only kOpl = 1 is instantiated.)
+                constexpr uint32_t kOpl = 1u;
                 auto load_ops = [&](uint32_t kb, uint32_t (&wd)[kOpl]) {
                     const uint32_t kl = kb + kOpl * lane;
                     if constexpr (kOpl == 1u) {

@@ -970,18 +970,18 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                             unit(vb0, b_u0, b_sr, b_tr);
                             if (b_u0 + 1u <= b_u1) unit(vb1, b_u0 + 1u, b_sr, b_tr);
                         }
-                        if (ns >= 1u)
-                            for (uint32_t u = a_u0 + 2u; u <= a_u1; ++u) {
-                                Q16 v;
-                                __builtin_memcpy(&v, qbase + (a_qb + (u << 4)), 16);
-                                unit(v, u, a_sr, a_tr);
-                            }
-                        if (ns >= 2u)
-                            for (uint32_t u = b_u0 + 2u; u <= b_u1; ++u) {
-                                Q16 v;
-                                __builtin_memcpy(&v, qbase + (b_qb + (u << 4)), 16);
-                                unit(v, u, b_sr, b_tr);
-                            }
+                        // what is left of runs longer than two units (few lanes): one loop for both runs, a lane
+                        // takes A's next unit, then B's
+                        uint32_t ua = ns >= 1u ? a_u0 + 2u : 1u, ub2 = ns >= 2u ? b_u0 + 2u : 1u;
+                        const uint32_t ea = ns >= 1u ? a_u1 : 0u, eb = ns >= 2u ? b_u1 : 0u;
+                        while (ua <= ea || ub2 <= eb) {
+                            const bool fa = ua <= ea;
+                            const uint32_t u = fa ? ua : ub2;
+                            Q16 v;
+                            __builtin_memcpy(&v, qbase + ((fa ? a_qb : b_qb) + (u << 4)), 16);
+                            unit(v, u, fa ? a_sr : b_sr, fa ? a_tr : b_tr);
+                            if (fa) ++ua; else ++ub2;
+                        }
                     }
                     cur = nxt; on = on_n; cw_c = cw_n; cx_c = cx_n; cy_c = cy_n;
                     tb = tbn;

@@ -266,9 +266,13 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     // the 32-bit counter variant is used only after window_bounds asked for it (kNeedDeep)
     const bool orf = c->opt.min_base_quality <= 128;
     // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel variant
-    const bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
+    bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
     // ... with short runs (operations average < 32 bases: an indel every few bases): four operations per lane
-    const bool lng4 = lng && c->n_qual < 32ull * c->n_cigar;
+    bool lng4 = lng && c->n_qual < 32ull * c->n_cigar;
+    if (const char *fl = getenv("CL_FORCE_LONG")) {               // timing experiments: pick the variant by hand
+        const int v = atoi(fl);
+        lng = v != 0; lng4 = v == 4;
+    }
 #define CL_LAUNCH(ORF_, DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, ORF_, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
 #define CL_LAUNCH_L(ORF_, DEEP_) do { if (lng4) CL_LAUNCH(ORF_, DEEP_, 4); else if (lng) CL_LAUNCH(ORF_, DEEP_, 1); else CL_LAUNCH(ORF_, DEEP_, 0); } while (0)
     if (!c->deep) { if (orf) CL_LAUNCH_L(true, false); else CL_LAUNCH_L(false, false); }

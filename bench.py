@@ -157,7 +157,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        eng.contig_run()             # memset + five kernel launches on the engine's stream
+        eng.contig_run()             # four kernel launches on the engine's stream
     eng.sync()
     torch.cuda.synchronize()
     if world > 1:

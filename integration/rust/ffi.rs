@@ -1,0 +1,38 @@
+//! src/callable_loci/ffi.rs -- one declaration per symbol of include/callable_loci.h that the
+//! coverage path uses.  Not compiled in this repository (no Rust toolchain in the image).
+use std::os::raw::{c_char, c_int, c_void};
+
+#[repr(C)]
+pub struct ClOptions {            // CallableOptions, options.rs:2-9
+    pub min_depth: u32, pub max_depth: u32,
+    pub min_mapping_quality: u8, pub min_base_quality: u8,
+    pub min_depth_for_low_mapq: u32, pub max_low_mapq: u8,
+    pub max_low_mapq_fraction: f64,
+}
+#[repr(C)]
+pub struct ClReadTile {
+    pub n_reads: u64,
+    pub pos: *const i32, pub mapq: *const u8,
+    pub cigar_off: *const u32, pub cigar: *const u32,
+    pub qual_off: *const u64, pub qual: *const u8,
+}
+#[repr(C)] #[derive(Default)]
+pub struct ClContigSummary {
+    pub state_counts: [u64; 6],   // indexed by CalledState as usize (types.rs:36-43)
+    pub n_covered_bases: u64, pub summed_coverage: u64, pub summed_baseq: u64,
+    pub summed_mapq: u64, pub quality_bases: u64,
+    pub extent: u64, pub max_raw_depth: u64, pub n_intervals: u64,
+}
+#[repr(C)] pub struct ClInterval { pub start: u32, pub end: u32, pub state: u32 }
+pub enum ClCtx {}
+
+extern "C" {
+    pub fn cl_create(opt: *const ClOptions, device_id: c_int, stream: *mut c_void, out: *mut *mut ClCtx) -> c_int;
+    pub fn cl_destroy(ctx: *mut ClCtx);
+    pub fn cl_last_error(ctx: *const ClCtx) -> *const c_char;
+    pub fn cl_contig_begin(ctx: *mut ClCtx, tid: i32, contig_len: u32, ref_bases: *const u8, ref_len: u64) -> c_int;
+    pub fn cl_contig_reserve(ctx: *mut ClCtx, n_reads: u64, n_cigar_ops: u64, n_qual_bytes: u64) -> c_int; // optional hint
+    pub fn cl_push_reads(ctx: *mut ClCtx, tile: *const ClReadTile) -> c_int;
+    pub fn cl_contig_finish(ctx: *mut ClCtx, out: *mut ClContigSummary,
+                            iv: *mut *const ClInterval, n_iv: *mut usize) -> c_int;
+}

@@ -117,6 +117,10 @@ SYMBOLS = [
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     ("dut_profiler_new", C.c_void_p, [C.c_char_p]),
     ("dut_profiler_free", None, [C.c_void_p]),
+    ("dut_profiler_enable_plots", None, [C.c_void_p, C.c_uint32]),
+    ("dut_profiler_plot_bins", C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32, C.POINTER(C.c_uint32), C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    ("dut_profiler_finish_plot", C.c_int, [C.c_void_p, C.c_char_p, C.c_uint32]),
     ("dut_profiler_contig_counts", None, [C.c_void_p, C.c_char_p, C.POINTER(C.c_uint64)]),
     ("dut_profiler_feed_contig", C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t,
                                            C.POINTER(C.c_uint64)]),
@@ -178,6 +182,8 @@ SYMBOLS = [
                                            C.POINTER(C.c_uint64), C.c_size_t, C.POINTER(dut_export_meta),
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     ("dut_free", None, [C.c_void_p]),
+    ("dut_write_html_report", C.c_int, [C.POINTER(dut_contig_stats), C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.c_size_t,
+                                        C.POINTER(dut_export_meta), C.c_uint64, C.c_char_p]),
     # include/dut_haplogroup.h
     ("dut_tree_parse", C.c_void_p, [C.c_char_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),
     ("dut_tree_load", C.c_void_p, [C.c_char_p, C.c_int, C.c_int, C.c_char_p, C.c_size_t]),

@@ -88,9 +88,11 @@ class FastaReader:
 
 def coverage_files(bam_file: str, reference_file: str, output_bed: str = "callable_regions.bed",
                    summary_json: str = None, options: CallableOptions = None, contigs=None, device_id: int = 0,
-                   output_summary: str = "summary.html"):
+                   output_summary: str = None):
     """CoverageAnalyzer::analyze on files (CoverageInput of api/coverage.rs:124-132); summary_json
-    receives the CoverageOutput JSON of main.rs:68-69, output_summary is only named in it."""
+    receives the CoverageOutput JSON of main.rs:68-69; output_summary, when given, the HTML report
+    (api/coverage.rs:104; None: not written, the JSON then names "summary.html").  The per-contig coverage
+    figures `<contig>_coverage.svg` go beside the BED file (callable_profiler.rs:80-84)."""
     lib = _lib.load()
     options = options or CallableOptions()
     oc = options.to_c()
@@ -101,7 +103,7 @@ def coverage_files(bam_file: str, reference_file: str, output_bed: str = "callab
         arr = (C.c_char_p * max(n, 1))(*[c.encode() for c in contigs])
     err = C.create_string_buffer(1024)
     st = lib.dut_coverage_files(bam_file.encode(), reference_file.encode(), output_bed.encode(),
-                                summary_json.encode() if summary_json else None, output_summary.encode(),
+                                summary_json.encode() if summary_json else None, output_summary.encode() if output_summary else None,
                                 C.byref(oc), arr, n, device_id, err, 1024)
     if st != 0:
         raise EngineError(st, err.value.decode())

@@ -222,6 +222,31 @@ class CallableProfiler:
             raise OSError(f"cannot create {bed_file}")
         self.largest_contig_length = largest_contig_length
 
+    def enable_plots(self, largest_contig_length: Optional[int] = None):
+        """From here on every BED line of a plotted state is a range of the current contig's coverage figure
+        (callable_profiler.rs:48-59); `finish_plot` writes `<dir of the BED>/<contig>_coverage.svg`."""
+        if largest_contig_length is not None:
+            self.largest_contig_length = largest_contig_length
+        self._lib.dut_profiler_enable_plots(self._h, self.largest_contig_length)
+
+    def plot_bins(self, contig: str, contig_length: int):
+        """(stride, callable, low_qual, ref_n): positions of the three plotted states per stride of the
+        pending ranges (histogram_plotter.rs:74-101)."""
+        n = C.c_size_t(); stride = C.c_uint32()
+        st = self._lib.dut_profiler_plot_bins(self._h, contig.encode(), contig_length, C.byref(stride), None, None, None, 0, C.byref(n))
+        if st != 0:
+            raise EngineError(st, "dut_profiler_plot_bins failed")
+        a = [np.zeros(n.value, np.uint32) for _ in range(3)]
+        self._lib.dut_profiler_plot_bins(self._h, contig.encode(), contig_length, C.byref(stride), _ptr(a[0]), _ptr(a[1]), _ptr(a[2]),
+                                         n.value, C.byref(n))
+        return int(stride.value), a[0], a[1], a[2]
+
+    def finish_plot(self, contig: str, contig_length: int) -> bool:
+        st = self._lib.dut_profiler_finish_plot(self._h, contig.encode(), contig_length)
+        if st < 0:
+            raise EngineError(st, "dut_profiler_finish_plot failed")
+        return st == 1
+
     def get_contig_counts(self, contig: str):
         out = (C.c_uint64 * 6)()
         self._lib.dut_profiler_contig_counts(self._h, contig.encode(), out)

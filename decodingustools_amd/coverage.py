@@ -140,12 +140,16 @@ def write_bed(outcomes: List[ContigOutcome], bed_path: str):
     """One CallableProfiler over all contigs in ascending tid (api/coverage.rs:229-234), which
     reproduces the duplicated last line of every contig but the last (callable_profiler.rs:64-66)."""
     counter = CallableProfiler(bed_path)
+    # the coverage figures beside the BED (callable_profiler.rs:64-84; stride from the longest contig but chrM,
+    # api/coverage.rs:210-215)
+    counter.enable_plots(max([o.stats.length for o in outcomes if o.stats.name != "chrM"], default=0))
     try:
         for o in sorted(outcomes, key=lambda o: o.tid):
             class _S:                      # feed_contig only needs .state_counts and .intervals
                 pass
             r = _S(); r.state_counts = o.state_counts; r.intervals = o.intervals
             counter.feed_contig(o.stats.name, r)
+            counter.finish_plot(o.stats.name, o.stats.length)
     finally:
         counter.close()
 
@@ -346,9 +350,14 @@ def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, 
             oc = out.outcomes
             text = coverage_output_json([o.stats for o in oc], [o.stats.name for o in oc], [o.state_counts for o in oc],
                                         bs.aligner(), bs.reference_build(), bs.infer_platform(), bs.average_read_length(),
-                                        output_bed, output_summary)
+                                        output_bed, output_summary or "summary.html",
+                                        [f"{o.stats.name}_coverage.svg" for o in oc if os.path.exists(f"{o.stats.name}_coverage.svg")])
             with open(summary_json, "w") as f:
                 f.write(text)
+            if output_summary:
+                from .report import write_html_report
+                write_html_report(output_summary, [o.stats for o in oc], [o.stats.name for o in oc], [o.state_counts for o in oc],
+                                  bs.aligner(), bs.reference_build(), bs.infer_platform(), bs.average_read_length())
         return out
     finally:
         if pool:

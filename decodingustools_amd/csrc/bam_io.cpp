@@ -869,6 +869,11 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         else {
             prof = dut_profiler_new(bed_path);
             if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; }
+            else {
+                uint32_t largest = 0;                       // api/coverage.rs:210-215: the longest selected contig but chrM
+                for (int t : tids) if (strcmp(dut_bam_ref_name(bam, t), "chrM") != 0) largest = std::max(largest, dut_bam_ref_len(bam, t));
+                dut_profiler_enable_plots(prof, largest);
+            }
         }
         for (size_t i = 0; rc == CL_OK && i < tids.size(); ++i) {
             const int t = tids[i];
@@ -895,11 +900,19 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         if (slot[1].bam) { dut_fasta_close(slot[1].fa); dut_bam_close(slot[1].bam); }
         if (rc != CL_OK) goto out;
     }
-    if (summary_json) {
-        // CoverageOutput as main.rs:68-69 serialises it (the HTML report and the SVG plots are not produced)
+    if (summary_json || summary_html) {
         std::vector<const char *> nm;
         std::vector<uint64_t> c6;
         for (size_t i = 0; i < stats.size(); ++i) { nm.push_back(names[i].c_str()); c6.insert(c6.end(), counts[i].begin(), counts[i].end()); }
+        // collect_coverage_plots (api/coverage.rs:263-274): the figures that exist relative to the working directory
+        // (they are written beside the BED file); listed in tid order here, in HashMap order there
+        std::vector<std::string> plots;
+        for (size_t i = 0; i < stats.size(); ++i) {
+            const std::string pth = names[i] + "_coverage.svg";
+            if (FILE *pf = fopen(pth.c_str(), "rb")) { fclose(pf); plots.push_back(pth); }
+        }
+        std::vector<const char *> plot_ptrs;
+        for (const std::string &q : plots) plot_ptrs.push_back(q.c_str());
         dut_export_meta meta;
         memset(&meta, 0, sizeof(meta));
         meta.aligner = dut_bam_stats_aligner(bstats);
@@ -908,6 +921,13 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         meta.read_length = dut_bam_stats_average_read_length(bstats);
         meta.bed_file = bed_path;
         meta.summary_html = summary_html ? summary_html : "summary.html";
+        meta.coverage_plots = plot_ptrs.data(); meta.n_coverage_plots = plot_ptrs.size();
+        if (summary_html) {                                   // api/coverage.rs:104
+            rc = dut_write_html_report(stats.data(), nm.data(), c6.data(), stats.size(), &meta, 10000, summary_html);
+            if (rc != CL_OK) { set_err(err, err_len, std::string("cannot create ") + summary_html); goto out; }
+        }
+    if (summary_json) {
+        // CoverageOutput as main.rs:68-69 serialises it
         char *js = nullptr; size_t jl = 0;
         rc = dut_coverage_output_json(stats.data(), nm.data(), c6.data(), stats.size(), &meta, &js, &jl);
         if (rc != CL_OK) { set_err(err, err_len, "cannot build the summary"); goto out; }
@@ -916,6 +936,7 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         fwrite(js, 1, jl, jf);
         fclose(jf);
         dut_free(js);
+    }
     }
 out:
     io_stage_time("(since the last decode) + summary", tm);

@@ -1,8 +1,8 @@
 // dut-coverage -- the `coverage`, `find-y-branch` and `find-mt-branch` subcommands of the reference CLI;
 // `coverage` is the default: (src/cli.rs:14-61, src/main.rs:36-70)
 // on the MI355X engine.  Same flags and defaults; BED to -o, the CoverageOutput JSON to ./summary.json.
-// (-s/--summary names the reference's HTML report, which is presentation and not produced; the name
-// still appears in summary.json as files.summary_html.)
+// -s/--summary: the HTML report (the reference's sections and numbers in this project's own markup); the
+// per-contig coverage figures <contig>_coverage.svg go beside the BED file.
 #include "../../include/dut_bam.h"
 #include "../../include/dut_haplogroup.h"
 

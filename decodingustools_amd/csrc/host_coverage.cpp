@@ -102,14 +102,102 @@ struct dut_profiler {
     uint64_t cur_start = 0, cur_end = 0;
     uint32_t cur_state = 0;
     std::unordered_map<std::string, std::array<uint64_t, 6>> counts;    // contig_counts, callable_profiler.rs:13
+    // coverage figure (callable_profiler.rs:48-59, 64-84): every written line of one of the three plotted states
+    // is also a range of the current figure; finish_plot bins and clears them
+    struct PlotRange { uint32_t start, end, state; };
+    bool plots = false;
+    uint32_t largest_contig_length = 0;
+    std::string out_dir;
+    std::vector<PlotRange> ranges;
 
     void write_state()                       // callable_profiler.rs:39-62
     {
-        if (has_state)
-            fprintf(bed, "%s\t%llu\t%llu\t%s\n", cur_contig.c_str(), (unsigned long long)cur_start,
-                    (unsigned long long)cur_end, kStateNames[cur_state]);
+        if (!has_state) return;
+        fprintf(bed, "%s\t%llu\t%llu\t%s\n", cur_contig.c_str(), (unsigned long long)cur_start,
+                (unsigned long long)cur_end, kStateNames[cur_state]);
+        if (plots && (cur_state == CL_CALLABLE || cur_state == CL_POOR_MAPPING_QUALITY || cur_state == CL_REF_N))
+            ranges.push_back({(uint32_t)cur_start, (uint32_t)cur_end, cur_state});      // `as u32`, :53-54
     }
 };
+
+namespace {
+// histogram_plotter.rs:74-101 + 412-440: positions of the three plotted states per stride of the contig.
+// stride: ceil(16569 / 200) for "chrM", else ceil(largest selected non-chrM contig / 2000).
+bool plot_bins(const dut_profiler *p, const char *contig, uint32_t contig_length, uint32_t &stride,
+               std::vector<uint32_t> &call, std::vector<uint32_t> &lowq, std::vector<uint32_t> &refn)
+{
+    stride = strcmp(contig, "chrM") == 0 ? (16569u + 200u - 1u) / 200u : (uint32_t)(((uint64_t)p->largest_contig_length + 2000u - 1u) / 2000u);
+    if (stride == 0) return false;                                        // the reference divides by zero here
+    const size_t n = (size_t)(contig_length / stride) + 1;
+    call.assign(n, 0); lowq.assign(n, 0); refn.assign(n, 0);
+    for (const dut_profiler::PlotRange &r : p->ranges) {
+        std::vector<uint32_t> &dst = r.state == CL_CALLABLE ? call : (r.state == CL_REF_N ? refn : lowq);
+        for (uint64_t pos = r.start; pos < r.end;) {                      // bin by bin instead of position by position
+            const uint64_t idx = pos / stride, stop = std::min<uint64_t>(r.end, (idx + 1) * stride);
+            if (idx < n) dst[idx] += (uint32_t)(stop - pos);              // ranges past the arrays are ignored (:88)
+            pos = stop;
+        }
+    }
+    return true;
+}
+
+std::string xml_escape(const std::string &s)
+{
+    std::string o;
+    for (char c : s) {
+        switch (c) {
+        case '&': o += "&amp;"; break; case '<': o += "&lt;"; break; case '>': o += "&gt;"; break;
+        case '"': o += "&quot;"; break; case '\'': o += "&apos;"; break; default: o += c;
+        }
+    }
+    return o;
+}
+
+// The figure itself is this project's own drawing of those three arrays (the reference's SVG markup is
+// presentation and is not reproduced): one 1-px column per stride, stacked callable / poor mapping quality /
+// reference N as fractions of the stride, equal neighbouring columns merged into one rectangle.
+std::string plot_svg(const std::string &contig, uint32_t contig_length, uint32_t stride, const std::vector<uint32_t> &call,
+                     const std::vector<uint32_t> &lowq, const std::vector<uint32_t> &refn)
+{
+    const int H = 100, top = 24, left = 8;
+    const size_t n = call.size();
+    char buf[256];
+    std::string o;
+    snprintf(buf, sizeof(buf), "<svg xmlns=\"http://www.w3.org/2000/svg\" width=\"%zu\" height=\"%d\" role=\"img\">\n", n + 2 * left, H + top + 22);
+    o += buf;
+    o += "<title>Coverage distribution for " + xml_escape(contig) + "</title>\n";
+    snprintf(buf, sizeof(buf), "<rect x=\"0\" y=\"0\" width=\"%zu\" height=\"%d\" fill=\"#ffffff\"/>\n", n + 2 * left, H + top + 22);
+    o += buf;
+    o += "<text x=\"8\" y=\"15\" font-family=\"sans-serif\" font-size=\"12\">" + xml_escape(contig);
+    snprintf(buf, sizeof(buf), " (%u bp, %u bp per column): callable green, poor mapping quality orange, reference N grey</text>\n", contig_length, stride);
+    o += buf;
+    auto px = [&](uint32_t v) { return (int)(((uint64_t)std::min(v, stride) * H + stride / 2) / stride); };
+    const char *fill[3] = {"#2e8b57", "#e69f00", "#9e9e9e"};
+    const std::vector<uint32_t> *arr[3] = {&call, &lowq, &refn};
+    for (size_t a = 0; a < n;) {
+        size_t b = a + 1;
+        while (b < n && px(call[b]) == px(call[a]) && px(lowq[b]) == px(lowq[a]) && px(refn[b]) == px(refn[a])) ++b;
+        int y = top + H;
+        for (int k = 0; k < 3; ++k) {
+            const int h = px((*arr[k])[a]);
+            if (h > 0) {
+                y -= h;
+                snprintf(buf, sizeof(buf), "<rect x=\"%zu\" y=\"%d\" width=\"%zu\" height=\"%d\" fill=\"%s\"/>\n", left + a, y < top ? top : y, b - a, h, fill[k]);
+                o += buf;
+            }
+        }
+        a = b;
+    }
+    snprintf(buf, sizeof(buf), "<line x1=\"%d\" y1=\"%d\" x2=\"%zu\" y2=\"%d\" stroke=\"#000000\" stroke-width=\"1\"/>\n", left, top + H, left + n, top + H);
+    o += buf;
+    snprintf(buf, sizeof(buf), "<text x=\"%d\" y=\"%d\" font-family=\"sans-serif\" font-size=\"10\">0</text>\n", left, top + H + 14);
+    o += buf;
+    snprintf(buf, sizeof(buf), "<text x=\"%zu\" y=\"%d\" font-family=\"sans-serif\" font-size=\"10\" text-anchor=\"end\">%u</text>\n", left + n, top + H + 14, contig_length);
+    o += buf;
+    o += "</svg>\n";
+    return o;
+}
+} // namespace
 
 extern "C" {
 
@@ -123,7 +211,50 @@ dut_profiler *dut_profiler_new(const char *bed_path)
     setvbuf(f, nullptr, _IOFBF, 1 << 20);
     dut_profiler *p = new dut_profiler();
     p->bed = f;
+    const std::string bp(bed_path);                        // output_dir = parent of the BED file, :23-26
+    const size_t slash = bp.find_last_of('/');
+    p->out_dir = slash == std::string::npos ? std::string() : (slash == 0 ? std::string("/") : bp.substr(0, slash));
     return p;
+}
+
+void dut_profiler_enable_plots(dut_profiler *p, uint32_t largest_contig_length)
+{
+    if (!p) return;
+    p->plots = true; p->largest_contig_length = largest_contig_length;
+}
+
+int dut_profiler_plot_bins(const dut_profiler *p, const char *contig, uint32_t contig_length, uint32_t *stride,
+                           uint32_t *callable, uint32_t *low_qual, uint32_t *ref_n, size_t cap, size_t *n_bins)
+{
+    if (!p || !contig || !n_bins) return CL_ERR_INVALID;
+    std::vector<uint32_t> c, l, r;
+    uint32_t st = 0;
+    if (!plot_bins(p, contig, contig_length, st, c, l, r)) return CL_ERR_INVALID;
+    *n_bins = c.size();
+    if (stride) *stride = st;
+    if (cap >= c.size()) {
+        if (callable) memcpy(callable, c.data(), c.size() * 4);
+        if (low_qual) memcpy(low_qual, l.data(), l.size() * 4);
+        if (ref_n) memcpy(ref_n, r.data(), r.size() * 4);
+    }
+    return CL_OK;
+}
+
+int dut_profiler_finish_plot(dut_profiler *p, const char *contig, uint32_t contig_length)
+{
+    if (!p || !contig) return CL_ERR_INVALID;
+    if (!p->plots || p->ranges.empty()) return 0;          // finish_contig: nothing to draw, :67
+    std::vector<uint32_t> c, l, r;
+    uint32_t st = 0;
+    if (!plot_bins(p, contig, contig_length, st, c, l, r)) { p->ranges.clear(); return CL_ERR_INVALID; }
+    const std::string svg = plot_svg(contig, contig_length, st, c, l, r);
+    p->ranges.clear();                                     // std::mem::take, :69
+    const std::string path = (p->out_dir.empty() ? std::string() : (p->out_dir == "/" ? p->out_dir : p->out_dir + "/")) + contig + "_coverage.svg";
+    FILE *f = fopen(path.c_str(), "wb");
+    if (!f) return CL_ERR_INVALID;
+    fwrite(svg.data(), 1, svg.size(), f);
+    fclose(f);
+    return 1;
 }
 
 void dut_profiler_free(dut_profiler *p)
@@ -374,6 +505,7 @@ int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats 
     if (rc != CL_OK) return rc;
     double tm = dut_now();
     rc = dut_profiler_feed_contig(prof, contig_name, iv, niv, counts);
+    if (rc == CL_OK && dut_profiler_finish_plot(prof, contig_name, contig_len) < 0) rc = CL_ERR_INVALID;   // finish_contig, :67-84
     dut_stage_time("BED lines", tm);
     return rc;
 }

@@ -539,6 +539,99 @@ int dut_coverage_output_json(const dut_contig_stats *stats, const char *const *n
     return CL_OK;
 }
 
+// summary.html (report.rs:136-340): the sections, rows and number formats of the reference's report from the same
+// export -- in this project's own markup and style sheet (the reference's template files are presentation and
+// are not reproduced).
+int dut_write_html_report(const dut_contig_stats *stats, const char *const *names, const uint64_t *state_counts,
+                          size_t n, const dut_export_meta *meta, uint64_t bam_stats_max_samples, const char *html_path)
+{
+    if ((n && (!stats || !names || !state_counts)) || !meta || !html_path) return CL_ERR_INVALID;
+    std::vector<size_t> order(n);
+    for (size_t i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return dut_compare_contig_names(names[a], names[b]) < 0; });
+    std::vector<dut_contig_stats> so; std::vector<uint64_t> call;
+    for (size_t i : order) { so.push_back(stats[i]); call.push_back(state_counts[6 * i + 1]); }
+    dut_genome_summary g;
+    dut_genome_summary_build(so.data(), call.data(), n, &g);
+    auto esc = [](const char *p) {
+        std::string o;
+        for (const char *c = p ? p : ""; *c; ++c) {
+            switch (*c) { case '&': o += "&amp;"; break; case '<': o += "&lt;"; break; case '>': o += "&gt;"; break;
+                          case '"': o += "&quot;"; break; default: o += *c; }
+        }
+        return o;
+    };
+    auto fx = [](const char *fmt, double v) { char b[64]; snprintf(b, sizeof(b), fmt, v); return std::string(b); };   // {:.N}
+    auto u = [](uint64_t v) { return std::to_string(v); };
+    std::string h;
+    h += "<!DOCTYPE html>\n<html lang=\"en\"><head><meta charset=\"utf-8\"><title>Coverage summary</title>\n<style>\n"
+         "body{font-family:sans-serif;margin:1.5em;color:#222}h1{font-size:1.4em}h2{font-size:1.1em}\n"
+         ".stats-box{border:1px solid #ccc;padding:.6em 1em;margin-bottom:1em}.stats-columns{display:flex;gap:3em}\n"
+         "dl{display:grid;grid-template-columns:auto auto;gap:.2em 1em;margin:0}dt{font-weight:bold}dd{margin:0}\n"
+         "table{border-collapse:collapse;margin:.6em 0}td,th{border:1px solid #ccc;padding:.25em .7em;text-align:left}\n"
+         ".group td{font-weight:bold;background:#f5f5f5}.tab-panel{display:none}.tab-panel.active{display:block}\n"
+         ".sample-note{font-weight:normal;color:#666;font-size:.85em}figure{margin:.5em 0;overflow-x:auto}\n"
+         "</style></head><body>\n<h1>Callable loci coverage summary</h1>\n";
+    // ---- BAM statistics (write_bam_stats_section, :162-212) ----
+    h += "<section class=\"stats-box\"><h2>BAM Statistics <span class=\"sample-note\">(based on first " + u(bam_stats_max_samples) + " reads)</span></h2>\n";
+    h += "<div class=\"stats-columns\"><dl>";
+    h += "<dt>Reference Build</dt><dd>" + esc(meta->reference_build) + "</dd>";
+    h += "<dt>Aligner</dt><dd>" + esc(meta->aligner) + "</dd>";
+    h += "<dt>Sequencing Platform</dt><dd>" + esc(meta->sequencing_platform) + "</dd>";
+    h += "<dt>Average read length</dt><dd>" + u(meta->read_length) + " bp</dd>";
+    h += "<dt>Total Unique Reads</dt><dd>" + u(g.total_unique_reads) + "</dd>";
+    h += "<dt>Total Bases</dt><dd>" + u(g.total_bases) + "</dd></dl>\n<dl>";
+    h += "<dt>Callable Bases</dt><dd>" + u(g.callable_bases) + "</dd>";
+    h += "<dt>Callable Percentage</dt><dd>" + fx("%.2f", g.callable_percentage) + "%</dd>";
+    h += "<dt>Average Depth</dt><dd>" + fx("%.2f", g.average_depth) + "\xC3\x97</dd>";
+    h += "<dt>Contigs Analyzed</dt><dd>" + u(g.contigs_analyzed) + "</dd>";
+    h += "<dt>Average MapQ</dt><dd>" + fx("%.1f", g.average_mapq) + "</dd>";
+    h += "<dt>Average BaseQ</dt><dd>" + fx("%.1f", g.average_baseq) + "</dd></dl></div></section>\n";
+    // ---- one panel per contig (write_contig_analysis_section / write_contig_panel, :214-330) ----
+    h += "<div class=\"contig-analysis\"><div class=\"contig-selector\"><select id=\"contig-select\" aria-label=\"Select contig\">";
+    for (size_t k = 0; k < order.size(); ++k)
+        h += "<option value=\"panel-" + u(k) + "\"" + (k == 0 ? " selected" : "") + ">" + esc(names[order[k]]) + "</option>";
+    h += "</select></div>\n<div class=\"contig-panels\">\n";
+    auto row = [&](const char *label, const std::string &v) { h += std::string("<tr><td>") + label + "</td><td>" + v + "</td></tr>"; };
+    for (size_t k = 0; k < order.size(); ++k) {
+        const size_t i = order[k];
+        dut_contig_derived d;
+        dut_contig_derive(&stats[i], &d);
+        const uint64_t *c = state_counts + 6 * i;
+        h += "<div class=\"tab-panel" + std::string(k == 0 ? " active" : "") + "\" id=\"panel-" + u(k) + "\"><table><thead><tr><th>Metric</th><th>Value</th></tr></thead><tbody>";
+        row("Length", u(stats[i].length) + " bp");
+        row("Unique Reads", u(stats[i].n_reads));
+        row("Covered Bases", u(stats[i].n_covered_bases));
+        row("Coverage Percent", fx("%.2f", d.coverage_percent) + "%");
+        row("Average Depth", fx("%.2f", d.average_depth) + "\xC3\x97");
+        h += "<tr class=\"group\"><td colspan=\"2\">Quality Metrics</td></tr>";
+        row("Average MapQ", fx("%.1f", d.average_mapq));
+        row("Average BaseQ", fx("%.1f", d.average_baseq));
+        row("Q30 Percentage", fx("%.2f", d.q30_percentage) + "%");
+        h += "<tr class=\"group\"><td colspan=\"2\">State Distribution</td></tr>";
+        row("Reference N", u(c[0])); row("Callable", u(c[1])); row("No Coverage", u(c[2]));
+        row("Low Coverage", u(c[3])); row("Excessive Coverage", u(c[4])); row("Poor Mapping Quality", u(c[5]));
+        h += "</tbody></table>";
+        const std::string plot = std::string(names[i]) + "_coverage.svg";          // looked up relative to the working directory, :316-317
+        if (FILE *pf = fopen(plot.c_str(), "rb")) {
+            fclose(pf);
+            h += "<figure class=\"coverage-plot\"><img src=\"" + esc(plot.c_str()) + "\" alt=\"Coverage distribution for " + esc(names[i]) +
+                 "\" loading=\"lazy\"><figcaption>Coverage distribution for " + esc(names[i]) + "</figcaption></figure>";
+        }
+        h += "</div>\n";
+    }
+    h += "</div></div>\n<script>\n"
+         "document.getElementById('contig-select').addEventListener('change', function () {\n"
+         "  var panels = document.querySelectorAll('.tab-panel');\n"
+         "  for (var i = 0; i < panels.length; i++) panels[i].classList.toggle('active', panels[i].id === this.value);\n"
+         "});\n</script>\n</body></html>\n";
+    FILE *f = fopen(html_path, "wb");
+    if (!f) return CL_ERR_INVALID;
+    fwrite(h.data(), 1, h.size(), f);
+    fclose(f);
+    return CL_OK;
+}
+
 void dut_free(void *p) { free(p); }
 
 } // extern "C"

@@ -131,3 +131,26 @@ def coverage_output_json(stats: Sequence, names: Sequence[str], state_counts: Se
         return C.string_at(out.value, ln.value).decode()
     finally:
         lib.dut_free(out)
+
+
+def write_html_report(path: str, stats: Sequence, names: Sequence[str], state_counts: Sequence[Sequence[int]],
+                      aligner: str, reference_build: str, sequencing_platform: str, read_length: int,
+                      max_samples: int = 10000) -> None:
+    """summary.html (report.rs:136-340): the reference's sections, rows and number formats in this project's own
+    markup; a contig's figure is embedded when `<name>_coverage.svg` exists in the working directory."""
+    lib = _lib.load()
+    n = len(stats)
+    cs = (_lib.dut_contig_stats * max(n, 1))()
+    for i, s in enumerate(stats):
+        cs[i].length = s.length; cs[i].n_covered_bases = s.n_covered_bases
+        cs[i].summed_coverage = s.summed_coverage; cs[i].summed_baseq = s.summed_baseq
+        cs[i].summed_mapq = s.summed_mapq; cs[i].quality_bases = s.quality_bases
+        cs[i].n_reads = s.n_reads
+    nm = (C.c_char_p * max(n, 1))(*[x.encode() for x in names])
+    cnt = (C.c_uint64 * max(6 * n, 1))(*[int(v) for row in state_counts for v in row])
+    plots = (C.c_char_p * 1)()
+    meta = _lib.dut_export_meta(aligner.encode(), reference_build.encode(), sequencing_platform.encode(),
+                                read_length, b"", b"", plots, 0)
+    st = lib.dut_write_html_report(cs, nm, cnt, n, C.byref(meta), max_samples, path.encode())
+    if st != 0:
+        raise EngineError(st, f"cannot write {path}")

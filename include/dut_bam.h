@@ -58,8 +58,11 @@ int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint6
 /* `coverage <bam> -r <fasta> -o <bed> -s <html> [-L contig]...` on one GPU: BamStats over the first
  * 10000 records, then per selected contig (ascending tid) read, admit, run the engine, append BED
  * lines; then write the CoverageOutput JSON (dut_report.h, what main.rs:68-69 puts in
- * ./summary.json) to summary_json (may be NULL).  summary_html is only named in that JSON -- the
- * HTML report itself is presentation and is not produced (NULL = "summary.html").
+ * ./summary.json) to summary_json (may be NULL).  The per-contig coverage figures `<contig>_coverage.svg` are
+ * written beside the BED file (callable_profiler.rs:64-84) and, when summary_html is given, the HTML report
+ * (api/coverage.rs:104; dut_report.h) to that path; NULL: no report, the JSON names "summary.html".
+ * files.coverage_plots of the JSON lists the figures that exist relative to the working directory
+ * (api/coverage.rs:263-274), in tid order.
  * contigs == NULL selects every header contig.  With a .bai and more than one selected contig the next
  * contig's records and bases are read ahead on a second reader while the current one is processed
  * (environment DUT_PIPELINE=0 turns that off; the output is the same either way).

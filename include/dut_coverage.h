@@ -79,6 +79,19 @@ typedef struct dut_profiler dut_profiler;
 dut_profiler *dut_profiler_new(const char *bed_path);
 /* Drop: flushes; like the reference it does not write a pending state. */
 void dut_profiler_free(dut_profiler *p);
+/* The per-contig coverage figure (callable_profiler.rs:48-59,64-84; utils/histogram_plotter.rs:74-101,412-440):
+ * after enable_plots every BED line of state CALLABLE / POOR_MAPPING_QUALITY / REF_N is also a range of the
+ * current figure -- the duplicated last line of the previous contig included, as in the reference.
+ * largest_contig_length: the longest selected contig other than "chrM" (api/coverage.rs:210-215).
+ * plot_bins: positions of the three states per stride (ceil(largest / 2000); "chrM": ceil(16569 / 200)),
+ * n = contig_length / stride + 1 entries each (arrays may be NULL; filled only if cap >= n).
+ * finish_plot: what finish_contig does after the last line -- writes `<dir of the BED>/<contig>_coverage.svg`
+ * (this project's own drawing of those arrays) and clears the ranges.  Returns 1 if a file was written,
+ * 0 if there was nothing to draw, negative on error. */
+void dut_profiler_enable_plots(dut_profiler *p, uint32_t largest_contig_length);
+int dut_profiler_plot_bins(const dut_profiler *p, const char *contig, uint32_t contig_length, uint32_t *stride,
+                           uint32_t *callable, uint32_t *low_qual, uint32_t *ref_n, size_t cap, size_t *n_bins);
+int dut_profiler_finish_plot(dut_profiler *p, const char *contig, uint32_t contig_length);
 /* get_contig_counts (callable_profiler.rs:158-160): zeros for an unknown contig */
 void dut_profiler_contig_counts(const dut_profiler *p, const char *contig, uint64_t out[6]);
 /* Feeds one contig's runs (what process_position would have produced position by position,

@@ -93,6 +93,13 @@ int dut_coverage_output_json(const dut_contig_stats *stats, const char *const *n
                              const uint64_t *state_counts /* n x 6 */, size_t n_contigs,
                              const dut_export_meta *meta, char **json, size_t *json_len);
 void dut_free(void *p);
+/* summary.html (report.rs:136-340): the sections, rows, labels and number formats of the reference's report from
+ * the same export (contigs sorted the same way; a contig's figure is embedded when `<name>_coverage.svg` exists in
+ * the working directory, as there) -- in this project's own markup; the reference's template files are
+ * presentation and are not reproduced.  bam_stats_max_samples: BamStats.max_samples (10000 in the reference). */
+int dut_write_html_report(const dut_contig_stats *stats, const char *const *names,
+                          const uint64_t *state_counts /* n x 6 */, size_t n_contigs,
+                          const dut_export_meta *meta, uint64_t bam_stats_max_samples, const char *html_path);
 
 #ifdef __cplusplus
 }

@@ -377,3 +377,43 @@ def coverage_output(stats, names, counts, aligner, reference_build_, platform, r
 
 def coverage_output_json(*a, **k) -> str:
     return to_pretty(coverage_output(*a, **k))
+
+
+# ---- the per-contig coverage figure's data (TEST INFRASTRUCTURE, like everything in oracle/) -------------
+# callable_profiler.rs:39-84 (write_state pushes every written line of a plotted state; finish_contig writes the
+# pending line WITHOUT clearing it, draws and empties the list -- so the previous contig's last line is written,
+# and pushed, once more when the next contig starts) and utils/histogram_plotter.rs:74-101, 412-440 (positions
+# per stride; stride = ceil(largest / 2000), "chrM": ceil(16569 / 200); n = length / stride + 1 bins).
+PLOTTED = ("CALLABLE", "POOR_MAPPING_QUALITY", "REF_N")
+
+
+def coverage_plot_bins(contigs, largest_contig_length):
+    """contigs: [(name, length, [(start, end, state_name), ...])] in processing order, runs maximal and without
+    the duplicated lines.  -> [(stride, [callable bins], [low-quality bins], [ref-N bins], n_ranges)] per contig;
+    the reference draws a figure only when n_ranges > 0 (callable_profiler.rs:67)."""
+    out = []
+    cur = None
+    ranges = []
+
+    def write_state():
+        if cur is not None and cur[2] in PLOTTED:
+            ranges.append(cur)
+
+    for name, length, runs in contigs:
+        for run in runs:
+            if cur is not None:
+                write_state()                     # the state or the contig changed
+            cur = run
+        write_state()                             # finish_contig: the line stays pending
+        stride = (16569 + 200 - 1) // 200 if name == "chrM" else (largest_contig_length + 2000 - 1) // 2000
+        n = length // stride + 1
+        bins = [[0] * n for _ in range(3)]
+        for s, e, st in ranges:
+            row = bins[PLOTTED.index(st)]
+            for pos in range(s & 0xFFFFFFFF, e & 0xFFFFFFFF):
+                idx = pos // stride
+                if idx < n:
+                    row[idx] += 1
+        out.append((stride, bins[0], bins[1], bins[2], len(ranges)))
+        ranges = []
+    return out

@@ -377,19 +377,24 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     contigs = [(n, t, lens[t], refs[t], recs.get(t, ContigRecords.empty())) for t, n in enumerate(names)]
     o_res, o_bed = oracle_run(contigs, make_options({}), str(tmp_path / "o.bed"))
     bed = str(tmp_path / "g.bed"); js = str(tmp_path / "summary.json")
-    coverage_files(bam, fa, bed, js, CallableOptions(), output_summary="rep.html")     # indexed, 4 contigs: contig i+1 is read ahead
+    rep = str(tmp_path / "rep.html")
+    coverage_files(bam, fa, bed, js, CallableOptions(), output_summary=rep)     # indexed, 4 contigs: contig i+1 is read ahead
     assert open(bed).read() == o_bed
+    # the HTML report and the coverage figures beside the BED (chrX has no reads: one NO_COVERAGE/REF_N picture or none)
+    html = open(rep, encoding="utf-8").read()
+    assert html.count('class="tab-panel') == 4 and "<dt>Aligner</dt>" in html
+    assert os.path.exists(tmp_path / "chr1_coverage.svg") and os.path.exists(tmp_path / "chrM_coverage.svg")
     # the same without the read-ahead thread, and without an index (one sequential pass over the file)
     import shutil
     os.environ["DUT_PIPELINE"] = "0"
     try:
-        coverage_files(bam, fa, str(tmp_path / "g0.bed"), str(tmp_path / "s0.json"), CallableOptions(), output_summary="rep.html")
+        coverage_files(bam, fa, str(tmp_path / "g0.bed"), str(tmp_path / "s0.json"), CallableOptions())
     finally:
         del os.environ["DUT_PIPELINE"]
     assert open(tmp_path / "g0.bed").read() == o_bed
     bam_ni = str(tmp_path / "noindex.bam")
     shutil.copy(bam, bam_ni)
-    coverage_files(bam_ni, fa, str(tmp_path / "g1.bed"), str(tmp_path / "s1.json"), CallableOptions(), output_summary="rep.html")
+    coverage_files(bam_ni, fa, str(tmp_path / "g1.bed"), str(tmp_path / "s1.json"), CallableOptions())
     assert open(tmp_path / "g1.bed").read() == o_bed
     # a file cut off inside a later contig: the error comes back from the read-ahead thread, nothing hangs
     from decodingustools_amd import EngineError
@@ -413,7 +418,7 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     assert len(ob.infer_platform_candidates()) == 1
     want = RO.coverage_output_json([o_res[n]["stats"] for n in names], names, [o_res[n]["state_counts"] for n in names],
                                    ob.aligner, ob.reference_build, ob.infer_platform_candidates()[0], ob.average_read_length(),
-                                   bed, "rep.html")
+                                   bed, rep)
     assert open(js).read() == want
     summ = _json.load(open(js))["export"]
     assert [c["name"] for c in summ["contigs"]] == ["chr1", "chr2", "chrX", "chrM"]
@@ -433,7 +438,9 @@ def test_coverage_on_bam_and_fasta_files_and_cli(tmp_path):
     assert r.returncode == 0, r.stderr
     assert open(out).read() == o_bed2
     cli_js = _json.load(open(tmp_path / "summary.json"))
-    assert cli_js["files"] == {"bed_file": out, "summary_html": "summary.html", "coverage_plots": []}
+    plots = [f"{n}_coverage.svg" for n in ("chr2", "chrM") if os.path.exists(tmp_path / f"{n}_coverage.svg")]
+    assert cli_js["files"] == {"bed_file": out, "summary_html": "summary.html", "coverage_plots": plots} and len(plots) == 2
+    assert "Callable Percentage" in open(tmp_path / "summary.html", encoding="utf-8").read()
     assert [c["name"] for c in cli_js["export"]["contigs"]] == ["chr2", "chrM"] and cli_js["export"]["summary"]["contigs_analyzed"] == 2
     r = subprocess.run([_b.CLI, bam, "-r", fa, "-o", out, "-L", "nope"], cwd=str(tmp_path), capture_output=True, text=True)
     assert r.returncode == 1 and "None of the specified contigs (nope) were found in the BAM file" in r.stderr
@@ -684,7 +691,8 @@ def test_coverage_on_files_over_two_processes(tmp_path):
         bed1 = str(one / f"{tag}.bed"); js1 = str(one / f"{tag}.json")
         coverage_files(bam, fa, bed1, js1, CallableOptions(), contigs=sel)
         bed2 = str(two / f"{tag}.bed"); js2 = str(two / f"{tag}.json")
-        args = [bam, "-r", fa, "-o", bed2, "--summary-json", js2, "--backend", "gloo"] + sum((["-L", c] for c in (sel or [])), [])
+        html2 = str(two / f"{tag}.html")
+        args = [bam, "-r", fa, "-o", bed2, "--summary-json", js2, "-s", html2, "--backend", "gloo"] + sum((["-L", c] for c in (sel or [])), [])
         s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
         ctx = mp.get_context("spawn")
         procs = [ctx.Process(target=_mgpu_worker, args=(r, 2, port, args)) for r in range(2)]
@@ -692,8 +700,14 @@ def test_coverage_on_files_over_two_processes(tmp_path):
         for p in procs: p.join(300)
         assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
         assert open(bed2).read() == open(bed1).read()
-        j1 = open(js1).read().replace(bed1, "BED"); j2 = open(js2).read().replace(bed2, "BED")
+        j1 = open(js1).read().replace(bed1, "BED"); j2 = open(js2).read().replace(bed2, "BED").replace(html2, "summary.html")
         assert j1 == j2
+        # the coverage figures beside the two BED files are the same drawings, and rank 0 wrote the report
+        svgs = sorted(f for f in os.listdir(one) if f.endswith("_coverage.svg"))
+        assert svgs and svgs == sorted(f for f in os.listdir(two) if f.endswith("_coverage.svg"))
+        for f in svgs:
+            assert open(one / f).read() == open(two / f).read(), f
+        assert "Callable Percentage" in open(html2, encoding="utf-8").read()
 
 
 def test_many_small_contigs_with_random_options(tmp_path):

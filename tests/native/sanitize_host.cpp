@@ -2,6 +2,7 @@
 // JSON writer, tree parsing / scoring / report) under AddressSanitizer + UBSan or ThreadSanitizer on the CPU.
 // The device engine is not part of this binary: the few cl_* symbols the host sources reference are
 // defined below as failing stubs for the link only (nothing here reaches them).
+#include "../../include/dut_coverage.h"
 #include "../../include/dut_haplogroup.h"
 #include "../../include/dut_report.h"
 
@@ -92,5 +93,24 @@ int main(int argc, char **argv)
     char *js = nullptr; size_t jl = 0;
     if (dut_coverage_output_json(st, names, counts, 2, &meta, &js, &jl) == CL_OK) printf("json %zu bytes\n", jl);
     dut_free(js);
+    // BED writer with the coverage figures + the HTML report (host only), into the tree file's directory
+    if (argc > 2) {
+        const std::string dir = std::string(argv[2]).substr(0, std::string(argv[2]).find_last_of('/'));
+        dut_profiler *pr = dut_profiler_new((dir + "/san.bed").c_str());
+        if (pr) {
+            dut_profiler_enable_plots(pr, 5000);
+            const cl_interval iv1[4] = {{0, 3, CL_REF_N}, {3, 900, CL_CALLABLE}, {900, 2100, CL_POOR_MAPPING_QUALITY}, {2100, 5000, CL_CALLABLE}};
+            const uint64_t c1[6] = {3, 3797, 0, 0, 0, 1200};
+            dut_profiler_feed_contig(pr, names[0], iv1, 4, c1);
+            dut_profiler_finish_plot(pr, names[0], 5000);
+            dut_profiler_feed_contig(pr, "chrM", nullptr, 0, c1);            // inherits the previous contig's last line
+            size_t nb = 0; uint32_t stride = 0;
+            std::vector<uint32_t> a(512), b(512), c(512);
+            dut_profiler_plot_bins(pr, "chrM", 16569, &stride, a.data(), b.data(), c.data(), 512, &nb);
+            printf("plot: %d figure(s), %zu bins of %u\n", dut_profiler_finish_plot(pr, "chrM", 16569), nb, stride);
+            dut_profiler_free(pr);
+        }
+        printf("html rc %d\n", dut_write_html_report(st, names, counts, 2, &meta, 10000, (dir + "/san.html").c_str()));
+    }
     return 0;
 }

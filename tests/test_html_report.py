@@ -102,3 +102,33 @@ def test_coverage_figure_bins_svg_and_html(tmp_path, monkeypatch):
         assert f"<tr><td>Callable</td><td>{c[1]}</td></tr>" in text
         assert (f'<img src="{name}_coverage.svg"' in text) == (name in drawn)
     assert text.count('class="tab-panel') == 5 and text.count('class="tab-panel active"') == 1
+
+
+def test_coverage_figure_known_answer(tmp_path):
+    """Worked by hand from callable_profiler.rs:39-84 and histogram_plotter.rs:74-101, 412-440.
+    Contig A (10 bp): REF_N [0,2), CALLABLE [2,10).  Contig B (6 bp): POOR_MAPPING_QUALITY [0,6).  chrM (3 bp):
+    NO_COVERAGE [0,3).  largest (non-chrM) = 10 -> stride 1; chrM: stride ceil(16569/200) = 83.
+      figure A: lines written while A is processed: REF_N [0,2) (at position 2), CALLABLE [2,10) (finish) -> 11 bins
+      figure B: A's pending CALLABLE [2,10) is written again when B starts -> bins 2..6 of B's 7 (7..9 fall outside),
+                then POOR_MAPPING_QUALITY [0,6) at finish
+      figure chrM: B's pending line once more: positions 0..5 all fall into bin 0 of chrM's single bin (3/83 + 1 = 1);
+                   chrM's own NO_COVERAGE line is not a plotted state."""
+    runs = [("A", 10, [(0, 2, "REF_N"), (2, 10, "CALLABLE")]), ("B", 6, [(0, 6, "POOR_MAPPING_QUALITY")]), ("chrM", 3, [(0, 3, "NO_COVERAGE")])]
+    want = [(1, [0, 0, 1, 1, 1, 1, 1, 1, 1, 1, 0], [0] * 11, [1, 1] + [0] * 9),
+            (1, [0, 0, 1, 1, 1, 1, 1], [1, 1, 1, 1, 1, 1, 0], [0] * 7),
+            (83, [0], [6], [0])]
+    got_oracle = RO.coverage_plot_bins(runs, 10)
+    assert [(s, c, l, n) for s, c, l, n, _ in got_oracle] == want
+    prof = CallableProfiler(str(tmp_path / "k.bed"))
+    prof.enable_plots(10)
+    for (name, L, rr), (stride, c, l, n) in zip(runs, want):
+        class _R:
+            pass
+        res = _R(); res.state_counts = [0] * 6; res.intervals = np.array([(s, e, STATE_ID[st]) for s, e, st in rr], np.uint32).reshape(-1, 3)
+        prof.feed_contig(name, res)
+        gs, gc, gl, gn = prof.plot_bins(name, L)
+        assert (gs, gc.tolist(), gl.tolist(), gn.tolist()) == (stride, c, l, n), name
+        assert prof.finish_plot(name, L)
+    prof.close()
+    assert open(tmp_path / "k.bed").read() == ("A\t0\t2\tREF_N\nA\t2\t10\tCALLABLE\nA\t2\t10\tCALLABLE\nB\t0\t6\tPOOR_MAPPING_QUALITY\n"
+                                               "B\t0\t6\tPOOR_MAPPING_QUALITY\nchrM\t0\t3\tNO_COVERAGE\n")

@@ -267,8 +267,9 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     const bool orf = c->opt.min_base_quality <= 128;
     // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel variant
     bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
-    // ... with short runs (operations average < 32 bases: an indel every few bases): four operations per lane
-    bool lng4 = lng && c->n_qual < 32ull * c->n_cigar;
+    // ... with short runs (operations average < 56 bases -- the measured crossover of the two
+    // variants lies between 50 and 70): four operations per lane, block-parallel
+    bool lng4 = lng && c->n_qual < 56ull * c->n_cigar;
     if (const char *fl = getenv("CL_FORCE_LONG")) {               // timing experiments: pick the variant by hand
         const int v = atoi(fl);
         lng = v != 0; lng4 = v == 4;

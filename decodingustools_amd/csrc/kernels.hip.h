@@ -488,7 +488,7 @@ struct PileupArgs {
 // replaced by an operation-parallel one -- live reads are compacted; LONG = 1: a wave takes 64 operations
 // of a read at a time, two DPP scans give every operation its reference / query start, each lane consumes
 // its own M/=/X run (runs longer than 64 bases go through the list and the quad loop); LONG = 4 (operations
-// average < 32 bases): the (read, 64-operation block) pairs that can touch the window form one flat list,
+// average < 56 bases): the (read, 64-operation block) pairs that can touch the window form one flat list,
 // a wave trip takes four of them, one per row of 16 lanes, four operations per lane, starting from the
 // blocks' checkpoints.
 //

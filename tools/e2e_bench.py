@@ -28,7 +28,7 @@ for threads in os.environ.get("E2E_THREADS", "16,1").split(","):
     env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads)
     for rep in range(2):
         t0 = time.time()
-        r = subprocess.run([_b.CLI, "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")], cwd=out, env=env, capture_output=True, text=True)
+        r = subprocess.run([os.environ.get("E2E_CLI", _b.CLI), "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")], cwd=out, env=env, capture_output=True, text=True)
         dt = time.time() - t0
         print(f"--- DUT_THREADS={threads} run {rep}: {dt:.2f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)
         print(r.stderr.strip(), flush=True)

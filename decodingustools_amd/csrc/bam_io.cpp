@@ -413,6 +413,51 @@ bool load_bai(dut_bam *b)
     return true;
 }
 
+// .csi (what `samtools index -c` writes, needed for references longer than 2^29): BGZF-compressed; magic, min_shift,
+// depth, l_aux + aux, n_ref, then per reference the bins with {bin, loffset, n_chunk, chunks}.  Only what the
+// .bai gives is taken: the smallest chunk start per reference and the mapped-read count of the metadata
+// pseudo-bin, whose number depends on the depth: ((1 << 3 * (depth + 1)) - 1) / 7 + 1.
+bool load_csi(dut_bam *b)
+{
+    std::string p1 = b->path + ".csi", p2 = b->path;
+    if (p2.size() > 4 && p2.substr(p2.size() - 4) == ".bam") p2 = p2.substr(0, p2.size() - 4) + ".csi";
+    Bgzf z;
+    z.fp = fopen(p1.c_str(), "rb");
+    if (!z.fp) z.fp = fopen(p2.c_str(), "rb");
+    if (!z.fp) return false;
+    std::vector<uint8_t> d;
+    uint8_t buf[65536];
+    size_t g;
+    while ((g = z.read(buf, sizeof(buf))) > 0) { d.insert(d.end(), buf, buf + g); if (d.size() > (1ull << 31)) break; }
+    fclose(z.fp); z.fp = nullptr;
+    if (!z.err.empty() || d.size() < 20 || memcmp(d.data(), "CSI\1", 4) != 0) return false;
+    const int32_t depth = (int32_t)rd32(&d[8]), l_aux = (int32_t)rd32(&d[12]);
+    if (depth < 0 || depth > 9 || l_aux < 0) return false;
+    size_t o = 16 + (size_t)l_aux;
+    if (o + 4 > d.size()) return false;
+    const uint32_t n_ref = rd32(&d[o]); o += 4;
+    const uint32_t meta_bin = (uint32_t)((((uint64_t)1 << (3 * (depth + 1))) - 1) / 7 + 1);
+    std::vector<uint64_t> start(n_ref, UINT64_MAX);
+    std::vector<int64_t> mapped(n_ref, -1);
+    for (uint32_t r = 0; r < n_ref; ++r) {
+        if (o + 4 > d.size()) return false;
+        const uint32_t n_bin = rd32(&d[o]); o += 4;
+        for (uint32_t i = 0; i < n_bin; ++i) {
+            if (o + 16 > d.size()) return false;
+            const uint32_t bin = rd32(&d[o]), n_chunk = rd32(&d[o + 12]); o += 16;      // bin, loffset (8), n_chunk
+            if (o + 16ull * n_chunk > d.size()) return false;
+            if (bin != meta_bin)
+                for (uint32_t c = 0; c < n_chunk; ++c) start[r] = std::min(start[r], rd64(&d[o + 16ull * c]));
+            else if (n_chunk >= 2) mapped[r] = (int64_t)rd64(&d[o + 16]);
+            o += 16ull * n_chunk;
+        }
+    }
+    if (n_ref != b->refs.size()) return false;
+    b->ref_start.swap(start);
+    b->ref_mapped.swap(mapped);
+    return true;
+}
+
 } // namespace
 
 extern "C" {
@@ -441,7 +486,7 @@ dut_bam *dut_bam_open(const char *path, char *err, size_t err_len)
         b->refs.push_back({nm, rd32(m)});
     }
     b->data_start = b->z.tell();
-    b->has_index = load_bai(b);
+    b->has_index = load_bai(b) || load_csi(b);
     return b;
 }
 

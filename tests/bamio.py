@@ -51,9 +51,9 @@ def _reg2bin(beg, end):
 
 
 def write_bam(path, refs, per_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", write_index=True, block_every=None,
-              long_cigar_tag=False, tlen=None, unmapped_tail=()):
+              long_cigar_tag=False, tlen=None, unmapped_tail=(), csi=False):
     """refs: [(name, length)]; per_tid: {tid: ContigRecords} (coordinate sorted).  Writes path and,
-    if asked, path + '.bai'.  block_every: start a new BGZF block every that many records (exercises
+    if asked, path + '.bai' (csi=True: path + '.csi' instead).  block_every: start a new BGZF block every that many records (exercises
     records that straddle / start blocks).  long_cigar_tag: store CIGARs with more than 3 ops in a
     CG:B,I tag behind the <l_seq>S<reflen>N placeholder, the way BAM stores > 65535 ops.
     tlen: {tid: sequence of template lengths}; unmapped_tail: [(name bytes, flag, l_seq, tlen)] records
@@ -119,7 +119,22 @@ def write_bam(path, refs, per_tid, header_text="@HD\tVN:1.6\tSO:coordinate\n", w
         body += nm + bytes((l_seq + 1) // 2) + b"\xff" * l_seq
         w.write(struct.pack("<I", len(body)) + body)
     w.close()
-    if write_index:
+    if write_index and csi:
+        # .csi with the BAM defaults min_shift 14, depth 5 (same bin numbering as .bai; per bin a loffset, no linear
+        # index), BGZF-compressed like every .csi
+        cw = _BgzfWriter(path + ".csi")
+        cw.write(b"CSI\1" + struct.pack("<iii", 14, 5, 0) + struct.pack("<i", len(refs)))
+        for tid in range(len(refs)):
+            bins, lin = index.get(tid, ({}, {}))
+            cw.write(struct.pack("<i", len(bins)))
+            for b in sorted(bins):
+                loff = min(v0 for v0, _ in bins[b]) if b != 37450 else 0
+                cw.write(struct.pack("<IQi", b, loff, len(bins[b])))
+                for v0, v1 in bins[b]:
+                    cw.write(struct.pack("<QQ", v0, v1))
+        cw.write(struct.pack("<Q", 0))
+        cw.close()
+    elif write_index:
         with open(path + ".bai", "wb") as f:
             f.write(b"BAI\1" + struct.pack("<I", len(refs)))
             for tid in range(len(refs)):

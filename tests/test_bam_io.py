@@ -207,3 +207,23 @@ def test_index_metadata_gives_mapped_read_counts(tmp_path):
     os.remove(path + ".bai") if os.path.exists(path + ".bai") else None
     with BamReader(path) as r:
         assert r.target_mapped == [-1] * len(refs)
+
+
+def test_csi_index_is_used_like_a_bai(tmp_path):
+    """A BAM indexed with .csi (BGZF-compressed, bins with loffset): random access per contig and the mapped counts of
+    the metadata pseudo-bin work as with a .bai."""
+    refs, per = _dataset()
+    path = str(tmp_path / "c.bam")
+    write_bam(path, refs, per, csi=True, block_every=50)
+    assert os.path.exists(path + ".csi") and not os.path.exists(path + ".bai")
+    with BamReader(path) as r:
+        assert r.has_index
+        for tid in range(len(refs)):
+            want = int(np.count_nonzero((per[tid].flag & 4) == 0)) if tid in per and per[tid].n else -1
+            assert r.target_mapped[tid] == want
+        for tid in reversed(range(len(refs))):                 # out of order: needs the index
+            got = r.fetch_contig(tid)
+            exp = per.get(tid)
+            assert got.n == (exp.n if exp is not None else 0)
+            if exp is not None and exp.n:
+                assert np.array_equal(got.pos, exp.pos) and np.array_equal(got.cigar, exp.cigar) and np.array_equal(got.qual, exp.qual)

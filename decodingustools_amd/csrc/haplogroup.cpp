@@ -705,7 +705,7 @@ int dut_find_branch_files(const char *bam_path, const char *fasta_path, const ch
     std::vector<const char *> names;
     std::vector<uint32_t> hist;
     int tid = -1;
-    if (!dut_bam_has_index(bam)) { set_err(err, err_len, std::string("no .bai index beside ") + bam_path); rc = CL_ERR_INVALID; goto out; }
+    if (!dut_bam_has_index(bam)) { set_err(err, err_len, std::string("no .bai or .csi index beside ") + bam_path); rc = CL_ERR_INVALID; goto out; }
     for (int t = 0; t < dut_bam_n_ref(bam); ++t) names.push_back(dut_bam_ref_name(bam, t));
     {
         size_t tl = 0;

@@ -5,10 +5,10 @@
  *   BamReaderFactory::open_indexed            src/utils/bam_reader.rs:7-14
  *   bam.fetch((tid, 0, contig_len)) + records src/callable_loci/mod.rs:53-55
  *   faidx::Reader::from_path / fetch_seq      src/api/coverage.rs:73, mod.rs:79-80
- * and the file-level driver CoverageAnalyzer::run_analysis (src/api/coverage.rs:53-115) minus
- * BamStats and the HTML report (presentation, out of scope).
+ * and the file-level driver CoverageAnalyzer::run_analysis (src/api/coverage.rs:53-115), BamStats, the
+ * coverage figures and the HTML report included (dut_report.h, dut_coverage.h).
  *
- * BAM only (BGZF + BAM records; a .bai beside the file is used to seek to a contig when present,
+ * BAM only (BGZF + BAM records; a .bai or .csi beside the file is used to seek to a contig when present,
  * otherwise the file is read forward).  CRAM is not supported.
  */
 #ifndef DUT_BAM_H

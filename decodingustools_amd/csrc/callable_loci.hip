@@ -92,6 +92,7 @@ struct cl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    uint64_t host_max_end = 0;         // largest pos + reference span over the pushed reads (32-bit clamped spans), for the extent
     static constexpr int kCopyStreams = 4;
     hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};   // large pageable H2D copies, one host thread each (created on first use)
     cl_options opt{};
@@ -428,7 +429,7 @@ cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uin
     c->h_cigar_off.assign(1, 0u); c->h_qual_off.assign(1, 0ull);
     c->h_iv.clear();
     c->q_dev = 0;
-    c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0;
+    c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -522,7 +523,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     //      k_read_prep computes as end - pos): the longest ordinary span bounds every window's candidate
     //      range, reads wider than kWideSpan get their own list.  In chunks, on all host threads. ----
     const size_t grain = 65536, nchunk = (n + grain - 1) / grain;
-    struct Chunk { int bad = 0; bool has_long = false; uint32_t span_n = 0, span_w = 0; std::vector<uint32_t> wide; };
+    struct Chunk { int bad = 0; bool has_long = false; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide; };
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
     dut::parallel_for(nchunk, 1, [&](size_t k) {
@@ -543,6 +544,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
                 if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += t->cigar[q] >> 4;
             }
             const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;      // k_read_prep flags spans beyond the 32-bit range
+            if (l <= 0xFFFF0000ull - (uint64_t)p) o.max_end = std::max<uint64_t>(o.max_end, (uint64_t)p + l);   // beyond that: kErrRange from the device
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
         }
@@ -558,6 +560,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
         for (const Chunk &o : ch) {
             if (o.has_long) c->has_long = true;
             c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
+            c->host_max_end = std::max(c->host_max_end, o.max_end);
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
         }
         c->h_pos.insert(c->h_pos.end(), t->pos, t->pos + n);
@@ -624,7 +627,9 @@ cl_status cl_contig_upload(cl_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_len_dev = UINT64_MAX;            // force the reference to be re-laid out
-    cl_status s = size_for_extent(c, c->contig_len);
+    // a read overhanging the contig end makes the reference walk (and classify as REF_N, mod.rs:100-101) positions
+    // up to its end: the extent is known from the spans computed at cl_push_reads
+    cl_status s = size_for_extent(c, (uint32_t)std::max<uint64_t>(c->contig_len, c->host_max_end));
     if (s != CL_OK) return s;
     c->ref_len_dev = c->h_ref.size();
     if (c->d_iv.cap == 0) HIP_TRY(c, c->d_iv.reserve(1u << 20));

@@ -272,7 +272,7 @@ struct BlockStream {
         if (got >= used + 28 && cbuf_next.reserve(batch)) {            // more than the EOF marker follows: read on while this batch inflates
             ahead_off = next_coff; ahead_want = batch; ahead_got = 0;
             const int fd = fileno(fp);
-            ahead = std::thread([this, fd]() {
+            ahead = dut::spawn_or_run([this, fd]() {
                 size_t n = 0;
                 while (n < ahead_want) {
                     const ssize_t r = pread(fd, cbuf_next.p + n, ahead_want - n, (off_t)(ahead_off + n));
@@ -882,7 +882,7 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
     }
     {
         // the HIP runtime and the engine context come up on their own thread while the first contig is decoded
-        std::thread init([&]() { rc = cl_create(opt, device_id, nullptr, &ctx); });
+        std::thread init = dut::spawn_or_run([&]() { rc = cl_create(opt, device_id, nullptr, &ctx); });
         // Contigs are processed in ascending tid order (api/coverage.rs:229-234).  With an index and more
         // than one contig, the records and reference bases of contig i+1 are read by a second reader on
         // its own thread while contig i is admitted, pushed, run and written (DUT_PIPELINE=0: off).
@@ -902,14 +902,14 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
         auto fetch = [&](Slot &s, int t) {
             // the reference bases (one thread: read + strip the line ends) beside the record decode (all threads)
             s.bases = nullptr; s.blen = 0;
-            std::thread fb([&]() { dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen); });
+            std::thread fb = dut::spawn_or_run([&]() { dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen); });
             s.rc = dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
-            fb.join();
+            if (fb.joinable()) fb.join();
         };
         std::thread ahead;
         io_stage_time("(before contigs)", tm);
         if (!tids.empty()) fetch(slot[0], tids[0]);
-        init.join();
+        if (init.joinable()) init.join();
         if (rc != CL_OK) set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)");
         else {
             prof = dut_profiler_new(bed_path);
@@ -925,7 +925,7 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
             Slot &cur = pipeline ? slot[i & 1] : slot[0];
             if (i > 0 && !pipeline) fetch(cur, t);
             io_stage_time(pipeline && i > 0 ? "wait for the read-ahead" : "BAM read + decode, FASTA fetch", tm);
-            if (pipeline && i + 1 < tids.size()) ahead = std::thread(fetch, std::ref(slot[(i + 1) & 1]), tids[i + 1]);
+            if (pipeline && i + 1 < tids.size()) { Slot &nx = slot[(i + 1) & 1]; const int tn = tids[i + 1]; ahead = dut::spawn_or_run([&fetch, &nx, tn]() { fetch(nx, tn); }); }
             if (cur.rc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_bam_error(cur.bam)); rc = cur.rc; }
             dut_contig_stats st;
             memset(&st, 0, sizeof(st));
@@ -989,11 +989,11 @@ out:
     if (prof) dut_profiler_free(prof);
     {
         // giving the device memory back and unmapping the decode buffers take a few hundred ms at chr21 size: side by side
-        std::thread td([&]() { if (ctx) cl_destroy(ctx); });
+        std::thread td = dut::spawn_or_run([&]() { if (ctx) cl_destroy(ctx); });
         dut_fasta_close(fa);
         dut_bam_close(bam);
         io_stage_time("readers closed", tm);
-        td.join();
+        if (td.joinable()) td.join();
     }
     io_stage_time("engine destroyed", tm);
     return rc;

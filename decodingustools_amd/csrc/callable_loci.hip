@@ -509,12 +509,12 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
         for (int i = 0; i < nsl; ++i) {
             const uint64_t a = std::min<uint64_t>(nq, per * i), b = std::min<uint64_t>(nq, per * (i + 1));
             if (b <= a) continue;
-            copiers.emplace_back([c, dst, src, a, b, i, &copy_err]() {
+            copiers.push_back(dut::spawn_or_run([c, dst, src, a, b, i, &copy_err]() {
                 hipError_t e = hipSetDevice(c->device);
                 if (e == hipSuccess) e = hipMemcpyAsync(dst + a, src + a, b - a, hipMemcpyHostToDevice, c->copy_stream[i]);
                 if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream[i]);
                 copy_err[i] = e;
-            });
+            }));
         }
     }
     const unsigned long long qbase = c->q_dev + c->h_qual.size();
@@ -579,7 +579,7 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     } catch (const std::bad_alloc &) {
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
-    for (auto &x : copiers) x.join();
+    for (auto &x : copiers) if (x.joinable()) x.join();
     for (int i = 0; i < cl_ctx::kCopyStreams; ++i) HIP_TRY(c, copy_err[i]);
     if (direct) c->q_dev += nq;
     return CL_OK;

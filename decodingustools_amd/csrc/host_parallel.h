@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdlib>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -38,9 +39,22 @@ void parallel_for(size_t n, size_t grain, F fn)
         }
     };
     std::vector<std::thread> th;
-    for (int t = 1; t < nt; ++t) th.emplace_back(body);
+    th.reserve((size_t)nt);
+    for (int t = 1; t < nt; ++t) {
+        try { th.emplace_back(body); } catch (const std::system_error &) { break; }   // no more threads: the ones we have do the work
+    }
     body();
     for (auto &t : th) t.join();
+}
+
+// Starts fn on a new thread; when the system has no thread to give, runs it here and now instead (no exception
+// leaves the library through the C ABI).  Returns a thread that is joinable only in the first case.
+template <class F>
+std::thread spawn_or_run(F fn)
+{
+    try { return std::thread(fn); } catch (const std::system_error &) {}
+    fn();
+    return std::thread();
 }
 
 } // namespace dut

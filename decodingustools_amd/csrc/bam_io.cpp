@@ -509,7 +509,7 @@ int64_t dut_bam_ref_mapped(const dut_bam *b, int tid)
     return (b && b->has_index && tid >= 0 && (size_t)tid < b->ref_mapped.size()) ? b->ref_mapped[tid] : -1;
 }
 
-int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4)
+static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4)
 {
     if (!b || !out || tid < 0 || (size_t)tid >= b->refs.size()) return CL_ERR_INVALID;
     b->err.clear();
@@ -746,6 +746,15 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
     return CL_OK;
 }
 
+int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_bam_read_contig_impl(b, tid, out, seq_off, seq4); }
+    catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
+    catch (...) { return CL_ERR_INVALID; }
+}
+
+
 int dut_bam_sample(dut_bam *b, dut_bam_sample_fn fn, void *ud)
 {
     if (!b || !fn) return CL_ERR_INVALID;
@@ -844,7 +853,7 @@ static void io_stage_time(const char *what, double &t0)
     t0 = t1;
 }
 
-extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
+static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path, const char *bed_path,
                                   const char *summary_json, const char *summary_html, const cl_options *opt,
                                   const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len)
 {
@@ -998,3 +1007,14 @@ out:
     io_stage_time("engine destroyed", tm);
     return rc;
 }
+
+extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, const char *bed_path,
+                                  const char *summary_json, const char *summary_html, const cl_options *opt,
+                                  const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_coverage_files_impl(bam_path, fasta_path, bed_path, summary_json, summary_html, opt, contigs, n_contigs, device_id, err, err_len); }
+    catch (const std::bad_alloc &) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_NOMEM; }
+    catch (...) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_INVALID; }
+}
+

@@ -686,7 +686,7 @@ int dut_validate_reference(const char *header_text, size_t len, const char *cons
     return CL_ERR_INVALID;
 }
 
-int dut_find_branch_files(const char *bam_path, const char *fasta_path, const char *tree_json_path,
+static int dut_find_branch_files_impl(const char *bam_path, const char *fasta_path, const char *tree_json_path,
                           const char *output_path, uint32_t min_depth, uint8_t min_quality, int tree_type,
                           int provider, int show_snps, int device_id, char *err, size_t err_len)
 {
@@ -761,5 +761,16 @@ out:
     dut_fasta_close(fa);
     return rc;
 }
+
+int dut_find_branch_files(const char *bam_path, const char *fasta_path, const char *tree_json_path,
+                          const char *output_path, uint32_t min_depth, uint8_t min_quality, int tree_type,
+                          int provider, int show_snps, int device_id, char *err, size_t err_len)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_find_branch_files_impl(bam_path, fasta_path, tree_json_path, output_path, min_depth, min_quality, tree_type, provider, show_snps, device_id, err, err_len); }
+    catch (const std::bad_alloc &) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_NOMEM; }
+    catch (...) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_INVALID; }
+}
+
 
 } // extern "C"

@@ -323,7 +323,7 @@ static void dut_stage_time(const char *what, double &t0)
     t0 = t1;
 }
 
-int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, const dut_records *rec,
+static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t contig_len, const dut_records *rec,
                     uint8_t *accepted, uint32_t *n_unique_names, uint64_t *n_accepted)
 {
     if (!opt || !rec || (!accepted && rec->n)) return CL_ERR_INVALID;
@@ -494,6 +494,16 @@ int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, con
     return CL_OK;
 }
 
+int dut_admit_reads(const cl_options *opt, int32_t tid, uint32_t contig_len, const dut_records *rec,
+                    uint8_t *accepted, uint32_t *n_unique_names, uint64_t *n_accepted)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_admit_reads_impl(opt, tid, contig_len, rec, accepted, n_unique_names, n_accepted); }
+    catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
+    catch (...) { return CL_ERR_INVALID; }
+}
+
+
 
 int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats *stats, const cl_options *opt,
                               const char *contig_name, int32_t tid, uint32_t contig_len, const uint8_t *ref,
@@ -510,7 +520,7 @@ int dut_process_single_contig(cl_ctx *ctx, dut_profiler *prof, dut_contig_stats 
     return rc;
 }
 
-int dut_process_single_contig_runs(cl_ctx *ctx, dut_contig_stats *stats, const cl_options *opt, int32_t tid,
+static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *stats, const cl_options *opt, int32_t tid,
                                    uint32_t contig_len, const uint8_t *ref, uint64_t ref_len, const dut_records *rec,
                                    uint64_t state_counts[6], const cl_interval **intervals, size_t *n_intervals)
 {
@@ -592,6 +602,17 @@ int dut_process_single_contig_runs(cl_ctx *ctx, dut_contig_stats *stats, const c
     stats->reserved = 0;
     return CL_OK;
 }
+
+int dut_process_single_contig_runs(cl_ctx *ctx, dut_contig_stats *stats, const cl_options *opt, int32_t tid,
+                                   uint32_t contig_len, const uint8_t *ref, uint64_t ref_len, const dut_records *rec,
+                                   uint64_t state_counts[6], const cl_interval **intervals, size_t *n_intervals)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_process_single_contig_runs_impl(ctx, stats, opt, tid, contig_len, ref, ref_len, rec, state_counts, intervals, n_intervals); }
+    catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
+    catch (...) { return CL_ERR_INVALID; }
+}
+
 
 void dut_contig_derive(const dut_contig_stats *s, dut_contig_derived *o)
 {

@@ -458,7 +458,7 @@ size_t dut_format_f64(double v, char *buf)
     return (size_t)(o - buf);
 }
 
-int dut_coverage_output_json(const dut_contig_stats *stats, const char *const *names,
+static int dut_coverage_output_json_impl(const dut_contig_stats *stats, const char *const *names,
                              const uint64_t *state_counts, size_t n, const dut_export_meta *meta,
                              char **json, size_t *json_len)
 {
@@ -539,10 +539,21 @@ int dut_coverage_output_json(const dut_contig_stats *stats, const char *const *n
     return CL_OK;
 }
 
+int dut_coverage_output_json(const dut_contig_stats *stats, const char *const *names,
+                             const uint64_t *state_counts, size_t n, const dut_export_meta *meta,
+                             char **json, size_t *json_len)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_coverage_output_json_impl(stats, names, state_counts, n, meta, json, json_len); }
+    catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
+    catch (...) { return CL_ERR_INVALID; }
+}
+
+
 // summary.html (report.rs:136-340): the sections, rows and number formats of the reference's report from the same
 // export -- in this project's own markup and style sheet (the reference's template files are presentation and
 // are not reproduced).
-int dut_write_html_report(const dut_contig_stats *stats, const char *const *names, const uint64_t *state_counts,
+static int dut_write_html_report_impl(const dut_contig_stats *stats, const char *const *names, const uint64_t *state_counts,
                           size_t n, const dut_export_meta *meta, uint64_t bam_stats_max_samples, const char *html_path)
 {
     if ((n && (!stats || !names || !state_counts)) || !meta || !html_path) return CL_ERR_INVALID;
@@ -631,6 +642,16 @@ int dut_write_html_report(const dut_contig_stats *stats, const char *const *name
     fclose(f);
     return CL_OK;
 }
+
+int dut_write_html_report(const dut_contig_stats *stats, const char *const *names, const uint64_t *state_counts,
+                          size_t n, const dut_export_meta *meta, uint64_t bam_stats_max_samples, const char *html_path)
+{
+    // no exception leaves the library through the C ABI
+    try { return dut_write_html_report_impl(stats, names, state_counts, n, meta, bam_stats_max_samples, html_path); }
+    catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
+    catch (...) { return CL_ERR_INVALID; }
+}
+
 
 void dut_free(void *p) { free(p); }
 

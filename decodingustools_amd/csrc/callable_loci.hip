@@ -416,7 +416,7 @@ void cl_destroy(cl_ctx *c)
 
 const char *cl_last_error(const cl_ctx *c) { return c ? c->err.c_str() : "null context"; }
 
-cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uint8_t *ref_bases,
+static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_len, const uint8_t *ref_bases,
                           uint64_t ref_len)
 {
     if (!c) return CL_ERR_INVALID;
@@ -433,6 +433,16 @@ cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uin
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
+
+cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t contig_len, const uint8_t *ref_bases,
+                          uint64_t ref_len)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_contig_begin_impl(c, tid, contig_len, ref_bases, ref_len); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
 
 namespace {
 // quality bytes staged on the host so far go to the device, behind the ones already there
@@ -465,7 +475,7 @@ cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, u
     return CL_OK;
 }
 
-cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
+static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
 {
     if (!c || !t) return CL_ERR_INVALID;
     if (!c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_push_reads outside cl_contig_begin .. upload");
@@ -585,7 +595,16 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     return CL_OK;
 }
 
-cl_status cl_contig_upload(cl_ctx *c)
+cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_push_reads_impl(c, t); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
+
+static cl_status cl_contig_upload_impl(cl_ctx *c)
 {
     Range rg("cl_contig_upload");
     if (!c || !c->in_contig) return fail(c, CL_ERR_INVALID, "cl_contig_upload without cl_contig_begin");
@@ -644,6 +663,15 @@ cl_status cl_contig_upload(cl_ctx *c)
     return CL_OK;
 }
 
+cl_status cl_contig_upload(cl_ctx *c)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_contig_upload_impl(c); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
+
 cl_status cl_contig_run(cl_ctx *c)
 {
     Range rg("cl_contig_run");
@@ -670,7 +698,7 @@ static cl_status check_summary(cl_ctx *c)
     return CL_OK;
 }
 
-cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
+static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
 {
     Range rg("cl_contig_collect");
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
@@ -735,6 +763,15 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
     return CL_OK;
 }
 
+cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_contig_collect_impl(c, out, intervals, n_intervals); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
+
 cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
 {
     cl_status s = cl_contig_upload(c);
@@ -792,7 +829,7 @@ cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_byt
     return CL_OK;
 }
 
-cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low, uint8_t *state, uint64_t cap)
+static cl_status cl_debug_depths_impl(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low, uint8_t *state, uint64_t cap)
 {
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_debug_depths needs a collected contig");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -810,7 +847,16 @@ cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low,
     return CL_OK;
 }
 
-cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, uint64_t ref_len,
+cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low, uint8_t *state, uint64_t cap)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_debug_depths_impl(c, raw, qc, low, state, cap); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
+
+static cl_status cl_site_pileup_impl(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, uint64_t ref_len,
                          const cl_site_tile *t, const uint32_t *sites, size_t n_sites, uint32_t *hist)
 {
     if (!c || !t || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
@@ -879,5 +925,15 @@ cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, ui
     cleanup();
     return CL_OK;
 }
+
+cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, uint64_t ref_len,
+                         const cl_site_tile *t, const uint32_t *sites, size_t n_sites, uint32_t *hist)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_site_pileup_impl(c, min_quality, contig_len, ref_len, t, sites, n_sites, hist); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
 
 } // extern "C"

@@ -543,17 +543,29 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     while (n_keep > 0 && (int64_t)rec->pos[n_keep - 1] >= (int64_t)contig_len) --n_keep;
     while (a0 < n_keep && rec->pos[a0] < 0 && !acc[a0]) ++a0;
     bool in_order = true;
-    for (uint64_t i = a0 + 1; i < n_keep && in_order; ++i) in_order = rec->pos[i] >= rec->pos[i - 1];
+    uint64_t n_in = 0;
+    {   // sortedness and the number of accepted reads in [a0, n_keep), in chunks on all host threads
+        const size_t grain = 1u << 18, nchunk = n_keep > a0 ? (n_keep - a0 + grain - 1) / grain : 0;
+        std::vector<uint64_t> c_in(nchunk, 0);
+        std::vector<uint8_t> c_ok(nchunk, 1);
+        dut::parallel_for(nchunk, 1, [&](size_t c) {
+            const uint64_t b0 = a0 + c * grain, b1 = std::min<uint64_t>(n_keep, b0 + grain);
+            uint64_t k = 0; bool ok = true;
+            for (uint64_t i = b0; i < b1; ++i) { k += acc[i]; if (i > a0 && rec->pos[i] < rec->pos[i - 1]) ok = false; }
+            c_in[c] = k; c_ok[c] = ok;
+        });
+        for (size_t c = 0; c < nchunk; ++c) { n_in += c_in[c]; in_order = in_order && c_ok[c]; }
+    }
     if (in_order && a0 < n_keep) {
         std::vector<uint32_t> patched;
         const uint32_t *cig = rec->cigar;
-        uint64_t n_in = 0;
-        for (uint64_t i = a0; i < n_keep; ++i) n_in += acc[i];
         if (n_in != n_keep - a0) {
-            patched.assign(rec->cigar, rec->cigar + rec->cigar_off[n_keep]);
-            for (uint64_t i = a0; i < n_keep; ++i)
-                if (!acc[i])
-                    for (uint32_t k = rec->cigar_off[i]; k < rec->cigar_off[i + 1]; ++k) patched[k] = (patched[k] & ~15u) | 5u;
+            patched.resize(rec->cigar_off[n_keep]);
+            uint32_t *pp = patched.data();
+            dut::parallel_for(n_keep, 1u << 16, [&](size_t i) {           // reads in front of a0 keep their words: they are not in the tile
+                const bool keep = i < a0 || acc[i];
+                for (uint32_t k = rec->cigar_off[i]; k < rec->cigar_off[i + 1]; ++k) pp[k] = keep ? rec->cigar[k] : ((rec->cigar[k] & ~15u) | 5u);
+            });
             cig = patched.data();
         }
         cl_read_tile t;

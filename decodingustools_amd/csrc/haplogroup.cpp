@@ -14,6 +14,7 @@
 #include <unordered_map>
 #include <utility>
 #include "host_parallel.h"
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -116,7 +117,7 @@ struct JParser {
         if (c == '{') {
             v.t = JVal::Obj; ++p; ws();
             if (p < e && *p == '}') ++p;
-            else for (;;) {
+            else for (v.o.reserve(12);;) {             // the trees' objects have 7-12 members: no regrowth of heavy elements
                 ws();
                 std::string k;
                 if (!str(k)) { ok = false; break; }
@@ -133,7 +134,7 @@ struct JParser {
         } else if (c == '[') {
             v.t = JVal::Arr; ++p; ws();
             if (p < e && *p == ']') ++p;
-            else for (;;) {
+            else for (v.a.reserve(4);;) {
                 v.a.emplace_back();
                 if (!value(v.a.back())) { ok = false; break; }
                 ws();
@@ -156,10 +157,17 @@ struct JParser {
             if (ok && q < e && (*q == 'e' || *q == 'E')) { integral = false; ++q; if (q < e && (*q == '+' || *q == '-')) ++q; const char *x0 = q; while (q < e && *q >= '0' && *q <= '9') ++q; if (q == x0) ok = fail("bad number"); }
             if (ok) {
                 v.t = JVal::Num;
-                const std::string txt(p, q);
-                v.num = strtod(txt.c_str(), nullptr);
                 v.neg = *p == '-';
-                if (integral && (q - d0) <= 19) { v.is_int = true; v.mag = strtoull(std::string(d0, q).c_str(), nullptr, 10); }
+                if (integral && (q - d0) <= 19) {
+                    // an integer of at most 19 digits fits 64 bits; its nearest double is what strtod would return
+                    uint64_t m = 0;
+                    for (const char *d = d0; d < q; ++d) m = m * 10u + (uint64_t)(*d - '0');
+                    v.is_int = true; v.mag = m;
+                    v.num = v.neg ? -(double)m : (double)m;
+                } else {
+                    const std::string txt(p, q);
+                    v.num = strtod(txt.c_str(), nullptr);
+                }
                 p = q;
             }
         } else ok = fail("unexpected character");
@@ -474,10 +482,14 @@ dut_tree *dut_tree_parse(const char *json, size_t len, int provider, int tree_ty
     if (!json) { set_err(err, err_len, "null tree"); return nullptr; }
     JVal doc;
     JParser jp(json, len);
+    const auto T0 = std::chrono::steady_clock::now();
     if (!jp.document(doc)) { set_err(err, err_len, "Failed to parse tree: " + jp.err); return nullptr; }
+    const auto T1 = std::chrono::steady_clock::now();
     dut_tree *t = new dut_tree();
     std::string e;
     const bool ok = provider == DUT_PROVIDER_DECODINGUS ? parse_decodingus(doc, t->all, e) : parse_ftdna(doc, t->all, e);
+    const auto T2 = std::chrono::steady_clock::now();
+    if (getenv("DUT_TIMING")) fprintf(stderr, "[dut-timing] tree: json %.0f ms, nodes %.0f ms\n", std::chrono::duration<double>(T1 - T0).count() * 1e3, std::chrono::duration<double>(T2 - T1).count() * 1e3);
     if (!ok) { set_err(err, err_len, "Failed to parse tree: " + e); delete t; return nullptr; }
     // root selection, tree.rs:29-47
     const Node *root = nullptr;

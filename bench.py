@@ -1,17 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- callable-loci hot path on MI355X: reference bases classified per second.
 
-A step = one pass of the whole device path (read prep -> window bounds -> pileup/classify ->
-run-length intervals + summary) over ONE resident chr21-shaped contig (46 709 983 bp, 30x,
-2x150 bp paired reads; BASELINE.json configs[1]) per GPU.  Inputs are resident in HBM when the
-timed region starts.  N > 1: one process per GPU (torchrun), every rank owns its own contig of
-the same shape (contigs shard with no data-path collective -> weak scaling); the per-contig
-summaries are gathered with one RCCL all_gather.
+A step = one pass of the whole device path (read prep + window bounds -> pileup/classify ->
+run-length intervals + summary) over the rank's resident input.  Inputs are resident in HBM when the
+timed region starts.
+
+  --gpus 1 (default)   BASELINE.json configs[1], the configuration the metric is quoted on: ONE
+                       chr21-shaped contig (46 709 983 bp, 30x, 2x150 bp paired reads).  The whole contig
+                       is also run through the CPU oracle (single thread, like the reference) and the BED /
+                       summary compared bit for bit; configs[2] (long reads) and configs[4] (site pileup) are
+                       measured as secondary lines under "configs".
+  --gpus N > 1         BASELINE.json configs[3]: the FIXED whole-genome input -- the 25 hg38 primary contigs
+                       at 30x -- dealt to the ranks by longest-processing-time-first (strong scaling: what is
+                       sharded is the reference's serial contig loop, src/api/coverage.rs:229-234).  Every rank
+                       generates, uploads and keeps resident only its own contigs; a step runs them all and
+                       ends with the path's only exchange, one all_gather (RCCL over xGMI) of the per-contig
+                       summary records taken straight from HBM (cl_device_summary).
+  --workload chr21|wgs overrides the choice (e.g. the whole genome on one GPU; chr21 per rank = weak scaling).
+
+K steps are timed exactly as the contract says (barrier + synchronize on both sides, max over ranks).  One
+such block lasts ~10 ms at the default K, so the block is repeated until --min-time seconds of timed
+blocks have accumulated; ms_per_step is the mean over the blocks (every block's figures are kept).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
+import math
 import os
 import sys
 import tempfile
@@ -23,21 +38,30 @@ if ROOT not in sys.path:
 
 import numpy as np  # noqa: E402
 
+PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md
+METRIC = "reference bases classified/sec (whole node) + BED bit-exact vs CPU ref"
+
 
 def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline legs (the oracle is the checker and the reported baseline, never the product path)
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(rec, ref, L_sample, opt, tid):
-    """The oracle (CPU restatement of the reference algorithm, single thread like the reference)
-    on a bounded sample: the first L_sample positions of the same contig."""
+    """The oracle (CPU restatement of the reference algorithm, single thread like the reference) on the
+    first L_sample positions of the contig (the whole contig by default)."""
     import oracle
     from decodingustools_amd.records import ContigRecords
-    n = int(np.searchsorted(rec.pos, L_sample))
-    sub = ContigRecords(pos=rec.pos[:n], flag=rec.flag[:n], mapq=rec.mapq[:n],
-                        cigar_off=rec.cigar_off[:n + 1], cigar=rec.cigar[:int(rec.cigar_off[n])],
-                        qual_off=rec.qual_off[:n + 1], qual=rec.qual[:int(rec.qual_off[n])],
-                        qname_off=rec.qname_off[:n + 1], qname=rec.qname[:int(rec.qname_off[n])])
+    if L_sample >= ref.shape[0]:
+        sub = rec
+    else:
+        n = int(np.searchsorted(rec.pos, L_sample))
+        sub = ContigRecords(pos=rec.pos[:n], flag=rec.flag[:n], mapq=rec.mapq[:n],
+                            cigar_off=rec.cigar_off[:n + 1], cigar=rec.cigar[:int(rec.cigar_off[n])],
+                            qual_off=rec.qual_off[:n + 1], qual=rec.qual[:int(rec.qual_off[n])],
+                            qname_off=rec.qname_off[:n + 1], qname=rec.qname[:int(rec.qname_off[n])])
     with tempfile.TemporaryDirectory() as d:
         bed = os.path.join(d, "o.bed")
         prof = oracle.Profiler(bed)
@@ -45,21 +69,19 @@ def cpu_baseline(rec, ref, L_sample, opt, tid):
         st, _ = oracle.process_single_contig(prof, opt, "chr21", tid, L_sample, ref[:L_sample], sub)
         prof.close()
         dt = time.perf_counter() - t0
-        counts = None
         obed = open(bed).read()
     return sub, st, obed, dt
 
 
-def cpu_baseline_all_cores(rec, ref, opt, tid, start, piece, threads):
+def cpu_baseline_all_cores(rec, ref, opt, tid, piece, threads):
     """The same oracle on `threads` host threads at once, each on its own `piece`-long stretch of the
     contig (taken as a contig of its own).  The reference is single-threaded; this is the tile-parallel
     figure SURVEY 8d asks to be shown beside it."""
     import oracle
     from concurrent.futures import ThreadPoolExecutor
-    from decodingustools_amd.records import ContigRecords
     jobs = []
     for t in range(threads):
-        a = start + t * piece
+        a = 1_000_000 + t * piece
         if a + piece > ref.shape[0]:
             break
         i0, i1 = int(np.searchsorted(rec.pos, a)), int(np.searchsorted(rec.pos, a + piece))
@@ -82,14 +104,348 @@ def cpu_baseline_all_cores(rec, ref, opt, tid, start, piece, threads):
             "sample": f"{len(jobs)} stretches of {piece} positions, one oracle thread each, {dt:.1f}s"}
 
 
+# ------------------------------------------------------------------------------------------------
+# timing
+# ------------------------------------------------------------------------------------------------
+def timed_blocks(step, sync, args, world, dist, torch, coll_dev):
+    """W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + synchronize on both
+    sides; blocks repeat until --min-time seconds of them have accumulated (the count is agreed across
+    ranks).  Returns per-block durations (max over ranks), seconds."""
+    for _ in range(args.warmup):
+        step()
+    sync()
+
+    def block():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        return time.perf_counter() - t0
+    first = block()
+    t = torch.tensor([first], dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n_more = int(min(args.max_blocks - 1, max(0, math.ceil(args.min_time / max(float(t.item()), 1e-6)) - 1)))
+    dts = [first] + [block() for _ in range(n_more)]
+    t = torch.tensor(dts, dtype=torch.float64, device=coll_dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return [float(x) for x in t.cpu().tolist()]
+
+
+def kernel_profile(engines, steps):
+    """Per-kernel durations: the same steps once more with HIP events between the kernel groups on the
+    engines' stream (direct launches; outside the timed region).  Returns ({group: ms per step summed over the
+    engines}, runs per engine)."""
+    for e in engines:
+        e.set_profiling(True)
+        e.reset_kernel_ms()
+    n = max(5, min(steps, 20))
+    for _ in range(n):
+        for e in engines:
+            e.contig_run()
+    tot = {}
+    for e in engines:
+        e.sync()
+        kms, nruns = e.kernel_ms()
+        for k, v in kms.items():
+            tot[k] = tot.get(k, 0.0) + v / max(nruns, 1)
+        e.set_profiling(False)
+    return tot, n
+
+
+def traffic_from_profiles():
+    """The PMC-measured HBM traffic of one k_pileup launch is a builder-side figure (rocprofv3 --pmc needs its
+    own run): it is quoted from the committed profile, under its own key, never as a measurement of this run."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        d = json.load(open(tf))
+        return {"k_pileup_hbm_bytes_per_launch": d.get("k_pileup_hbm_bytes_per_launch"),
+                "file": "profiles/traffic.json", "build": d.get("build"), "workload": d.get("workload", "chr21 30x")}
+    except Exception:
+        return None
+
+
+def roofline(alg_bytes, pile_ms, step_ms, kms, n_gpus=1):
+    """alg_bytes / pile_ms: algorithmic bytes and k_pileup time summed over the launches of one step (over all
+    GPUs when there are several: the quotient is then the launch-weighted mean per GPU); step_*: the same bytes
+    over the wall time of a whole step, per GPU."""
+    ach = alg_bytes / (pile_ms * 1e-3) / 1e9 if pile_ms > 0 else 0.0
+    step_ach = alg_bytes / n_gpus / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+    return {"bound": "hbm", "kernel": "k_pileup", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": None, "traffic_from_profiles": traffic_from_profiles(),
+            "algorithmic_bytes_per_launch": alg_bytes, "kernel_ms": pile_ms,
+            "step_achieved": step_ach, "step_frac": step_ach / PEAK_HBM_GBS, "all_kernel_ms": kms}
+
+
+# ------------------------------------------------------------------------------------------------
+# secondary configurations (N = 1 only): driver-observed lines for configs[2] and configs[4]
+# ------------------------------------------------------------------------------------------------
+def secondary_configs(dev_id, opt, args):
+    from decodingustools_amd import CallableProfiler, ContigProfiler, Engine, process_single_contig, synth
+    out = {}
+    tmpd = tempfile.mkdtemp()
+    # configs[2]: chrY-shaped, 50x, long reads (median 10 kb, an indel every ~15 bases)
+    try:
+        L = args.long_length
+        t0 = time.perf_counter()
+        seed = synth.seed_for(3, 23)
+        rec = synth.long_read_contig(L, 50, seed)
+        ref = synth.make_reference(L, seed)
+        gen = time.perf_counter() - t0
+        with Engine(opt, dev_id) as eng:
+            counter = CallableProfiler(os.path.join(tmpd, "long.bed"))
+            st = ContigProfiler("chrY", L)
+            process_single_contig(eng, counter, st, opt, 23, rec, ref)
+            counter.close()
+            for _ in range(2):
+                eng.contig_run()
+            eng.sync()
+            kms, _ = kernel_profile([eng], 5)
+            inb, outb = eng.contig_bytes()
+        step = sum(kms.values())
+        out["long_read_chrY_50x"] = {
+            "workload": "coverage -L chrY synthetic 50x long-read (10 kb ONT-style CIGAR with indels), device-resident",
+            "contig_len": L, "reads": rec.n, "cigar_ops": int(rec.cigar.shape[0]), "aligned_bases": int(rec.qual.shape[0]),
+            "value": L / (step * 1e-3), "unit": "bases/s", "ms_per_step": step, "generated_in_s": round(gen, 1),
+            "roofline": roofline(inb + outb, kms["pileup"], step, kms)}
+        out["long_read_chrY_50x"]["roofline"].pop("traffic_from_profiles", None)
+        del rec, ref
+    except Exception as e:                                  # a secondary line must not cost the headline
+        out["long_read_chrY_50x"] = {"error": str(e)}
+    # configs[4]: chrY-shaped, 40x, config-2 read model with bases, 200 000 sites, min_quality 20
+    try:
+        L = args.site_length
+        t0 = time.perf_counter()
+        seed = synth.seed_for(5, 23)
+        ref = synth.make_reference(L, seed)
+        rec = synth.short_read_contig(L, 40, seed, with_seq=True, ref=ref, max_live_assert=0)
+        rng = np.random.default_rng(5)
+        sites = rng.choice(np.arange(1, L + 1), size=min(200_000, L), replace=False).astype(np.uint32)
+        gen = time.perf_counter() - t0
+        with Engine(opt, dev_id) as eng:
+            ms_all = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                hist = eng.site_pileup(20, L, L, rec, sites)
+                call = time.perf_counter() - t0
+                kms_, nb = eng.site_pileup_stats()
+                ms_all.append(kms_)
+        kms_ = min(ms_all)
+        ach = nb / (kms_ * 1e-3) / 1e9 if kms_ > 0 else 0.0
+        out["site_pileup_chrY_40x"] = {
+            "workload": "find-y-branch pileup path: chrY 40x synthetic, 200 000-site list, device kernel only",
+            "contig_len": L, "reads": rec.n, "sites": int(sites.shape[0]), "sites_hit": int((hist.sum(1) > 0).sum()),
+            "kernel_ms": kms_, "call_s_incl_h2d": call, "generated_in_s": round(gen, 1),
+            "roofline": {"bound": "hbm", "kernel": "k_site_pileup", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_launch": nb}}
+    except Exception as e:
+        out["site_pileup_chrY_40x"] = {"error": str(e)}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------
+def run_chr21(args, rank, world, dev_id, torch, dist, coll_dev):
+    from decodingustools_amd import (CallableOptions, CallableProfiler, ContigProfiler, Engine,
+                                     process_single_contig, synth)
+    L = args.length
+    tid = 20
+    seed = synth.seed_for(2, tid) + 1000 * rank
+    t0 = time.perf_counter()
+    rec = synth.short_read_contig(L, args.depth, seed)
+    ref = synth.make_reference(L, seed)
+    log(f"[bench r{rank}] synthetic contig: {L} bp, {rec.n} reads, {rec.qual.shape[0]} aligned bases "
+        f"({time.perf_counter() - t0:.1f}s)")
+
+    opt = CallableOptions()          # the CLI defaults (cli.rs:34-60)
+    eng = Engine(opt, dev_id)
+    tmpd = tempfile.mkdtemp()
+    # ---- first pass through the module API: admission + H2D + kernels + D2H + BED text ----
+    gbed_path = os.path.join(tmpd, f"g{rank}.bed")
+    counter = CallableProfiler(gbed_path)
+    st = ContigProfiler("chr21", L)
+    t0 = time.perf_counter()
+    process_single_contig(eng, counter, st, opt, tid, rec, ref)
+    counter.close()
+    e2e = time.perf_counter() - t0
+    first = eng.contig_collect()
+    log(f"[bench r{rank}] end-to-end first pass (host admission + PCIe + kernels + BED): {e2e:.2f}s "
+        f"= {L / e2e / 1e9:.3f} Gbase/s; intervals {first.summary.n_intervals}")
+
+    # ---- timed region: resident contig, blocks of K steps ----
+    dts = timed_blocks(eng.contig_run, eng.sync, args, world, dist, torch, coll_dev)
+    kms, _ = kernel_profile([eng], args.steps)
+    again = eng.contig_collect()
+    assert again.as_dict() == first.as_dict() and np.array_equal(again.intervals, first.intervals), \
+        "resident re-run changed the result"
+
+    # RCCL gather of the per-contig summaries (the path's only exchange), straight from HBM
+    from decodingustools_amd.coverage import device_summary_tensor
+    summ = device_summary_tensor(eng).clone()
+    if coll_dev == "cpu":
+        summ = summ.cpu()
+    if world > 1:
+        allsum = [torch.zeros_like(summ) for _ in range(world)]
+        dist.all_gather(allsum, summ)
+    else:
+        allsum = [summ]
+    total_bases = sum(int(s[11].item()) for s in allsum)           # word 11: extent
+    if rank != 0:
+        eng.close()
+        return None
+    dt_mean = sum(dts) / len(dts)
+    ms_step = dt_mean * 1e3 / args.steps
+    inb, outb = eng.contig_bytes()
+    out = {
+        "metric": METRIC,
+        "value": total_bases / (dt_mean / args.steps), "unit": "bases/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "coverage -L chr21 synthetic 30x 150bp paired, device-resident, one contig per GPU",
+                   "contig_len": L, "depth": args.depth, "reads_per_contig": rec.n,
+                   "aligned_bases_per_contig": int(rec.qual.shape[0]), "parallelism": f"contig-per-gpu x{world}",
+                   "options": "cli defaults (4,500,10,20,10,1,0.1)"},
+        "timing": {"blocks": len(dts), "steps_per_block": args.steps, "timed_region_s": sum(dts),
+                   "ms_per_step_min": min(dts) * 1e3 / args.steps, "ms_per_step_max": max(dts) * 1e3 / args.steps},
+        "roofline": roofline(inb + outb, kms["pileup"], ms_step, kms),
+        "end_to_end_first_pass_s": e2e,
+    }
+    if world == 1 and args.cpu_sample != 0:
+        Ls = L if args.cpu_sample < 0 else min(args.cpu_sample, L)
+        sub, ost, obed, cdt = cpu_baseline(rec, ref, Ls, opt, tid)
+        if Ls == L:
+            gbed = open(gbed_path).read()            # the first pass above: the whole contig
+            gst = st
+        else:                                        # the same sample through the GPU engine
+            counter = CallableProfiler(os.path.join(tmpd, "gs.bed"))
+            gst = ContigProfiler("chr21", Ls)
+            process_single_contig(eng, counter, gst, opt, tid, sub, ref[:Ls])
+            counter.close()
+            gbed = open(os.path.join(tmpd, "gs.bed")).read()
+        exact = (gbed == obed) and all(getattr(gst, k) == ost[k] for k in
+                                       ("n_covered_bases", "summed_coverage", "summed_baseq", "summed_mapq",
+                                        "quality_bases", "n_reads"))
+        out["cpu_baseline"] = {"value": Ls / cdt, "unit": "bases/s", "cores": 1, "kind": "port",
+                               "sample": (f"the whole contig, {Ls} positions" if Ls == L else f"first {Ls} positions of the same contig")
+                                         + f" ({sub.n} reads), oracle/callable_oracle.c single thread, {cdt:.1f}s"}
+        try:
+            allc = cpu_baseline_all_cores(rec, ref, opt, tid, 2_000_000, min(16, os.cpu_count() or 1))
+            if allc:
+                out["cpu_baseline"]["all_cores"] = allc
+        except Exception as e:                      # the single-thread figure above is the contract's
+            log(f"[bench] all-cores CPU baseline skipped: {e}")
+        out["bed_bit_exact"] = bool(exact)
+        out["bed_bit_exact_positions"] = Ls
+        if not exact:
+            log("[bench] WARNING: GPU BED/summary differs from the oracle")
+    eng.close()
+    del rec, ref
+    if world == 1 and not args.no_secondary:
+        out["configs"] = secondary_configs(dev_id, opt, args)
+    return out
+
+
+def run_wgs(args, rank, world, dev_id, torch, dist, coll_dev):
+    """BASELINE.json configs[3]: fixed whole-genome input, LPT-dealt, strong scaling."""
+    from decodingustools_amd import CallableOptions, wgs
+    opt = CallableOptions()
+    stream = torch.cuda.Stream(device=dev_id)            # every engine of the rank and the collective share it
+    t0 = time.perf_counter()
+    with torch.cuda.stream(stream):
+        shard = wgs.build_shard(rank, world, dev_id, opt, depth=args.depth, scale=args.wgs_scale,
+                                stream=stream.cuda_stream, gen_threads=args.gen_threads, log=log)
+        build_s = time.perf_counter() - t0
+        last = {}
+
+        def step():
+            shard.step()
+            last["g"] = shard.gather_device(coll_dev)     # all_gather of the summary records, device to device
+
+        def sync():
+            stream.synchronize()
+        dts = timed_blocks(step, sync, args, world, dist, torch, coll_dev)
+        table = shard.parse(last["g"])
+        kms, _ = kernel_profile([c.engine for c in shard.mine], args.steps)
+        stream.synchronize()
+        # what every rank did in one step, and how even the deal was
+        mine_ms = sum(kms.values())
+        info = torch.tensor([float(shard.bases), mine_ms, float(sum(c.first_pass_s for c in shard.mine)),
+                             float(sum(c.aligned_bases for c in shard.mine)), kms.get("pileup", 0.0),
+                             float(sum(sum(c.engine.contig_bytes()) for c in shard.mine))],
+                            dtype=torch.float64, device=coll_dev)
+        infos = [torch.zeros_like(info) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(infos, info)
+        else:
+            infos = [info]
+    infos = [x.cpu().tolist() for x in infos]
+    # every rank holds the whole table: check it against the rank's own first pass
+    for c in shard.mine:
+        row = table[c.tid]
+        assert [int(x) for x in row[:6]] == c.outcome.state_counts and int(row[13]) == c.outcome.intervals.shape[0], \
+            f"gathered summary of {c.name} differs from the first pass"
+    total_bases = sum(int(table[t][11]) for t, _, _ in shard.contigs)       # word 11: extent (= length, no overhang)
+    out = None
+    if rank == 0:
+        dt_mean = sum(dts) / len(dts)
+        ms_step = dt_mean * 1e3 / args.steps
+        loads = [x[0] for x in infos]
+        alg = sum(x[5] for x in infos)
+        pile_ms = sum(x[4] for x in infos)
+        callable_b = sum(int(table[t][1]) for t, _, _ in shard.contigs)
+        out = {
+            "metric": METRIC,
+            "value": total_bases / (dt_mean / args.steps), "unit": "bases/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "whole-genome synthetic 30x hg38 (25 primary contigs), contigs LPT-dealt to the GPUs, "
+                                   "device-resident, one all_gather of the per-contig summaries per step",
+                       "contigs": len(shard.contigs), "total_bases": total_bases, "depth": args.depth, "wgs_scale": args.wgs_scale,
+                       "aligned_bases": int(sum(x[3] for x in infos)), "parallelism": f"contig-sharded x{world} (LPT)",
+                       "collective_backend": args.backend, "options": "cli defaults (4,500,10,20,10,1,0.1)"},
+            "timing": {"blocks": len(dts), "steps_per_block": args.steps, "timed_region_s": sum(dts),
+                       "ms_per_step_min": min(dts) * 1e3 / args.steps, "ms_per_step_max": max(dts) * 1e3 / args.steps},
+            "sharding": {"per_rank_bases": [int(x) for x in loads], "per_rank_kernel_ms": [x[1] for x in infos],
+                         "per_rank_first_pass_s": [x[2] for x in infos],
+                         "lpt_imbalance": max(loads) / (sum(loads) / len(loads)),
+                         "contigs_of_rank": [[n for (_, n, _), r in zip(shard.contigs, shard.rank_of) if r == k] for k in range(world)],
+                         "build_s_rank0": build_s},
+            # the dominant kernel over the whole job: every rank's algorithmic bytes / every rank's k_pileup time
+            "roofline": roofline(alg, pile_ms, ms_step, kms, world),
+            "callable_fraction": callable_b / max(total_bases, 1),
+        }
+        out["roofline"]["per_rank_frac"] = [x[5] / (x[4] * 1e-3) / 1e9 / PEAK_HBM_GBS if x[4] > 0 else 0.0 for x in infos]
+        out["roofline"]["all_kernel_ms_of"] = "rank 0"
+    shard.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--length", type=int, default=46_709_983, help="contig length (default chr21)")
+    ap.add_argument("--workload", choices=["auto", "chr21", "wgs"], default="auto",
+                    help="auto: chr21 (configs[1]) on one GPU, the whole genome (configs[3]) on several")
+    ap.add_argument("--length", type=int, default=46_709_983, help="chr21 workload: contig length")
     ap.add_argument("--depth", type=float, default=30.0)
-    ap.add_argument("--cpu-sample", type=int, default=16_000_000, help="positions of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--min-time", type=float, default=0.6, help="seconds of timed K-step blocks to accumulate")
+    ap.add_argument("--max-blocks", type=int, default=400)
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="positions of the CPU baseline / bit-exactness sample (-1 = the whole contig, 0 = skip)")
+    ap.add_argument("--wgs-scale", type=float, default=1.0, help="wgs workload: contig lengths x this (rehearsals)")
+    ap.add_argument("--gen-threads", type=int, default=4, help="wgs workload: contigs generated ahead on host threads")
+    ap.add_argument("--long-length", type=int, default=57_227_415, help="secondary config 3: contig length (chrY)")
+    ap.add_argument("--site-length", type=int, default=57_227_415, help="secondary config 5: contig length (chrY)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs[2] / configs[4] lines")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank logic on one GPU)")
     args = ap.parse_args()
 
@@ -121,135 +477,14 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_id))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
-
-    from decodingustools_amd import (CallableOptions, CallableProfiler, ContigProfiler, Engine,
-                                     process_single_contig, synth)
-
-    L = args.length
-    tid = 20
-    seed = synth.seed_for(2, tid) + 1000 * rank
-    t0 = time.perf_counter()
-    rec = synth.short_read_contig(L, args.depth, seed)
-    ref = synth.make_reference(L, seed)
-    log(f"[bench r{rank}] synthetic contig: {L} bp, {rec.n} reads, {rec.qual.shape[0]} aligned bases "
-        f"({time.perf_counter() - t0:.1f}s)")
-
-    opt = CallableOptions()          # the CLI defaults (cli.rs:34-60)
-    eng = Engine(opt, dev_id)
-    tmpd = tempfile.mkdtemp()
-    # ---- first pass through the module API: admission + H2D + kernels + D2H + BED text ----
-    counter = CallableProfiler(os.path.join(tmpd, f"g{rank}.bed"))
-    st = ContigProfiler("chr21", L)
-    t0 = time.perf_counter()
-    process_single_contig(eng, counter, st, opt, tid, rec, ref)
-    counter.close()
-    e2e = time.perf_counter() - t0
-    first = eng.contig_collect()
-    log(f"[bench r{rank}] end-to-end first pass (host admission + PCIe + kernels + BED): {e2e:.2f}s "
-        f"= {L / e2e / 1e9:.3f} Gbase/s; intervals {first.summary.n_intervals}")
-
-    # ---- timed region: resident contig, K steps ----
-    for _ in range(args.warmup):
-        eng.contig_run()
-    eng.sync()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.contig_run()             # four kernel launches on the engine's stream
-    eng.sync()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    # per-kernel durations: the same steps once more with HIP events between the kernel groups on the
-    # engine's stream (direct launches; outside the timed region)
-    eng.set_profiling(True)
-    eng.reset_kernel_ms()
-    for _ in range(max(5, min(args.steps, 20))):
-        eng.contig_run()
-    eng.sync()
-    kms, nruns = eng.kernel_ms()
-    eng.set_profiling(False)
-    again = eng.contig_collect()
-    assert again.as_dict() == first.as_dict() and np.array_equal(again.intervals, first.intervals), \
-        "resident re-run changed the result"
-
-    # max over ranks + RCCL gather of the per-contig summaries (the path's only exchange)
-    tsr = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-    summ = torch.tensor([int(x) for x in first.state_counts] +
-                        [int(first.summary.n_covered_bases), int(first.summary.summed_coverage),
-                         int(first.summary.summed_baseq), int(first.summary.summed_mapq),
-                         int(first.summary.quality_bases), int(first.summary.extent)],
-                        dtype=torch.int64, device=coll_dev)
-    if world > 1:
-        dist.all_reduce(tsr, op=dist.ReduceOp.MAX)
-        allsum = [torch.zeros_like(summ) for _ in range(world)]
-        dist.all_gather(allsum, summ)
-    else:
-        allsum = [summ]
-    dt_max = float(tsr.item())
-    total_bases = sum(int(s[11].item()) for s in allsum)
-
-    if rank == 0:
-        ms_step = dt_max * 1e3 / args.steps
-        value = total_bases / (dt_max / args.steps)
-        inb, outb = eng.contig_bytes()
-        pile_ms = kms["pileup"] / max(nruns, 1)
-        alg = inb + outb
-        achieved = alg / (pile_ms * 1e-3) / 1e9 if pile_ms > 0 else 0.0
-        peak = 8000.0
-        traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tf):
-            try:
-                traffic = json.load(open(tf)).get("k_pileup_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "reference bases classified/sec (whole node) + BED bit-exact vs CPU ref",
-            "value": value, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "coverage -L chr21 synthetic 30x 150bp paired, device-resident, one contig per GPU",
-                       "contig_len": L, "depth": args.depth, "reads_per_contig": rec.n,
-                       "aligned_bases_per_contig": int(rec.qual.shape[0]), "parallelism": f"contig-per-gpu x{world}",
-                       "options": "cli defaults (4,500,10,20,10,1,0.1)"},
-            "roofline": {"bound": "hbm", "kernel": "k_pileup", "achieved": achieved, "peak": peak, "unit": "GB/s",
-                         "frac": achieved / peak, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg, "kernel_ms": pile_ms,
-                         "all_kernel_ms": {k: v / max(nruns, 1) for k, v in kms.items()}},
-            "end_to_end_first_pass_s": e2e,
-        }
-        if world == 1 and args.cpu_sample > 0:
-            Ls = min(args.cpu_sample, L)
-            sub, ost, obed, cdt = cpu_baseline(rec, ref, Ls, opt, tid)
-            # the same sample through the GPU engine: BED must be bit-identical
-            counter = CallableProfiler(os.path.join(tmpd, "gs.bed"))
-            st2 = ContigProfiler("chr21", Ls)
-            process_single_contig(eng, counter, st2, opt, tid, sub, ref[:Ls])
-            counter.close()
-            gbed = open(os.path.join(tmpd, "gs.bed")).read()
-            exact = (gbed == obed) and all(getattr(st2, k) == ost[k] for k in
-                                           ("n_covered_bases", "summed_coverage", "summed_baseq", "summed_mapq",
-                                            "quality_bases", "n_reads"))
-            out["cpu_baseline"] = {"value": Ls / cdt, "unit": "bases/s", "cores": 1, "kind": "port",
-                                   "sample": f"first {Ls} positions of the same contig ({sub.n} reads), "
-                                             f"oracle/callable_oracle.c single thread, {cdt:.1f}s"}
-            try:
-                allc = cpu_baseline_all_cores(rec, ref, opt, tid, Ls, 2_000_000, min(16, os.cpu_count() or 1))
-                if allc:
-                    out["cpu_baseline"]["all_cores"] = allc
-            except Exception as e:                      # the single-thread figure above is the contract's
-                log(f"[bench] all-cores CPU baseline skipped: {e}")
-            out["bed_bit_exact"] = bool(exact)
-            if not exact:
-                log("[bench] WARNING: GPU BED/summary differs from the oracle on the sample")
-        print(json.dumps(out), flush=True)
-    eng.close()
-    if world > 1:
-        dist.destroy_process_group()
+    workload = args.workload if args.workload != "auto" else ("chr21" if world == 1 else "wgs")
+    try:
+        out = (run_chr21 if workload == "chr21" else run_wgs)(args, rank, world, dev_id, torch, dist, coll_dev)
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
 
 
 if __name__ == "__main__":

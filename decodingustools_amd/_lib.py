@@ -115,6 +115,7 @@ SYMBOLS = [
     ("cl_debug_depths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("cl_site_pileup", C.c_int, [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(cl_site_tile),
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("cl_site_pileup_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("dut_profiler_new", C.c_void_p, [C.c_char_p]),
     ("dut_profiler_free", None, [C.c_void_p]),
     ("dut_profiler_enable_plots", None, [C.c_void_p, C.c_uint32]),
@@ -152,6 +153,7 @@ SYMBOLS = [
     ("dut_fasta_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("dut_fasta_close", None, [C.c_void_p]),
     ("dut_fasta_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),
+    ("dut_fasta_error", C.c_char_p, [C.c_void_p]),
     ("dut_coverage_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.POINTER(cl_options), C.POINTER(C.c_char_p), C.c_size_t, C.c_int,
                                      C.c_char_p, C.c_size_t]),

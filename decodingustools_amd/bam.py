@@ -77,7 +77,9 @@ class FastaReader:
 
     def fetch(self, name: str) -> np.ndarray:
         p, n = C.c_void_p(), C.c_uint64()
-        self._lib.dut_fasta_fetch(self._h, name.encode(), C.byref(p), C.byref(n))
+        st = self._lib.dut_fasta_fetch(self._h, name.encode(), C.byref(p), C.byref(n))
+        if st != 0:                                    # fetch_seq(..)? of the reference (mod.rs:79)
+            raise OSError(self._lib.dut_fasta_error(self._h).decode())
         return _arr(p.value, int(n.value), np.uint8)
 
     def close(self):

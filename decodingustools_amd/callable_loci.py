@@ -193,6 +193,12 @@ class Engine:
                                              _ptr(sites), sites.shape[0], _ptr(hist)))
         return hist
 
+    def site_pileup_stats(self):
+        """(kernel milliseconds, algorithmic bytes) of the last site_pileup."""
+        ms = C.c_double(); b = C.c_uint64()
+        self._check(self._lib.cl_site_pileup_stats(self._h, C.byref(ms), C.byref(b)))
+        return ms.value, b.value
+
 
 @dataclass
 class ContigResult:

@@ -57,9 +57,8 @@ class ContigOutcome:
     stats: ContigProfiler
     state_counts: List[int]
     intervals: np.ndarray                  # (n,3) uint32
+    dev_summary: object = None             # optional: the engine's resident cl_contig_summary (device tensor view)
 
-
-SUMMARY_FIELDS = 14   # 6 counts, covered, sum_cov, sum_baseq, sum_mapq, quality_bases, n_reads, length, n_intervals
 
 
 def initialize_contig_stats(inp: CoverageInput):
@@ -80,7 +79,8 @@ def validate_contig_selection(stats, inp: CoverageInput):
             ", ".join(inp.selected)))
 
 
-def engine_process_contig(engine: Engine, options: CallableOptions, tid: int, c: ContigInput) -> ContigOutcome:
+def engine_process_contig(engine: Engine, options: CallableOptions, tid: int, c: ContigInput,
+                          with_dev_summary: bool = False) -> ContigOutcome:
     """process_single_contig (mod.rs:44-147) on the device engine, returning the runs instead of
     writing them (the caller owns the BED writer)."""
     acc, n_names = admit_reads(options, tid, c.length, c.records)
@@ -104,7 +104,8 @@ def engine_process_contig(engine: Engine, options: CallableOptions, tid: int, c:
     st.n_covered_bases = int(s.n_covered_bases); st.summed_coverage = int(s.summed_coverage)
     st.summed_baseq = int(s.summed_baseq); st.summed_mapq = int(s.summed_mapq)
     st.quality_bases = int(s.quality_bases); st.n_reads = int(n_names)
-    return ContigOutcome(tid=tid, stats=st, state_counts=res.state_counts, intervals=res.intervals)
+    return ContigOutcome(tid=tid, stats=st, state_counts=res.state_counts, intervals=res.intervals,
+                         dev_summary=device_summary_tensor(engine) if with_dev_summary else None)
 
 
 def build_coverage_export(outcomes: List[ContigOutcome]) -> Dict:
@@ -206,12 +207,55 @@ def _outcome_row(o: ContigOutcome) -> List[int]:
                                    s.quality_bases, s.n_reads, s.length, int(o.intervals.shape[0])]
 
 
+# columns of a gathered summary row: the contig's tid, the 14 words of cl_contig_summary exactly as the
+# engine leaves them in HBM (include/callable_loci.h: state_counts[6], n_covered_bases, summed_coverage,
+# summed_baseq, summed_mapq, quality_bases, extent, max_raw_depth, n_intervals), then the host-side
+# distinct-name count
+ROW_WORDS = 16
+
+
+class DeviceWords:
+    """A zero-copy view of `n` 64-bit words at a device address (`__cuda_array_interface__`, which
+    torch.as_tensor understands on ROCm too): how the resident cl_contig_summary of an engine
+    (cl_device_summary) enters a collective without a host round trip."""
+
+    def __init__(self, ptr: int, n: int):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr="<i8", data=(int(ptr), False), version=2)
+
+
+def device_summary_tensor(engine: Engine):
+    """The engine's resident summary record as a torch int64 tensor on its device (no copy)."""
+    import torch
+    ptr, nbytes = engine.device_summary()
+    return torch.as_tensor(DeviceWords(ptr, nbytes // 8), device=torch.device("cuda", engine.device_id))
+
+
+def _exchange_status(rank: int, world: int, error: Optional[str], group=None) -> None:
+    """Every rank learns whether any rank failed before the data collectives start: a rank that raised in
+    its contig loop would otherwise leave the others blocked in the all_gather (with RCCL until the
+    watchdog fires).  Raises the reference's error text (api/coverage.rs:251) on every rank."""
+    import torch.distributed as dist
+    if world > 1:
+        status = [None] * world
+        dist.all_gather_object(status, error, group=group)
+    else:
+        status = [error]
+    bad = [(r, m) for r, m in enumerate(status) if m is not None]
+    if bad:
+        r, m = bad[0]
+        raise ApiError(f"Error processing contig: {m}" + (f" (rank {r})" if world > 1 else ""))
+
+
 def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: Callable[[int, ContigInput], ContigOutcome],
                     device="cpu", group=None, on_assignment: Optional[Callable[[List[int]], None]] = None) -> Optional[CoverageOutput]:
     """Every rank calls this with the same `inp` description (it only touches the contigs it is
     assigned).  `process_contig(tid, contig)` runs one contig on this rank's GPU
     (engine_process_contig bound to the rank's Engine).  Returns the output on rank 0, None elsewhere.
-    The only exchanges are the summary all_gather and the run lists sent to rank 0."""
+    The only exchanges are a status word per rank, the summary all_gather and the run lists sent to rank 0.
+
+    `device`: where the collectives' tensors live -- "cuda" with the nccl (= RCCL) backend, "cpu" with gloo.
+    An outcome may carry `dev_summary`, the engine's resident cl_contig_summary as a device tensor
+    (device_summary_tensor): its words then go from HBM into the gathered row device to device."""
     import torch
     import torch.distributed as dist
     stats = initialize_contig_stats(inp)
@@ -223,16 +267,32 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
     mine = [t for t, r in zip(tids, rank_of) if r == rank]
     if on_assignment is not None:
         on_assignment(list(mine))                      # the order process_contig will be called in (read-ahead hook)
-    local = {t: process_contig(t, inp.contigs[t]) for t in mine}
 
-    # --- summaries: fixed-size rows, one all_gather ---
+    # --- this rank's contigs; summaries land in fixed-size rows (one all_gather below) ---
     per_rank = max(1, max(rank_of.count(r) for r in range(world)) if tids else 1)
-    rows = torch.zeros((per_rank, SUMMARY_FIELDS + 1), dtype=torch.int64)
+    on_dev = str(device).startswith("cuda")
+    rows = torch.zeros((per_rank, ROW_WORDS), dtype=torch.int64, device=device if on_dev else "cpu")
     rows[:, 0] = -1
-    for i, t in enumerate(mine):
-        rows[i, 0] = t
-        rows[i, 1:] = torch.tensor(_outcome_row(local[t]), dtype=torch.int64)
-    rows = rows.to(device)
+    local = {}
+    error = None
+    try:
+        for i, t in enumerate(mine):
+            o = process_contig(t, inp.contigs[t])
+            local[t] = o
+            dv = getattr(o, "dev_summary", None)
+            if dv is not None and on_dev:
+                rows[i, 1:15].copy_(dv)                # HBM -> HBM; the engine has synchronised its stream
+                torch.cuda.current_stream().synchronize()   # ... and the record is free for the engine's next contig
+                o.dev_summary = None                   # the view dies with the engine's next contig
+                head_tail = torch.tensor([t, o.stats.n_reads], dtype=torch.int64).to(device)
+                rows[i, 0] = head_tail[0]; rows[i, 15] = head_tail[1]
+            else:
+                r14 = _outcome_row(o)                  # counts[6], 5 sums, n_reads, length, n_intervals
+                words = r14[:11] + [o.stats.length, 0, r14[13]]     # extent / max_raw_depth are not used downstream
+                rows[i] = torch.tensor([t] + words + [o.stats.n_reads], dtype=torch.int64).to(rows.device)
+    except Exception as e:                             # api/coverage.rs:251: the error is reported, not lost in a hang
+        error = f"{e}"
+    _exchange_status(rank, world, error, group)
     gathered = [torch.zeros_like(rows) for _ in range(world)]
     if world > 1:
         dist.all_gather(gathered, rows, group=group)
@@ -244,14 +304,14 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
             if row[0] >= 0:
                 table[int(row[0])] = row[1:]
 
-    # --- run lists to rank 0 (padded to the largest list of any rank) ---
+    # --- run lists to rank 0: (start, end, state) as 32-bit triplets, padded to the largest list of any rank ---
     n_iv_rank = [sum(table[t][13] for t, r in zip(tids, rank_of) if r == rr) for rr in range(world)]
     cap = max(1, max(n_iv_rank) if n_iv_rank else 1)
-    buf = torch.zeros((cap, 3), dtype=torch.int64)
+    buf = torch.zeros((cap, 3), dtype=torch.int32)
     off = 0
     for t in mine:
-        iv = local[t].intervals
-        buf[off:off + iv.shape[0]] = torch.from_numpy(iv.astype(np.int64))
+        iv = np.ascontiguousarray(local[t].intervals, np.uint32)
+        buf[off:off + iv.shape[0]] = torch.from_numpy(iv.view(np.int32))      # same bits
         off += iv.shape[0]
     buf = buf.to(device)
     if world > 1:
@@ -263,15 +323,16 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
         return None
     outcomes = []
     offs = [0] * world
+    host_bufs = [b.cpu().numpy().view(np.uint32) for b in bufs]
     for t, r in zip(tids, rank_of):
         row = table[t]
         n_iv = int(row[13])
-        iv = bufs[r][offs[r]:offs[r] + n_iv].cpu().numpy().astype(np.uint32)
+        iv = host_bufs[r][offs[r]:offs[r] + n_iv].copy()
         offs[r] += n_iv
         c = inp.contigs[t]
         st = ContigProfiler(c.name, c.length, n_covered_bases=int(row[6]), summed_coverage=int(row[7]),
                             summed_baseq=int(row[8]), summed_mapq=int(row[9]), quality_bases=int(row[10]),
-                            n_reads=int(row[11]))
+                            n_reads=int(row[14]))
         outcomes.append(ContigOutcome(tid=t, stats=st, state_counts=[int(x) for x in row[:6]], intervals=iv))
     write_bed(outcomes, inp.output_bed)
     out = CoverageOutput(export=build_coverage_export(outcomes), bed_file=inp.output_bed)
@@ -280,7 +341,7 @@ def analyze_sharded(inp: CoverageInput, rank: int, world: int, process_contig: C
 
 
 def engine_process_contig_runs(engine: Engine, options: CallableOptions, tid: int, name: str, length: int,
-                               rec: ContigRecords, ref: Optional[np.ndarray]) -> ContigOutcome:
+                               rec: ContigRecords, ref: Optional[np.ndarray], with_dev_summary: bool = False) -> ContigOutcome:
     """process_single_contig through the C driver (admission, one zero-copy tile, kernels), returning
     the runs instead of writing them."""
     import ctypes as C
@@ -298,7 +359,8 @@ def engine_process_contig_runs(engine: Engine, options: CallableOptions, tid: in
     st._load(cs)
     runs = (np.ctypeslib.as_array(C.cast(iv, C.POINTER(C.c_uint32)), shape=(n.value, 3)).copy() if n.value
             else np.zeros((0, 3), np.uint32))
-    return ContigOutcome(tid=tid, stats=st, state_counts=[int(x) for x in counts], intervals=runs)
+    return ContigOutcome(tid=tid, stats=st, state_counts=[int(x) for x in counts], intervals=runs,
+                         dev_summary=device_summary_tensor(engine) if with_dev_summary else None)
 
 
 def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, summary_json: Optional[str],
@@ -341,7 +403,8 @@ def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, 
                 if pool and i + 1 < len(order):
                     nt = order[i + 1]
                     pending[nt] = pool.submit(fetch, (i + 1) & 1, nt, descr[nt].name)
-                return engine_process_contig_runs(eng, options, tid, c.name, c.length, rec, bases)
+                return engine_process_contig_runs(eng, options, tid, c.name, c.length, rec, bases,
+                                                  with_dev_summary=str(coll_device).startswith("cuda"))
             out = analyze_sharded(inp, rank, world, run, device=coll_device, group=group, on_assignment=order.extend)
         if rank != 0:
             return None

@@ -187,7 +187,7 @@ struct BlockStream {
     RawBuf<uint8_t> cbuf;
     // read-ahead: while a batch is inflated the next one is read (pread, own thread) into cbuf_next
     RawBuf<uint8_t> cbuf_next;
-    std::thread ahead;
+    dut::Thread ahead;
     uint64_t ahead_off = 0;
     size_t ahead_want = 0, ahead_got = 0;
     void drop_ahead() { if (ahead.joinable()) ahead.join(); ahead_want = 0; }
@@ -787,24 +787,111 @@ struct dut_fasta {
     struct Ent { std::string name; uint64_t len, off, linebases, linewidth; };
     std::vector<Ent> ents;
     std::vector<uint8_t> seq;
+    std::string err;
+    uint64_t file_size = 0;
 };
+
+// What `samtools faidx` / htslib's fai_build writes: one row per sequence (name up to the first white space, length,
+// offset of the first base, bases per line, bytes per line).  The reference's faidx::Reader::from_path builds the
+// index when it is missing; so does dut_fasta_open.
+static bool fai_build(FILE *fp, std::vector<dut_fasta::Ent> &ents, std::string &err)
+{
+    std::vector<char> buf(1 << 20);
+    uint64_t off = 0;                 // file offset of buf[0]
+    dut_fasta::Ent cur{};
+    bool in_seq = false, in_name_line = false, name_done = false, last_line_short = false;
+    uint64_t line_b = 0, line_w = 0;  // bases / bytes of the current sequence line so far
+    auto end_line = [&]() -> bool {    // a sequence line of `cur` just ended
+        if (line_w == 0 && line_b == 0) return true;
+        if (cur.linebases == 0) { cur.linebases = line_b; cur.linewidth = line_w; }
+        else {
+            if (last_line_short && line_b) { err = "different line length in sequence '" + cur.name + "'"; return false; }
+            if (line_b != cur.linebases || line_w != cur.linewidth) {
+                if (line_b > cur.linebases) { err = "different line length in sequence '" + cur.name + "'"; return false; }
+                last_line_short = true;                       // only the last line may be shorter
+            }
+        }
+        cur.len += line_b;
+        line_b = 0; line_w = 0;
+        return true;
+    };
+    if (fseeko(fp, 0, SEEK_SET) != 0) { err = "cannot seek"; return false; }
+    for (;;) {
+        const size_t got = fread(buf.data(), 1, buf.size(), fp);
+        if (got == 0) break;
+        for (size_t i = 0; i < got; ++i) {
+            const char c = buf[i];
+            if (in_name_line) {
+                if (c == '\n') { in_name_line = false; cur.off = off + i + 1; }
+                else if (!name_done) { if (c == ' ' || c == '\t' || c == '\r') name_done = true; else cur.name.push_back(c); }
+                continue;
+            }
+            if (c == '>' && line_w == 0) {
+                if (in_seq) { if (!end_line()) return false; ents.push_back(cur); }
+                cur = dut_fasta::Ent{}; in_seq = true; in_name_line = true; name_done = false; last_line_short = false;
+                continue;
+            }
+            if (!in_seq) { if (c == '\n' || c == '\r') continue; err = "the file does not start with '>'"; return false; }
+            line_w += 1;
+            if (c == '\n') { if (!end_line()) return false; }
+            else if (c != '\r') line_b += 1;
+        }
+        off += got;
+    }
+    if (in_seq) {
+        if (line_w) { if (cur.linebases == 0) { cur.linebases = line_b; cur.linewidth = line_w + 1; } cur.len += line_b; line_b = 0; line_w = 0; }
+        ents.push_back(cur);
+    }
+    for (auto &e : ents) if (e.len == 0) { e.linebases = 0; e.linewidth = 0; }
+    return true;
+}
 
 extern "C" {
 
 dut_fasta *dut_fasta_open(const char *path, char *err, size_t err_len)
 {
     if (!path) { set_err(err, err_len, "null path"); return nullptr; }
-    FILE *fi = fopen((std::string(path) + ".fai").c_str(), "r");
-    if (!fi) { set_err(err, err_len, std::string("cannot open ") + path + ".fai (the reference needs a faidx index)"); return nullptr; }
     dut_fasta *f = new dut_fasta();
-    char line[4096];
-    while (fgets(line, sizeof(line), fi)) {
-        char nm[2048]; unsigned long long a, b, c, d;
-        if (sscanf(line, "%2047[^\t]\t%llu\t%llu\t%llu\t%llu", nm, &a, &b, &c, &d) == 5) f->ents.push_back({nm, a, b, c, d});
-    }
-    fclose(fi);
     f->fp = fopen(path, "rb");
     if (!f->fp) { set_err(err, err_len, std::string("cannot open ") + path); delete f; return nullptr; }
+    if (fseeko(f->fp, 0, SEEK_END) == 0) f->file_size = (uint64_t)ftello(f->fp);
+    const std::string fai_path = std::string(path) + ".fai";
+    FILE *fi = fopen(fai_path.c_str(), "r");
+    if (!fi) {
+        // no index beside the file: build it (and leave it there when the directory can be written, as htslib does)
+        std::string berr;
+        if (!fai_build(f->fp, f->ents, berr)) {
+            set_err(err, err_len, std::string("cannot index ") + path + ": " + berr);
+            fclose(f->fp); delete f; return nullptr;
+        }
+        if (FILE *fo = fopen(fai_path.c_str(), "w")) {
+            for (const auto &e : f->ents)
+                fprintf(fo, "%s\t%llu\t%llu\t%llu\t%llu\n", e.name.c_str(), (unsigned long long)e.len, (unsigned long long)e.off,
+                        (unsigned long long)e.linebases, (unsigned long long)e.linewidth);
+            fclose(fo);
+        }
+        return f;
+    }
+    char line[4096];
+    size_t row = 0;
+    while (fgets(line, sizeof(line), fi)) {
+        ++row;
+        char nm[2048]; unsigned long long a, b, c, d;
+        if (line[0] == '\n' || line[0] == 0) continue;
+        if (sscanf(line, "%2047[^\t]\t%llu\t%llu\t%llu\t%llu", nm, &a, &b, &c, &d) != 5) {
+            set_err(err, err_len, fai_path + ": malformed row " + std::to_string(row));
+            fclose(fi); fclose(f->fp); delete f; return nullptr;
+        }
+        // a row the fetch arithmetic cannot use: an empty sequence may have no line shape, any other needs
+        // 0 < bases per line <= bytes per line
+        const bool ok = a == 0 || (c > 0 && d >= c);
+        if (!ok) {
+            set_err(err, err_len, fai_path + ": invalid row " + std::to_string(row) + " (sequence '" + nm + "')");
+            fclose(fi); fclose(f->fp); delete f; return nullptr;
+        }
+        f->ents.push_back({nm, a, b, c, d});
+    }
+    fclose(fi);
     return f;
 }
 
@@ -815,19 +902,22 @@ void dut_fasta_close(dut_fasta *f)
     delete f;
 }
 
-int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len)
+const char *dut_fasta_error(const dut_fasta *f) { return f ? f->err.c_str() : "null reader"; }
+
+static int dut_fasta_fetch_impl(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len)
 {
-    if (!f || !name || !bases || !len) return CL_ERR_INVALID;
-    *bases = nullptr; *len = 0;
     for (const auto &e : f->ents) {
         if (e.name != name) continue;
         f->seq.clear();
-        if (e.len == 0 || e.linebases == 0) return CL_OK;
+        if (e.len == 0) return CL_OK;
         const uint64_t n_lines = (e.len + e.linebases - 1) / e.linebases;
-        const uint64_t span = e.len + (n_lines - 1) * (e.linewidth - e.linebases) ;
-        std::vector<uint8_t> raw(span);
-        if (fseeko(f->fp, (off_t)e.off, SEEK_SET) != 0) return CL_ERR_INVALID;
-        const size_t got = fread(raw.data(), 1, span, f->fp);
+        const uint64_t span = e.len + (n_lines - 1) * (e.linewidth - e.linebases);
+        // a file shorter than its index says: the bases that are there, the rest reads as 'N' (mod.rs:79-80)
+        const uint64_t want = f->file_size ? std::min<uint64_t>(span, f->file_size > e.off ? f->file_size - e.off : 0) : span;
+        std::vector<uint8_t> raw(want);
+        if (fseeko(f->fp, (off_t)e.off, SEEK_SET) != 0) { f->err = std::string("cannot seek to sequence '") + name + "'"; return CL_ERR_INVALID; }
+        const size_t got = fread(raw.data(), 1, want, f->fp);
+        if (got < want && ferror(f->fp)) { f->err = std::string("read error in sequence '") + name + "'"; return CL_ERR_INVALID; }
         f->seq.reserve(e.len);
         for (size_t i = 0; i < got && f->seq.size() < e.len; ++i) {
             if (i % e.linewidth < e.linebases) f->seq.push_back(raw[i]);
@@ -835,7 +925,20 @@ int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint6
         *bases = f->seq.data(); *len = f->seq.size();
         return CL_OK;
     }
-    return CL_OK;       // unknown name: zero bases, every position reads as 'N'
+    // faidx fetch_seq of a name the index does not hold is an error in the reference (mod.rs:79: `?`), not a run of 'N'
+    f->err = std::string("sequence '") + name + "' not found in the reference FASTA index";
+    return CL_ERR_INVALID;
+}
+
+int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len)
+{
+    if (!f || !name || !bases || !len) return CL_ERR_INVALID;
+    *bases = nullptr; *len = 0;
+    f->err.clear();
+    // no exception leaves the library through the C ABI (and none may end a helper thread)
+    try { return dut_fasta_fetch_impl(f, name, bases, len); }
+    catch (const std::bad_alloc &) { f->err = "out of memory"; return CL_ERR_NOMEM; }
+    catch (...) { f->err = "internal error"; return CL_ERR_INVALID; }
 }
 
 } // extern "C"
@@ -891,11 +994,11 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
     }
     {
         // the HIP runtime and the engine context come up on their own thread while the first contig is decoded
-        std::thread init = dut::spawn_or_run([&]() { rc = cl_create(opt, device_id, nullptr, &ctx); });
+        dut::Thread init = dut::spawn_or_run([&]() { rc = cl_create(opt, device_id, nullptr, &ctx); });
         // Contigs are processed in ascending tid order (api/coverage.rs:229-234).  With an index and more
         // than one contig, the records and reference bases of contig i+1 are read by a second reader on
         // its own thread while contig i is admitted, pushed, run and written (DUT_PIPELINE=0: off).
-        struct Slot { dut_bam *bam = nullptr; dut_fasta *fa = nullptr; dut_records rec; const uint8_t *bases = nullptr; uint64_t blen = 0; int rc = CL_OK; };
+        struct Slot { dut_bam *bam = nullptr; dut_fasta *fa = nullptr; dut_records rec; const uint8_t *bases = nullptr; uint64_t blen = 0; int rc = CL_OK, frc = CL_OK; };
         Slot slot[2];
         slot[0].bam = bam; slot[0].fa = fa;
         const char *pe = getenv("DUT_PIPELINE");
@@ -911,11 +1014,11 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
         auto fetch = [&](Slot &s, int t) {
             // the reference bases (one thread: read + strip the line ends) beside the record decode (all threads)
             s.bases = nullptr; s.blen = 0;
-            std::thread fb = dut::spawn_or_run([&]() { dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen); });
+            dut::Thread fb = dut::spawn_or_run([&]() { s.frc = dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen); });
             s.rc = dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
             if (fb.joinable()) fb.join();
         };
-        std::thread ahead;
+        dut::Thread ahead;
         io_stage_time("(before contigs)", tm);
         if (!tids.empty()) fetch(slot[0], tids[0]);
         if (init.joinable()) init.join();
@@ -936,6 +1039,7 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
             io_stage_time(pipeline && i > 0 ? "wait for the read-ahead" : "BAM read + decode, FASTA fetch", tm);
             if (pipeline && i + 1 < tids.size()) { Slot &nx = slot[(i + 1) & 1]; const int tn = tids[i + 1]; ahead = dut::spawn_or_run([&fetch, &nx, tn]() { fetch(nx, tn); }); }
             if (cur.rc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_bam_error(cur.bam)); rc = cur.rc; }
+            else if (cur.frc != CL_OK) { set_err(err, err_len, std::string("Error processing contig: ") + dut_fasta_error(cur.fa)); rc = cur.frc; }   // fetch_seq(..)?, mod.rs:79
             dut_contig_stats st;
             memset(&st, 0, sizeof(st));
             if (rc == CL_OK) {
@@ -998,7 +1102,7 @@ out:
     if (prof) dut_profiler_free(prof);
     {
         // giving the device memory back and unmapping the decode buffers take a few hundred ms at chr21 size: side by side
-        std::thread td = dut::spawn_or_run([&]() { if (ctx) cl_destroy(ctx); });
+        dut::Thread td = dut::spawn_or_run([&]() { if (ctx) cl_destroy(ctx); });
         dut_fasta_close(fa);
         dut_bam_close(bam);
         io_stage_time("readers closed", tm);

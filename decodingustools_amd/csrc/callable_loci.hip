@@ -47,8 +47,8 @@ struct Range {
 };
 
 
-// window size (reference positions per workgroup).  2048 -> 24.9 KiB of LDS per workgroup,
-// six workgroups (24 waves) per CU.
+// window size (reference positions per workgroup).  2048 -> about 19 KB of LDS per workgroup of the short-read
+// variant, eight workgroups (32 waves) per CU.
 #ifndef CL_WINDOW
 #define CL_WINDOW 2048
 #endif
@@ -161,6 +161,10 @@ struct cl_ctx {
     int ev_pending = 0;
     double ms[CL_K_COUNT] = {};
     uint64_t n_runs = 0;
+    // the last cl_site_pileup: duration of its kernel (HIP events on the stream) and its algorithmic bytes
+    hipEvent_t site_ev[2] = {nullptr, nullptr};
+    double site_ms = 0.0;
+    uint64_t site_bytes = 0;
 };
 
 namespace {
@@ -406,6 +410,7 @@ void cl_destroy(cl_ctx *c)
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
     c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
+    for (int i = 0; i < 2; ++i) if (c->site_ev[i]) (void)hipEventDestroy(c->site_ev[i]);
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
@@ -500,8 +505,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     //      slices that go down side by side, one host thread and stream each, while this thread validates the
     //      tile and stages the small arrays.  All are joined before the call returns (the caller's buffer is
     //      free again then); nothing of the context changes if the tile turns out to be invalid. ----
-    std::vector<std::thread> copiers;
-    struct Joiner { std::vector<std::thread> &t; ~Joiner() { for (auto &x : t) if (x.joinable()) x.join(); } } joiner{copiers};
+    std::vector<dut::Thread> copiers;                          // joined when they go out of scope, whichever way
     hipError_t copy_err[cl_ctx::kCopyStreams] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
     const bool direct = nq >= kDirectQual;
     if (direct) {
@@ -565,7 +569,19 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         if (o.bad == 3) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
     }
 
-    // ---- staging of the small arrays (offsets rebased onto the contig's) ----
+    // ---- staging of the small arrays (offsets rebased onto the contig's); undone if anything below fails, so that
+    //      a refused tile leaves the context as it was ----
+    struct Undo {
+        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
+        ~Undo()
+        {
+            if (!armed) return;
+            c->h_pos.resize(n_pos); c->h_mapq.resize(n_pos); c->h_cigar.resize(n_cig); c->h_qual.resize(n_qual);
+            c->h_cigar_off.resize(n_pos + 1); c->h_qual_off.resize(n_pos + 1);
+            c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide);
+            c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end;
+        }
+    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->has_long, c->span_n, c->span_w, c->host_max_end};
     try {
         for (const Chunk &o : ch) {
             if (o.has_long) c->has_long = true;
@@ -590,8 +606,9 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
     for (auto &x : copiers) if (x.joinable()) x.join();
-    for (int i = 0; i < cl_ctx::kCopyStreams; ++i) HIP_TRY(c, copy_err[i]);
+    for (int i = 0; i < cl_ctx::kCopyStreams; ++i) HIP_TRY(c, copy_err[i]);      // a failed copy: the staged arrays are rolled back
     if (direct) c->q_dev += nq;
+    undo.armed = false;
     return CL_OK;
 }
 
@@ -703,7 +720,11 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
     Range rg("cl_contig_collect");
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
     HIP_TRY(c, hipSetDevice(c->device));
-    for (int attempt = 0; attempt < 5; ++attempt) {
+    // every `continue` below re-runs the contig for one distinct reason (32-bit counters: once; 16-bit fields in the
+    // marked windows: the marks are sticky, at most twice; a larger extent: once per overhang level), so a handful of
+    // rounds always suffices -- if they do not, the device state and h_sum disagree and nothing may be returned
+    bool converged = false;
+    for (int attempt = 0; attempt < 8 && !converged; ++attempt) {
         HIP_TRY(c, hipMemcpyAsync(&c->h_sum, c->d_summary.p, sizeof(DevSummary), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         cl_status s = harvest_events(c);
@@ -745,8 +766,9 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
             }
             HIP_TRY(c, hipGetLastError());
         }
-        break;
+        converged = true;
     }
+    if (!converged) return fail(c, CL_ERR_DEVICE, "cl_contig_collect: the re-run loop (counter width / extent) did not converge");
     const size_t niv = c->h_sum.n_intervals;
     static_assert(sizeof(cl_interval) == sizeof(Interval), "interval layout");
     try { c->h_iv.resize(niv); } catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "interval buffer"); }
@@ -916,13 +938,32 @@ static cl_status cl_site_pileup_impl(cl_ctx *c, uint8_t min_quality, uint32_t co
     R.pos = d_pos.p; R.mapq = d_mapq.p; R.cigar_off = d_coff.p; R.cigar = d_cig.p; R.seq_off = d_soff.p;
     R.seq4 = d_seq.p; R.n = (uint32_t)n;
     const uint32_t grid = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, 8192);
+    if (!c->site_ev[0]) { SITE_TRY(hipEventCreate(&c->site_ev[0])); SITE_TRY(hipEventCreate(&c->site_ev[1])); }
+    SITE_TRY(hipEventRecord(c->site_ev[0], c->stream));
     hipLaunchKernelGGL(k_site_pileup, dim3(grid), dim3(kBlock), 0, c->stream, R, (uint32_t)min_quality, contig_len,
                        (unsigned long long)ref_len, d_p0.p, d_ix.p, d_bk.p, n_buckets, (uint32_t)pos0.size(), d_hist.p);
     SITE_TRY(hipGetLastError());
+    SITE_TRY(hipEventRecord(c->site_ev[1], c->stream));
     SITE_TRY(hipMemcpyAsync(hist, d_hist.p, n_sites * 16 * 4, hipMemcpyDeviceToHost, c->stream));
     SITE_TRY(hipStreamSynchronize(c->stream));
+    {
+        float t = 0.f;
+        SITE_TRY(hipEventElapsedTime(&t, c->site_ev[0], c->site_ev[1]));
+        c->site_ms = t;
+        // 4-bit bases + per-read pos/mapq/offsets + CIGAR words read, the sites' positions /
+        // indices read and their 16 counters written
+        c->site_bytes = (nbase + 1) / 2 + n * (4 + 1 + 4 + 8) + ncig * 4 + (uint64_t)pos0.size() * 8 + (uint64_t)n_sites * 64;
+    }
 #undef SITE_TRY
     cleanup();
+    return CL_OK;
+}
+
+cl_status cl_site_pileup_stats(cl_ctx *c, double *kernel_ms, uint64_t *bytes)
+{
+    if (!c) return CL_ERR_INVALID;
+    if (kernel_ms) *kernel_ms = c->site_ms;
+    if (bytes) *bytes = c->site_bytes;
     return CL_OK;
 }
 

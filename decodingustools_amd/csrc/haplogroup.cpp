@@ -735,19 +735,20 @@ static int dut_find_branch_files_impl(const char *bam_path, const char *fasta_pa
         char terr[512] = {0};
         int trc = CL_OK, crc = CL_OK;
         cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};
-        std::thread tt = dut::spawn_or_run([&]() {
+        dut::Thread tt = dut::spawn_or_run([&]() {
             tree = dut_tree_load(tree_json_path, provider, tree_type, terr, sizeof(terr));
             if (!tree) { trc = CL_ERR_INVALID; return; }
             trc = dut_tree_collect_sites(tree, build, chrom, &sites, &rel, &n_sites);
             if (trc != CL_OK) snprintf(terr, sizeof(terr), "collect_snps failed");
         });
-        std::thread ct = dut::spawn_or_run([&]() { crc = cl_create(&opt, device_id, nullptr, &ctx); });
+        dut::Thread ct = dut::spawn_or_run([&]() { crc = cl_create(&opt, device_id, nullptr, &ctx); });
         dut_records rec; const uint64_t *seq_off = nullptr; const uint8_t *seq4 = nullptr;
         const int brc = dut_bam_read_contig(bam, tid, &rec, &seq_off, &seq4);
         const uint8_t *bases = nullptr; uint64_t blen = 0;
-        dut_fasta_fetch(fa, chrom, &bases, &blen);
+        const int frc = dut_fasta_fetch(fa, chrom, &bases, &blen);       // fetch_seq(..)?, caller.rs:110
         if (tt.joinable()) tt.join();
         if (ct.joinable()) ct.join();
+        if (frc != CL_OK) { set_err(err, err_len, dut_fasta_error(fa)); rc = frc; goto out; }
         if (trc != CL_OK) { set_err(err, err_len, terr); rc = trc; goto out; }
         if (brc != CL_OK) { set_err(err, err_len, dut_bam_error(bam)); rc = brc; goto out; }
         if (crc != CL_OK) { set_err(err, err_len, "no usable HIP device (the engine has no CPU fallback)"); rc = crc; goto out; }

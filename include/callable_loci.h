@@ -152,8 +152,9 @@ cl_status cl_set_profiling(cl_ctx *ctx, int on);
  * bounds ride in the prep launch: their time is part of CL_K_PREP and CL_K_BOUNDS reads 0. */
 cl_status cl_get_kernel_ms(cl_ctx *ctx, double ms[CL_K_COUNT], uint64_t *n_runs);
 cl_status cl_reset_kernel_ms(cl_ctx *ctx);
-/* Bytes of the resident inputs the pileup kernel must read at least once and of the state
- * array it writes (the algorithmic traffic of one cl_contig_run). */
+/* Bytes of the resident inputs the pileup kernel must read at least once (quality bytes, per-read fields, CIGAR
+ * words, reference bases) and of the intervals it leaves behind (12 bytes each; the per-position counters and
+ * states never reach HBM): the algorithmic traffic of one cl_contig_run. */
 cl_status cl_contig_bytes(cl_ctx *ctx, uint64_t *input_bytes, uint64_t *output_bytes);
 
 /* ---- test hooks ------------------------------------------------------------------------- */
@@ -178,6 +179,11 @@ typedef struct cl_site_tile {
 cl_status cl_site_pileup(cl_ctx *ctx, uint8_t min_quality, uint32_t contig_len,
                          uint64_t ref_len, const cl_site_tile *tile,
                          const uint32_t *sites, size_t n_sites, uint32_t *hist);
+
+/* Measurement: duration of the last cl_site_pileup's kernel (HIP events on the context's stream, milliseconds)
+ * and its algorithmic bytes (4-bit bases, per-read fields and CIGAR words read, the sites'
+ * counters written). */
+cl_status cl_site_pileup_stats(cl_ctx *ctx, double *kernel_ms, uint64_t *bytes);
 
 #ifdef __cplusplus
 }

@@ -48,12 +48,16 @@ typedef int (*dut_bam_sample_fn)(void *ud, uint64_t index, uint16_t flag, uint32
                                  const uint8_t *qname, size_t qname_len, int32_t tlen);
 int dut_bam_sample(dut_bam *b, dut_bam_sample_fn fn, void *ud);
 
-/* FASTA with a .fai beside it (faidx).  NULL on failure. */
+/* FASTA with a faidx index (faidx::Reader::from_path, api/coverage.rs:73): the .fai beside the file is read and
+ * validated, or built (and written there when possible) when it is missing.  NULL on failure. */
 dut_fasta *dut_fasta_open(const char *path, char *err, size_t err_len);
 void dut_fasta_close(dut_fasta *f);
-/* The bases of one sequence, case preserved, reader-owned until the next call.  *len = 0 when the
- * name is unknown (every base then reads as 'N', mod.rs:79-80). */
+/* The bases of one sequence, case preserved, reader-owned until the next call (fetch_seq, mod.rs:79).  A name the
+ * index does not hold, a failed seek or read: negative cl_status, text in dut_fasta_error -- the reference fails
+ * the contig there ("Error processing contig: ...").  A file shorter than its index says yields the bases that
+ * are there (the rest reads as 'N', mod.rs:80). */
 int dut_fasta_fetch(dut_fasta *f, const char *name, const uint8_t **bases, uint64_t *len);
+const char *dut_fasta_error(const dut_fasta *f);
 
 /* `coverage <bam> -r <fasta> -o <bed> -s <html> [-L contig]...` on one GPU: BamStats over the first
  * 10000 records, then per selected contig (ascending tid) read, admit, run the engine, append BED

@@ -32,7 +32,8 @@ pub fn process_single_contig(bam: &mut bam::IndexedReader, fasta: &mut faidx::Re
         if rec.cigar().end_pos() > rec.pos() { names.insert(rec.qname().to_vec()); }
         soa.push(rec.pos() as i32, rec.mapq(), rec.raw_cigar(), rec.qual());
     }
-    let reference = fasta.fetch_seq(contig, 0, contig_len as usize - 1)?;   // one fetch, not one per base
+    // one fetch, not one per base; a zero-length contig (nothing to classify) fetches nothing
+    let reference = if contig_len == 0 { Vec::new() } else { fasta.fetch_seq(contig, 0, contig_len as usize - 1)? };
 
     unsafe {
         check(gpu, cl_contig_begin(gpu.ctx, tid as i32, contig_len as u32, reference.as_ptr(), reference.len() as u64))?;

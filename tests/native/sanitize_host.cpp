@@ -5,10 +5,12 @@
 #include "../../include/dut_coverage.h"
 #include "../../include/dut_haplogroup.h"
 #include "../../include/dut_report.h"
+#include "../../decodingustools_amd/csrc/host_parallel.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -80,6 +82,19 @@ int main(int argc, char **argv)
         }
         dut_free(res); dut_free(calls); dut_free(sites); dut_free(rel);
         dut_tree_free(t);
+    }
+    // an allocation failure inside a parallel loop or on a helper thread must come back to the caller as an
+    // exception on ITS thread (the C ABI wrappers turn it into a status), never end a worker (std::terminate)
+    {
+        std::atomic<size_t> done{0};
+        bool caught = false;
+        try {
+            dut::parallel_for(20000, 7, [&](size_t i) { if (i == 4177) throw std::bad_alloc(); done.fetch_add(1); });
+        } catch (const std::bad_alloc &) { caught = true; }
+        int ran = 0;
+        { dut::Thread t = dut::spawn_or_run([&]() { ran = 1; throw std::bad_alloc(); }); }
+        printf("parallel_for: exception %s, helper ran %d, not every index ran %d\n", caught ? "caught" : "LOST", ran, done.load() < 20000 ? 1 : 0);
+        if (!caught) return 3;
     }
     // summary JSON with awkward names
     dut_contig_stats st[2]; memset(st, 0, sizeof(st));

@@ -65,10 +65,59 @@ def test_fasta_fetch(tmp_path):
     write_fasta(path, [("chr1", a), ("chr2", b), ("empty", c)], width=50)
     f = FastaReader(path)
     assert np.array_equal(f.fetch("chr2"), b) and np.array_equal(f.fetch("chr1"), a)
-    assert f.fetch("empty").shape[0] == 0 and f.fetch("nope").shape[0] == 0
+    assert f.fetch("empty").shape[0] == 0
+    with pytest.raises(OSError, match="'nope' not found in the reference FASTA index"):
+        f.fetch("nope")                       # fetch_seq(..)? fails the contig in the reference (mod.rs:79)
+    assert np.array_equal(f.fetch("chr2"), b)   # the reader is usable after a failed fetch
     f.close()
     with pytest.raises(OSError):
         FastaReader(str(tmp_path / "missing.fa"))
+
+
+def test_fasta_index_is_built_when_missing_and_validated_when_present(tmp_path):
+    """faidx::Reader::from_path (api/coverage.rs:73) builds the .fai when there is none; a malformed one is an
+    error at open, not a division by zero or an allocation of a wrapped-around size later."""
+    a = synth.make_reference(1234, 1, lowercase=True)
+    b = synth.make_reference(61, 2)
+    path = str(tmp_path / "r.fa")
+    write_fasta(path, [("chr1", a), ("chr2", b), ("empty", np.zeros(0, np.uint8)), ("tail", b[:50])], width=50)
+    want = open(path + ".fai").read()
+    os.remove(path + ".fai")
+    f = FastaReader(path)
+    assert np.array_equal(f.fetch("chr1"), a) and np.array_equal(f.fetch("chr2"), b) and np.array_equal(f.fetch("tail"), b[:50])
+    assert f.fetch("empty").shape[0] == 0
+    f.close()
+    got = open(path + ".fai").read()
+    rows = lambda t: [r.split("\t") for r in t.splitlines()]
+    assert [r[:3] for r in rows(got)] == [r[:3] for r in rows(want)]
+    assert [r for r in rows(got) if r[1] != "0"] == [r for r in rows(want) if r[1] != "0"]
+    # CRLF line ends and no newline at the end of the file
+    crlf = str(tmp_path / "c.fa")
+    with open(crlf, "wb") as fo:
+        fo.write(b">s1 x\r\nACGTAC\r\nGTNN\r\n>s2\r\nTTTT")
+    f = FastaReader(crlf)
+    assert bytes(f.fetch("s1")) == b"ACGTACGTNN" and bytes(f.fetch("s2")) == b"TTTT"
+    f.close()
+    # lines of different lengths inside a sequence cannot be indexed
+    bad = str(tmp_path / "b.fa")
+    open(bad, "wb").write(b">s\nACGT\nAC\nACGT\n")
+    with pytest.raises(OSError, match="different line length"):
+        FastaReader(bad)
+    # malformed rows of an existing index
+    for row, what in (("chr1\t1234\t16\t0\t51\n", "invalid row"), ("chr1\t1234\t16\t50\t49\n", "invalid row"),
+                      ("chr1\tabc\n", "malformed row")):
+        open(path + ".fai", "w").write(row)
+        with pytest.raises(OSError, match=what):
+            FastaReader(path)
+    # a file shorter than its index says: the bases that are there
+    open(path + ".fai", "w").write(want)
+    size = os.path.getsize(path)
+    with open(path, "r+b") as fo:
+        fo.truncate(size - 80)
+    f = FastaReader(path)
+    assert np.array_equal(f.fetch("chr1"), a)
+    assert f.fetch("tail").shape[0] < 50
+    f.close()
 
 
 def test_not_a_bam(tmp_path):

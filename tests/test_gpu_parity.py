@@ -242,6 +242,42 @@ def test_engine_errors_are_reported():
             Engine(opt, 0).contig_run()
 
 
+def test_a_refused_tile_leaves_the_contig_as_it_was():
+    """cl_push_reads either takes a tile whole or leaves the context untouched: a contig pushed as good tile,
+    refused tile (unsorted / out of range / broken offsets, small and large), good tile gives what the two good
+    tiles alone give."""
+    from decodingustools_amd import EngineError
+    opt = CallableOptions()
+    L = 400_000
+    rec = synth.short_read_contig(L, 30, 99)
+    ref = synth.make_reference(L, 99)
+    h = rec.n // 2                                   # (the engine is compared with itself: no admission needed)
+    a, b = rec.slice(0, h), rec.slice(h, rec.n)
+
+    def push(eng, r):
+        eng.push_reads(r.pos, r.mapq, r.cigar_off, r.cigar, r.qual_off, r.qual)
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref)
+        push(eng, a); push(eng, b)
+        want = eng.contig_finish()
+        eng.contig_begin(0, L, ref)
+        push(eng, a)
+        bad = b.slice(0, b.n)
+        bad.pos = bad.pos.copy(); bad.pos[bad.n // 2] = 0                      # unsorted in the middle of a large tile (> 4 MiB of qualities)
+        assert bad.qual.shape[0] > (4 << 20)
+        with pytest.raises(EngineError):
+            push(eng, bad)
+        with pytest.raises(EngineError):                                      # starts before the previous tile ends
+            push(eng, a.slice(0, 10))
+        with pytest.raises(EngineError):                                      # outside the contig
+            eng.push_reads([L], [60], [0, 1], [5 << 4], [0, 5], np.full(5, 30, np.uint8))
+        with pytest.raises(EngineError):                                      # decreasing offsets
+            eng.push_reads([L - 10, L - 9], [60, 60], [0, 2, 1], [5 << 4, 5 << 4], [0, 5, 10], np.full(10, 30, np.uint8))
+        push(eng, b)
+        got = eng.contig_finish()
+    assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
+
+
 @pytest.mark.parametrize("case", KATS["site_cases"], ids=[c["name"] for c in KATS["site_cases"]])
 def test_site_kats_on_gpu(case):
     rec = ContigRecords.from_reads([tuple(r) for r in case["reads"]])

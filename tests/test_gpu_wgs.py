@@ -89,6 +89,7 @@ def test_whole_genome_25_contigs_full_length_one_engine(tmp_path):
             _property_checks(name, L, rec, ref, opt, acc, n_names, st, counts, res.intervals)
             n_iv += res.intervals.shape[0]
             total += L
+            print(f"[wgs test] {name}: {L} bp, {rec.n} reads, {res.intervals.shape[0]} runs ok", file=sys.stderr, flush=True)
             if name in ("chr1", "chrM"):
                 raw, qc, low, state = eng.debug_depths(L)
                 assert st.summed_coverage == int(raw.astype(np.int64).sum()) and st.n_covered_bases == int(np.count_nonzero(raw))

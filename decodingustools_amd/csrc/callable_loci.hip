@@ -116,6 +116,9 @@ struct cl_ctx {
     // reads whose reference span exceeds kWideSpan (ascending read index = ascending position)
     std::vector<uint32_t> h_wide_idx;
     std::vector<int32_t> h_wide_pos;
+    std::vector<uint32_t> h_long_list;   // reads with more than kLongOps CIGAR operations (k_read_prep_long's work list)
+    uint32_t n_long = 0;
+    uint32_t bounds_err = 0;             // kErrRange raised by the window bounds (reported by cl_contig_collect)
     uint32_t span_n = 0, span_w = 0; // longest span among the ordinary / the wide reads
     uint32_t n_wide = 0;
 
@@ -128,6 +131,7 @@ struct cl_ctx {
     DevBuf<uint8_t> d_qual;
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
+    DevBuf<ReadRec> d_rec;           // n + 1 packed records for the short-read form of k_pileup
     DevBuf<uint32_t> d_win_off, d_wide_idx;
     DevBuf<WinMeta> d_win;
     DevBuf<int32_t> d_wide_pos;
@@ -138,7 +142,7 @@ struct cl_ctx {
     DevBuf<WinPartial> d_winpart;
     DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
-    DevBuf<uint32_t> d_errflag;        // [0] error bits of window_bounds, [1] number of long reads
+    DevBuf<uint32_t> d_errflag;        // [0] error bits raised by the kernels of a run, [1] unused
     DevBuf<uint32_t> d_long_list, d_ck_x, d_ck_y;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
@@ -183,7 +187,7 @@ cl_status fail(cl_ctx *c, cl_status s, const std::string &m)
                         std::string(#call) + ": " + hipGetErrorString(e__));                 \
     } while (0)
 
-// constants of the byte-parallel quality threshold (kernels.hip.h qual_ge)
+// constants of the byte-parallel threshold test (kernels.hip.h swar_ge7)
 void make_ge_consts(uint8_t T, uint32_t &ge_add, uint32_t &ge_or, uint32_t &ge_and)
 {
     uint32_t add;
@@ -237,6 +241,31 @@ cl_status harvest_events(cl_ctx *c)
     return CL_OK;
 }
 
+// which form of k_pileup a resident contig gets: by its shape (CL_FORCE_LONG: timing experiments)
+struct Variant { bool lng, lng4; };
+Variant pick_variant(const cl_ctx *c)
+{
+    Variant v;
+    // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel forms ...
+    v.lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
+    // ... with short runs (operations average < 56 bases -- the measured crossover of the two
+    // variants lies between 50 and 70): four operations per lane, block-parallel
+    v.lng4 = v.lng && c->n_qual < 56ull * c->n_cigar;
+    if (const char *fl = getenv("CL_FORCE_LONG")) {
+        const int f = atoi(fl);
+        v.lng = f != 0; v.lng4 = f == 4;
+    }
+    return v;
+}
+
+Reads device_reads(const cl_ctx *c)
+{
+    Reads R;
+    R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
+    R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
+    return R;
+}
+
 // allocate everything that depends on extent
 cl_status size_for_extent(cl_ctx *c, uint32_t extent)
 {
@@ -259,30 +288,52 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, hipMemsetAsync(c->d_ref.p, 'N', padded + 16, c->stream));
     const size_t nref = std::min<size_t>(c->h_ref.size(), padded);
     if (nref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.p, c->h_ref.data(), nref, hipMemcpyHostToDevice, c->stream));
+    // the windows' candidate ranges: an index of the resident reads for this extent (binary searches over the sorted
+    // positions), built here once instead of in every run
+    if (c->n_win) {
+        BoundsArgs B;
+        B.span_n = c->span_n; B.span_w = c->span_w; B.wide_pos = c->d_wide_pos.p; B.wide_idx = c->d_wide_idx.p;
+        B.n_wide = c->n_wide; B.T = kT; B.n_win = c->n_win;
+        B.win = c->d_win.p; B.err_flag = c->d_errflag.p;
+        hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, device_reads(c), B);
+        HIP_TRY(c, hipGetLastError());
+    }
+    uint32_t flags[2] = {0, 0};
+    HIP_TRY(c, hipMemcpyAsync(flags, c->d_errflag.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // a window with more candidates than the 16-bit counters / differences hold: the 32-bit form from the start
+    if (flags[0] & kNeedDeep) c->deep = true;
+    c->bounds_err = flags[0] & kErrRange;
     return CL_OK;
+}
+
+// run lists -> intervals, one wave per window; the extra last workgroup reduces the summary (the read partials it
+// adds: k_read_prep's blocks for the long-read forms, k_read_prep_long's when there are such reads)
+void launch_rle(cl_ctx *c)
+{
+    const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
+    const Variant vr = pick_variant(c);
+    const PrepPartial *parts = vr.lng ? c->d_prep.p : c->d_prep.p + kPrepBlocks;
+    const uint32_t n_parts = (vr.lng ? (uint32_t)kPrepBlocks : 0u) + (c->n_long ? (uint32_t)kLongBlocks : 0u);
+    hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
+                       c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
+                       parts, n_parts, c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
+                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
 }
 
 template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
 {
     const uint32_t grid = a.n_win8 * 8u;
     if (grid == 0) return;
-    // the byte-parallel threshold test has a shorter form when min_base_quality <= 128;
-    // the 32-bit counter variant is used only after window_bounds asked for it (kNeedDeep)
-    const bool orf = c->opt.min_base_quality <= 128;
-    // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel variant
-    bool lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
-    // ... with short runs (operations average < 56 bases -- the measured crossover of the two
-    // variants lies between 50 and 70): four operations per lane, block-parallel
-    bool lng4 = lng && c->n_qual < 56ull * c->n_cigar;
-    if (const char *fl = getenv("CL_FORCE_LONG")) {               // timing experiments: pick the variant by hand
-        const int v = atoi(fl);
-        lng = v != 0; lng4 = v == 4;
-    }
-#define CL_LAUNCH(ORF_, DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, ORF_, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
-#define CL_LAUNCH_L(ORF_, DEEP_) do { if (lng4) CL_LAUNCH(ORF_, DEEP_, 4); else if (lng) CL_LAUNCH(ORF_, DEEP_, 1); else CL_LAUNCH(ORF_, DEEP_, 0); } while (0)
-    if (!c->deep) { if (orf) CL_LAUNCH_L(true, false); else CL_LAUNCH_L(false, false); }
-    else { if (orf) CL_LAUNCH_L(true, true); else CL_LAUNCH_L(false, true); }
+    // (the ORF template parameter once selected a shorter threshold test for min_base_quality <= 128; one form
+    // serves every threshold now and only ORF = true is instantiated)
+    const Variant vr = pick_variant(c);
+    const bool lng = vr.lng, lng4 = vr.lng4;
+#define CL_LAUNCH(DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
+#define CL_LAUNCH_L(DEEP_) do { if (lng4) CL_LAUNCH(DEEP_, 4); else if (lng) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
+    // the 32-bit counter variant is used only when the window bounds asked for it (kNeedDeep)
+    if (!c->deep) CL_LAUNCH_L(false); else CL_LAUNCH_L(true);
 #undef CL_LAUNCH_L
 #undef CL_LAUNCH
 }
@@ -297,27 +348,21 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
         if (s != CL_OK) return s;
     }
     hipEvent_t *ev = c->ev[c->ev_pending < cl_ctx::kEvSets ? c->ev_pending : 0];
-    Reads R;
-    R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
-    R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
+    const Reads R = device_reads(c);
+    const Variant vr = pick_variant(c);
 
     // d_errflag is zero here: cleared at upload, and by the summary workgroup at the end of every run
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    // the window bounds (binary searches, latency bound) ride in the first workgroups of the prep launch
-    BoundsArgs B;
-    B.span_n = c->span_n; B.span_w = c->span_w; B.wide_pos = c->d_wide_pos.p; B.wide_idx = c->d_wide_idx.p;
-    B.n_wide = c->n_wide; B.T = kT; B.n_win = c->n_win;
-    B.win = c->d_win.p; B.err_flag = c->d_errflag.p;
-    B.n_blocks = (c->n_win + kBlock - 1) / kBlock;
-    hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks + B.n_blocks), dim3(kBlock), 0, c->stream, R, c->dopt,
-                       c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p, B);
-    if (c->has_long)
+    // long-read forms: every read's end and separable sums come from k_read_prep; the short-read form of k_pileup
+    // walks its reads' whole CIGARs itself.  Reads with more than kLongOps operations: k_read_prep_long either way.
+    if (vr.lng)
+        hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt, c->d_end.p, c->d_prep.p);
+    if (c->n_long)
         hipLaunchKernelGGL(k_read_prep_long, dim3(kLongBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
-                           c->d_end.p, c->d_prep.p, c->d_errflag.p + 1, c->d_long_list.p, c->d_ck_x.p, c->d_ck_y.p);
-    const uint32_t n_parts = c->has_long ? (uint32_t)kPrepParts : (uint32_t)kPrepBlocks;
+                           c->d_end.p, c->d_prep.p, c->n_long, c->d_long_list.p, c->d_ck_x.p, c->d_ck_y.p);
     if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     PileupArgs a;
-    a.R = R; a.o = c->dopt; a.end = c->d_end.p; a.win = c->d_win.p;
+    a.R = R; a.o = c->dopt; a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
     a.wide_idx = c->d_wide_idx.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
@@ -336,11 +381,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (n_fin)
         hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_first_state.p,
                            c->d_last_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
-    // run lists -> intervals, one wave per window; the extra last workgroup reduces the summary
-    hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
-                       c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
-                       c->d_prep.p, n_parts, c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
-                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+    launch_rle(c);
     if (prof) {
         HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         c->ev_pending += 1;
@@ -383,7 +424,9 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     o.min_depth = opt->min_depth; o.max_depth = opt->max_depth; o.min_mapq = opt->min_mapping_quality;
     o.min_depth_for_low_mapq = opt->min_depth_for_low_mapq; o.max_low_mapq = opt->max_low_mapq;
     o.max_low_mapq_fraction = opt->max_low_mapq_fraction;
-    make_ge_consts(opt->min_base_quality, o.ge_add, o.ge_or, o.ge_and);
+    // pass_bytes: per byte (x + k + c) >> 1 has bit 7 set iff x >= min_base_quality
+    o.ge_k = (opt->min_base_quality == 0 ? 255u : 256u - opt->min_base_quality) * 0x01010101u;
+    o.ge_c = opt->min_base_quality == 0 ? 0x01010101u : 0u;
     o.md_all = opt->min_depth > 255 ? 1u : 0u;
     make_ge_consts((uint8_t)(opt->min_depth > 255 ? 255 : opt->min_depth), o.md_add, o.md_or, o.md_and);
     o.xd_on = (opt->max_depth >= 1 && opt->max_depth <= 254) ? 1u : 0u;
@@ -404,7 +447,7 @@ void cl_destroy(cl_ctx *c)
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
-    c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release();
+    c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
     c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
@@ -435,6 +478,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->h_iv.clear();
     c->q_dev = 0;
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
+    c->h_long_list.clear(); c->n_long = 0; c->bounds_err = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -537,7 +581,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     //      k_read_prep computes as end - pos): the longest ordinary span bounds every window's candidate
     //      range, reads wider than kWideSpan get their own list.  In chunks, on all host threads. ----
     const size_t grain = 65536, nchunk = (n + grain - 1) / grain;
-    struct Chunk { int bad = 0; bool has_long = false; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide; };
+    struct Chunk { int bad = 0; bool has_long = false; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide, longs; };
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
     dut::parallel_for(nchunk, 1, [&](size_t k) {
@@ -550,7 +594,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             else if (p < last) { if (!o.bad) o.bad = 2; }
             last = p;
             if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i]) { if (!o.bad) o.bad = 3; continue; }
-            if (t->cigar_off[i + 1] - t->cigar_off[i] > kLongOps) o.has_long = true;
+            if (t->cigar_off[i + 1] - t->cigar_off[i] > kLongOps) { o.has_long = true; o.longs.push_back((uint32_t)i); }
             if (t->cigar_off[i] < cig0 || t->cigar_off[i + 1] > cig0 + ncig) { if (!o.bad) o.bad = 3; continue; }
             unsigned long long l = 0;
             for (uint32_t q = t->cigar_off[i]; q < t->cigar_off[i + 1]; ++q) {
@@ -572,22 +616,23 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     // ---- staging of the small arrays (offsets rebased onto the contig's); undone if anything below fails, so that
     //      a refused tile leaves the context as it was ----
     struct Undo {
-        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
+        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide, n_long; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
         ~Undo()
         {
             if (!armed) return;
             c->h_pos.resize(n_pos); c->h_mapq.resize(n_pos); c->h_cigar.resize(n_cig); c->h_qual.resize(n_qual);
             c->h_cigar_off.resize(n_pos + 1); c->h_qual_off.resize(n_pos + 1);
-            c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide);
+            c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide); c->h_long_list.resize(n_long);
             c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end;
         }
-    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->has_long, c->span_n, c->span_w, c->host_max_end};
+    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->h_long_list.size(), c->has_long, c->span_n, c->span_w, c->host_max_end};
     try {
         for (const Chunk &o : ch) {
             if (o.has_long) c->has_long = true;
             c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
             c->host_max_end = std::max(c->host_max_end, o.max_end);
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
+            for (uint32_t i : o.longs) c->h_long_list.push_back((uint32_t)(rbase + i));
         }
         c->h_pos.insert(c->h_pos.end(), t->pos, t->pos + n);
         c->h_mapq.insert(c->h_mapq.end(), t->mapq, t->mapq + n);
@@ -640,7 +685,21 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
     HIP_TRY(c, c->d_qual_off.reserve(n + 1));
     HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));          // k_read_prep loads four words at a read's first op
-    HIP_TRY(c, c->d_long_list.reserve(n + 1));
+    c->n_long = (uint32_t)c->h_long_list.size();
+    HIP_TRY(c, c->d_long_list.reserve(c->n_long + 1));
+    HIP_TRY(c, c->d_rec.reserve(n + 1));
+    // the packed records of the short-read form: pos, CIGAR offset, low half of the quality offset, mapq and the
+    // two lengths when they fit their fields (else the marker: the kernel takes them from the next record)
+    std::vector<ReadRec> h_rec(n + 1);
+    dut::parallel_for(n, 262144, [&](size_t i) {
+        const uint32_t nc = c->h_cigar_off[i + 1] - c->h_cigar_off[i];
+        const unsigned long long ql = c->h_qual_off[i + 1] - c->h_qual_off[i];
+        ReadRec r;
+        r.pos = c->h_pos[i]; r.cigar_off = c->h_cigar_off[i]; r.qual_lo = (uint32_t)c->h_qual_off[i];
+        r.meta = (uint32_t)c->h_mapq[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<unsigned long long>(ql, 0xFFFFull) << 16);
+        h_rec[i] = r;
+    });
+    h_rec[n].pos = 0; h_rec[n].cigar_off = c->h_cigar_off[n]; h_rec[n].qual_lo = (uint32_t)c->h_qual_off[n]; h_rec[n].meta = 0;
     HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
@@ -651,6 +710,8 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, hipMemcpyAsync(c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
     if (c->n_cigar) HIP_TRY(c, hipMemcpyAsync(c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->d_rec.p, h_rec.data(), (n + 1) * sizeof(ReadRec), hipMemcpyHostToDevice, c->stream));
+    if (c->n_long) HIP_TRY(c, hipMemcpyAsync(c->d_long_list.p, c->h_long_list.data(), (size_t)c->n_long * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     c->n_wide = (uint32_t)c->h_wide_idx.size();
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
@@ -663,6 +724,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->ref_len_dev = UINT64_MAX;            // force the reference to be re-laid out
+    c->deep = false;                        // size_for_extent decides (the window bounds know)
     // a read overhanging the contig end makes the reference walk (and classify as REF_N, mod.rs:100-101) positions
     // up to its end: the extent is known from the spans computed at cl_push_reads
     cl_status s = size_for_extent(c, (uint32_t)std::max<uint64_t>(c->contig_len, c->host_max_end));
@@ -676,7 +738,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     std::vector<uint8_t>().swap(c->h_qual);
     std::vector<uint32_t>().swap(c->h_cigar_off);
     std::vector<unsigned long long>().swap(c->h_qual_off);
-    c->uploaded = true; c->ran = false; c->deep = false;
+    c->uploaded = true; c->ran = false;
     return CL_OK;
 }
 
@@ -708,7 +770,7 @@ cl_status cl_sync(cl_ctx *c)
 
 static cl_status check_summary(cl_ctx *c)
 {
-    if (c->h_sum.err & kErrRange) return fail(c, CL_ERR_RANGE, "a read ends beyond the engine's 32-bit coordinate range");
+    if ((c->h_sum.err | c->bounds_err) & kErrRange) return fail(c, CL_ERR_RANGE, "a read ends beyond the engine's 32-bit coordinate range");
     if (c->h_sum.err & kErrCigar)
         return fail(c, CL_ERR_CIGAR, "malformed CIGAR: zero-length reference-consuming operation, or a single non-match "
                                      "operation on a read that spans reference positions (undefined in htslib's pileup)");
@@ -756,14 +818,7 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
         }
         if (c->h_sum.n_intervals > c->d_iv.cap) {
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
-            {
-                const uint32_t n_fin2 = (c->n_win + kFinBlock - 1) / kFinBlock;
-                const uint32_t n_parts2 = c->has_long ? (uint32_t)kPrepParts : (uint32_t)kPrepBlocks;
-                hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
-                                   c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin2,
-                                   c->d_prep.p, n_parts2, c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
-                                   (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
-            }
+            launch_rle(c);
             HIP_TRY(c, hipGetLastError());
         }
         converged = true;
@@ -844,9 +899,12 @@ cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_byt
     // what one run must read at least once: quality bytes, per-read pos/mapq/offsets, CIGAR
     // words, reference bytes; what it must write: the intervals (12 bytes each; the per-position
     // counters and states never reach HBM)
+    // per read: one packed 16-byte record in the short-read form; pos 4 + mapq 1 + CIGAR offset 4 + quality offset 8 in
+    // the long-read forms
     const uint64_t n = c->n_reads;
+    const uint64_t per_read = pick_variant(c).lng ? (4 + 1 + 4 + 8) : sizeof(ReadRec);
     if (input_bytes)
-        *input_bytes = c->n_qual + n * (4 + 1 + 4 + 8) + c->n_cigar * 4 + (uint64_t)c->extent;
+        *input_bytes = c->n_qual + n * per_read + c->n_cigar * 4 + (uint64_t)c->extent;
     if (output_bytes) *output_bytes = 12ull * c->h_sum.n_intervals;
     return CL_OK;
 }

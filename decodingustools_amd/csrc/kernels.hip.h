@@ -2,9 +2,13 @@
 //
 // Data flow of one contig (all arrays resident in HBM, layouts in DESIGN.md section 3):
 //
-//   k_read_prep      per read: CIGAR walk -> end[r]; block partials of the per-read separable
-//                    sums (contig_profiler.rs:74,79-82 via SURVEY 8a-7), max span, max end
-//   window_bounds    per window of T reference positions: [lo,hi) range of reads that can touch it
+//   k_window_bounds  (once per upload / extent: an index of the resident layout, like the offsets) per window of
+//                    T reference positions the [lo,hi) range of reads that can touch it
+//   k_read_prep      contigs of long-read shape only (the LONG variants of k_pileup): per read the CIGAR walk
+//                    -> end[r] and block partials of the per-read separable sums (contig_profiler.rs:74,79-82 via
+//                    SURVEY 8a-7); for short-read contigs k_pileup does this itself (the window that holds a
+//                    read's start owns its sums) and only reads with more than kLongOps operations go through
+//                    k_read_prep_long (end[r] + CIGAR checkpoints)
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
 //                    (callable_profiler.rs:100-116) and reduced to the window's run list (the
@@ -51,6 +55,8 @@ struct WinPartial {
     unsigned long long n_cov;        // positions with raw_depth > 0
     unsigned long long sum_qc;       // -> quality_bases
     unsigned long long sum_q;        // -> summed_baseq
+    unsigned long long sum_reflen;   // reads that START in this window: sum of reference spans (-> summed_coverage) ...
+    unsigned long long sum_mapq_reflen;   // ... and of mapq * span over those with mapq >= min (-> summed_mapq); short-read form only
     uint32_t n_inner;                // run boundaries strictly inside the window
     uint32_t max_raw;
 };
@@ -80,8 +86,8 @@ struct Opts {
     uint32_t min_depth_for_low_mapq;
     uint32_t max_low_mapq;
     double   max_low_mapq_fraction;
-    // byte-parallel "quality >= min_base_quality" constants (see qual_ge)
-    uint32_t ge_add, ge_or, ge_and;
+    // byte-parallel "quality >= min_base_quality" constants (see pass_bytes)
+    uint32_t ge_k, ge_c;
     // the same for "qc_depth >= min_depth" (md_all: min_depth > 255, every byte-sized count is below)
     // and "qc_depth >= max_depth + 1" (xd_on: max_depth in 1..254), used by the byte-parallel final phase
     uint32_t md_add, md_or, md_and, md_all;
@@ -96,6 +102,17 @@ struct Reads {
     const unsigned long long *qual_off;
     const uint8_t  *qual;       // points kQualPad bytes into the allocation
     uint32_t n;
+};
+
+// One read as the short-read form of k_pileup takes it: one aligned 16-byte load instead of five scattered ones.
+// Built on the host at upload from the pushed arrays.  meta = mapq | n_cigar << 8 | qual_len << 16, where n_cigar
+// 255 / qual_len 0xFFFF mean "take it from the next record's offsets" (rec[n] is a sentinel holding the totals).
+// qual_lo = the low 32 bits of the read's quality offset: a window's candidates lie within 2^32 bytes of its q0.
+struct __attribute__((aligned(16))) ReadRec {
+    int32_t  pos;
+    uint32_t cigar_off;
+    uint32_t qual_lo;
+    uint32_t meta;
 };
 
 // 16 bytes at any byte address (compiles to one unaligned dwordx4 load)
@@ -202,7 +219,6 @@ struct BoundsArgs {
     uint32_t n_wide, T, n_win;
     WinMeta *win;
     uint32_t *err_flag;
-    uint32_t n_blocks;                 // the first n_blocks workgroups of the k_read_prep launch do the bounds
 };
 
 __device__ __forceinline__ void window_bounds(const Reads &R, const BoundsArgs &B, uint32_t w)
@@ -230,6 +246,13 @@ __device__ __forceinline__ void window_bounds(const Reads &R, const BoundsArgs &
     if ((hi - lo) + wn > 32767u) atomicOr(err_flag, kNeedDeep);
 }
 
+// The windows' candidate ranges depend on the resident reads and on the extent only: computed once per upload
+// (and again when the extent grows), not per run.
+__global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, BoundsArgs B)
+{
+    window_bounds(R, B, blockIdx.x * kBlock + threadIdx.x);
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_read_prep: one thread per read (grid-stride).
 //   end[r] = pos + bam_cigar2rlen  (the pileup node span)
@@ -238,14 +261,9 @@ __device__ __forceinline__ void window_bounds(const Reads &R, const BoundsArgs &
 // CIGAR shapes htslib's resolve_cigar2 asserts on / indexes out of bounds for are flagged.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t *__restrict__ end_out,
-                                                       PrepPartial *__restrict__ part,
-                                                       uint32_t *__restrict__ long_cnt,
-                                                       uint32_t *__restrict__ long_list, BoundsArgs B)
+                                                       PrepPartial *__restrict__ part)
 {
-    // (measured on one box: bounds as its own kernel after this one 0.489 ms per step, as the last
-    // workgroups 0.488, as the first 0.479)
-    if (blockIdx.x < B.n_blocks) { window_bounds(R, B, blockIdx.x * kBlock + threadIdx.x); return; }
-    const uint32_t bid = blockIdx.x - B.n_blocks;
+    const uint32_t bid = blockIdx.x;
     __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
     __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
     unsigned long long sum_len = 0, sum_mq = 0;
@@ -273,10 +291,7 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
 #pragma unroll
         for (int i = 0; i < U; ++i) {
             if (!in[i]) continue;
-            if (k1[i] - k0[i] > kLongOps) {             // left to k_read_prep_long
-                long_list[atomicAdd(long_cnt, 1u)] = r0 + i * stride;
-                continue;
-            }
+            if (k1[i] - k0[i] > kLongOps) continue;     // left to k_read_prep_long (the host listed it at cl_push_reads)
             unsigned long long reflen = 0;
             for (uint32_t k = k0[i]; k < k1[i]; ++k) {
                 const uint32_t d = k - k0[i];
@@ -324,7 +339,7 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_read_prep_long: the reads k_read_prep diverted (more than kLongOps CIGAR ops, e.g. long reads
+// k_read_prep_long: the reads with more than kLongOps CIGAR ops (listed by the host at cl_push_reads; e.g. long reads
 // with an indel every ~15 bases), one wave per read.  The wave scans the CIGAR 256 ops at a time
 // (four consecutive ops per lane, wave prefix sums of the reference / query advance) and stores, for
 // every op index k that is a multiple of 64 inside the read, the reference and query position
@@ -333,14 +348,13 @@ __global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t 
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint32_t *__restrict__ end_out,
                                                             PrepPartial *__restrict__ part,
-                                                            const uint32_t *__restrict__ long_cnt,
+                                                            uint32_t n_long,
                                                             const uint32_t *__restrict__ long_list,
                                                             uint32_t *__restrict__ ck_x, uint32_t *__restrict__ ck_y)
 {
     __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
     __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    const uint32_t n_long = *long_cnt;
     unsigned long long sum_len = 0, sum_mq = 0;          // meaningful in lane 0
     uint32_t max_span = 0, max_end = 0, err = 0;
     for (uint32_t i = blockIdx.x * (kBlock / 64) + wv; i < n_long; i += gridDim.x * (kBlock / 64)) {
@@ -417,20 +431,14 @@ __global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint
 }
 
 // ---------------------------------------------------------------------------------------------
-// byte-parallel threshold test.  x holds 4 quality bytes; returns 0x80 in each byte with
-// quality >= min_base_quality (mod.rs:33).  Constants from make_ge_consts():
-//   T == 0        : always                   ge_add = 0x80.., OR form
-//   1 <= T <= 128 : hi(x) | (lo7(x) >= T)    ge_add = 128 - T, OR form
-//   T >= 129      : hi(x) & (lo7(x) >= T-128) ge_add = 256 - T, AND form
-// lo7 + ge_add never carries out of its byte (both <= 127 / 128+127 < 256).
+// byte-parallel ">= threshold" on four bytes at once, given the three constants of make_ge_consts()
+// (callable_loci.hip) for a threshold T: 0x80 in each byte >= T.
+//   T == 0        : always                    add = 0x80.., OR form
+//   1 <= T <= 128 : hi(x) | (lo7(x) >= T)     add = 128 - T, OR form
+//   T >= 129      : hi(x) & (lo7(x) >= T-128) add = 256 - T, AND form
+// lo7 + add never carries out of its byte (both <= 127 / 128+127 < 256).  Used by the final phase for
+// "qc_depth >= min_depth" / "> max_depth"; the quality threshold itself is pass_bytes() below.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t qual_ge(uint32_t x, const Opts &o)
-{
-    const uint32_t d = (x & 0x7f7f7f7fu) + o.ge_add;
-    return ((d | (x & o.ge_or)) & (x | o.ge_and)) & 0x80808080u;
-}
-
-// the same test for any byte threshold given its three constants: 0x80 per byte >= threshold
 __device__ __forceinline__ uint32_t swar_ge7(uint32_t q, uint32_t add, uint32_t orm, uint32_t andm)
 {
     const uint32_t d = (q & 0x7f7f7f7fu) + add;
@@ -441,7 +449,8 @@ __device__ __forceinline__ uint32_t swar_ge7(uint32_t q, uint32_t add, uint32_t 
 struct PileupArgs {
     Reads R;
     Opts o;
-    const uint32_t *end;          // per read
+    const ReadRec *rec;           // n + 1 packed records (the short-read form reads these instead of R's per-read arrays)
+    const uint32_t *end;          // per read (short-read form: valid for reads with more than kLongOps operations only)
     const WinMeta *win;
     const uint32_t *wide_idx;           // read indices of the wide reads, ascending
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
@@ -499,9 +508,11 @@ struct PileupArgs {
 template <bool ORF>
 __device__ __forceinline__ uint32_t pass_bytes(uint32_t xw, uint32_t vm, const Opts &o)
 {
-    // 0x01 in every byte of xw that is a valid position (vm) and passes the threshold
-    if (ORF) return ((((xw & 0x7f7f7f7fu) + o.ge_add) | xw) >> 7) & vm;
-    return (qual_ge(xw, o) >> 7) & vm;
+    // 0x01 in every byte of xw that is a valid position (vm) and passes the threshold (mod.rs:33).  v_lerp_u8 is a
+    // per-byte (x + k + (c & 1)) >> 1 with a 9-bit sum: with k = 256 - min_base_quality its bit 7 is the carry, i.e.
+    // x >= min_base_quality, for every threshold 1..255 (0: k = 255 and the rounding bit make it always set) -- one
+    // instruction where the masked add needs three (measured: 4.5 against 3 x 2.8 cycles per wave instruction)
+    return (__builtin_amdgcn_lerp(xw, o.ge_k, o.ge_c) >> 7) & vm;
 }
 
 // 8-bit counters, two sets (reads alternate between the sets, a window handled this way is
@@ -609,12 +620,17 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     __shared__ uint8_t s_last[kBlock];
     // per-wave totals: cnt[6], n_cov, sum_qc, sum_q, n_inner.  (Same-address LDS atomics are avoided:
     // hipcc turns them into a scalar loop over the active lanes.)
-    __shared__ unsigned long long s_wtot[kWaves][10];
+    __shared__ unsigned long long s_wtot[kWaves][12];          // [10], [11]: sums of the reads the window owns (LONG = 0)
     // LONG: the live reads of a pass, two entries each: {candidate number, op index, x, y}, {op end, quality offset, quality length, -}
     __shared__ __attribute__((aligned(16))) uint4 s_live[LONG ? 2 * kBlock : 1];
     __shared__ uint32_t s_nlive;
     // LONG = 4: first block number of every live read of the pass (+ the total at [n])
     __shared__ uint32_t s_blk[LONG == 4 ? kBlock + 1 : 1];
+    // LONG = 4: per-wave unit lists, entries {quality offset of the run's window position 0 (+ 16 u = the unit's bytes),
+    // run start (11 bits) | run end - 1 (11) | unit index u (7) | counter set (1) | - | valid (1)}
+    constexpr int kUCap = LONG == 4 ? 352 : 1;     // entries per wave
+    constexpr int kUFlush = 128;                   // a trip leaves fewer than this many entries waiting
+    __shared__ __attribute__((aligned(8))) uint2 s_ul[LONG == 4 ? kWaves : 1][kUCap];
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
     // each XCD one contiguous range of windows so neighbouring windows share its L2.
@@ -684,6 +700,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     const uint32_t ql = lane & 3u, quad = lane >> 2;
     uint2 *list = s_list[wv];
     uint32_t n_keep = 0;                            // list entries carried over from the previous round (< 16)
+    unsigned long long win_len = 0, win_mq = 0;     // LONG = 0: wave-uniform sums over the reads this window owns
     // quads consume list entries [0, n_use): quad q takes entries q*Q .. q*Q+Q-1 (Q = n_use/16 rounded
     // up), i.e. concurrently active quads are Q entries (~4Q reads) apart.  Three units per lane and
     // trip: u, u+4, u+8; a unit past the end is clamped onto the last one and gets an empty mask.
@@ -730,6 +747,38 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         else if (mode8) { if (a.upl == 2u) consume(std::integral_constant<int, 0>{}, I2{}, n_use); else consume(std::integral_constant<int, 0>{}, I3{}, n_use); }
         else consume(std::integral_constant<int, 1>{}, I3{}, n_use);
     };
+    // LONG = 4: the wave's unit list, one entry per lane and four quality loads in flight per lane
+    uint2 *ul = s_ul[LONG == 4 ? wv : 0];
+    uint32_t n_ul = 0;
+    auto consume_units = [&](uint32_t n) {
+        constexpr int UL = 4;
+        if (a.ablate & 4u) return;                 // timing experiments: units located and listed, nothing applied
+        for (uint32_t b0 = 0; b0 < n; b0 += 64u * UL) {
+            uint2 d[UL];
+            Q16 v[UL];
+#pragma unroll
+            for (int j = 0; j < UL; ++j) {
+                const uint32_t idx = b0 + lane + 64u * (uint32_t)j;
+                d[j] = make_uint2((uint32_t)kQualPad, 0u);                   // a lane without an entry loads the window's first bytes
+                if (idx < n) d[j] = ul[idx];
+                __builtin_memcpy(&v[j], qbase + (d[j].x + (((d[j].y >> 22) & 127u) << 4)), 16);
+            }
+#pragma unroll
+            for (int j = 0; j < UL; ++j) {
+                if (d[j].y >> 31) {
+                    const uint32_t u = (d[j].y >> 22) & 127u, srel = d[j].y & 2047u, trel = ((d[j].y >> 11) & 2047u) + 1u;
+                    const uint32_t ps = u << 4;
+                    const uint32_t vs = srel > ps ? srel - ps : 0u;
+                    const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                    const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                    const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                    if (DEEP) sq32 += apply_unit32<ORF>(v[j], vm, u, s_qcw, a.o);
+                    else if (mode8) sq32 += apply_unit8<ORF>(v[j], vm, u, ((d[j].y >> 29) & 1u) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                    else sq32 += apply_unit16<ORF>(v[j], vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                }
+            }
+        }
+    };
     for (uint32_t base = 0; base < ((a.ablate & 2u) ? 0u : n_cand); base += kBlock) {
         const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets
         uint32_t r = lo + (v - wn);
@@ -738,15 +787,69 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         bool live = false;
         uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
         uint32_t nblk = 0, lim0 = 0, k0r = 0;        // LONG = 4
+        unsigned long long own_len = 0, own_mq = 0;  // LONG = 0: separable sums of the reads this window owns (this pass)
         if (v < n_cand) {
-            x = (uint32_t)a.R.pos[r];
-            const uint32_t e = a.end[r], mq = a.R.mapq[r];
-            k = a.R.cigar_off[r];
-            k0r = k;
-            k1 = a.R.cigar_off[r + 1];
-            const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
-            qrel = (uint32_t)(q0 - qwin);
-            qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
+            uint32_t e, mq;
+            bool fetch_cw = true;                    // cw still has to be loaded from cigar[k]
+            if constexpr (LONG == 0) {
+                // ---- short-read form: one packed record per read; the whole CIGAR is walked here once (what
+                //      k_read_prep does for the long-read forms): the read's end, the malformed shapes htslib asserts
+                //      on, and -- in the window that holds the read's start -- its separable sums
+                //      (contig_profiler.rs:74: summed_coverage = sum of spans, summed_mapq over mapq >= min) ----
+                const uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
+                x = rr.x; k = rr.y; mq = rr.w & 255u;
+                qlen = rr.w >> 16;
+                k1 = k + ((rr.w >> 8) & 255u);
+                if (((rr.w >> 8) & 255u) == 255u || qlen == 0xFFFFu) {          // rare: the next record's offsets
+                    const uint4 nx = *reinterpret_cast<const uint4 *>(a.rec + r + 1);
+                    k1 = nx.y; qlen = nx.z - rr.z;
+                }
+                qrel = rr.z - (uint32_t)qwin;
+                k0r = k;
+                const uint32_t n = k1 - k;
+                if (n <= kLongOps) {
+                    Q16 c4;                                      // the first four words (the array is padded)
+                    __builtin_memcpy(&c4, a.R.cigar + k, 16);
+                    unsigned long long reflen = 0;
+                    uint32_t er = 0;
+#pragma unroll
+                    for (uint32_t d = 0; d < 4u; ++d) {
+                        const uint32_t c = d < n ? c4.w[d] : 5u, l = c >> 4;       // beyond the read: H, advances nothing
+                        const bool radv = ((0x18Du >> (c & 15u)) & 1u) != 0u;
+                        reflen += radv ? l : 0u;
+                        if (radv && l == 0u) er |= kErrCigar;                      // zero-length reference-consuming op
+                    }
+                    for (uint32_t kk = k + 4u; kk < k1; ++kk) {                     // few reads have more than four ops
+                        const uint32_t c = a.R.cigar[kk], l = c >> 4;
+                        const bool radv = ((0x18Du >> (c & 15u)) & 1u) != 0u;
+                        reflen += radv ? l : 0u;
+                        if (radv && l == 0u) er |= kErrCigar;
+                    }
+                    // a read that reaches a column with a single non-match op is undefined in htslib
+                    if (reflen > 0 && n == 1u && !op_match(c4.w[0] & 15u)) er |= kErrCigar;
+                    const unsigned long long ee = (unsigned long long)x + reflen;
+                    if (ee > 0xFFFF0000ull) er |= kErrRange;
+                    e = ee > 0xFFFF0000ull ? x : (uint32_t)ee;
+                    if (er) atomicOr(a.err_flag, er);
+                    if (x >= W) {                                // every read starts in exactly one window
+                        own_len = e - x;
+                        own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
+                    }
+                    cw = n ? c4.w[0] : 0u;
+                    fetch_cw = false;
+                } else {
+                    e = a.end[r];                                // k_read_prep_long's (it owns this read's sums too)
+                }
+            } else {
+                x = (uint32_t)a.R.pos[r];
+                e = a.end[r]; mq = a.R.mapq[r];
+                k = a.R.cigar_off[r];
+                k0r = k;
+                k1 = a.R.cigar_off[r + 1];
+                const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
+                qrel = (uint32_t)(q0 - qwin);
+                qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
+            }
             if (e > W) {
                 const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
                 uint32_t ib, vb, ie, ve2;            // word index and addend of the +1 and of the -1
@@ -775,7 +878,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                     k = lo_j << 6; x = a.ck_x[lo_j]; y = a.ck_y[lo_j];
                 }
             }
-            if (!LONG && live) cw = a.R.cigar[k];    // invariant: cw == cigar[k] while live
+            if (!LONG && live && fetch_cw) cw = a.R.cigar[k];    // invariant: cw == cigar[k] while live
             if constexpr (LONG == 4) {
                 // blocks of the read that can touch the window: the one the walk starts in (it ends at the next
                 // multiple of 64 in the contig's operation numbering, where the next checkpoint sits), then one
@@ -795,6 +898,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 }
             }
         }
+        if constexpr (LONG == 0) { win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq); }
         if constexpr (LONG) {
             // ---- long-read shape: CIGAR operations in parallel.  The live reads of the pass are
             //      compacted into s_live; a wave takes a read and 64 of its operations at a time (one
@@ -886,27 +990,12 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                     }
                     const uint32_t ix = dpp_row_incl_scan_u32(tx), iy = dpp_row_incl_scan_u32(ty);
                     uint32_t xs = (cur.d ? cx_c : A.y) + (ix - tx), ys = (cur.d ? cy_c : A.z) + (iy - ty);
-                    auto unit = [&](const Q16 &v, uint32_t u, uint32_t srel, uint32_t trel) {
-                        const uint32_t ps = u << 4;
-                        const uint32_t vs = srel > ps ? srel - ps : 0u;
-                        const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
-                        const uint4 ms = s_mstart[vs], me = s_mend[ve];
-                        const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
-                        if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
-                        else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                        else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                    };
-                    auto run_direct = [&](uint32_t sr, uint32_t tr, uint32_t q) {
-                        const uint32_t qb = q + (uint32_t)kQualPad - sr;
-                        for (uint32_t u = sr >> 4; u <= (tr - 1u) >> 4; ++u) {
-                            Q16 v;
-                            __builtin_memcpy(&v, qbase + (qb + (u << 4)), 16);
-                            unit(v, u, sr, tr);
-                        }
-                    };
-                    // the lane's first two short runs (A, B) are consumed together below; a third or fourth
-                    // (=/X strings) and runs > 64 bases at once
-                    uint32_t a_st = 0, a_q = 0, b_st = 0, b_q = 0, ns = 0;
+                    // Every M/=/X run of the trip, clipped to the window, becomes unit entries -- (run, 16 reference
+                    // positions) pairs -- in the wave's unit list; the list is then consumed one entry per lane, four
+                    // quality loads in flight: every lane busy whatever the runs' lengths, one load latency per trip,
+                    // no run-length dependent control flow.  Runs longer than 64 bases (rare in this shape) go
+                    // through the segment list and the quad loop as before.
+                    uint32_t e_qb[4], e_st[4], nu[4], nl = 0;
 #pragma unroll
                     for (uint32_t j = 0; j < 4u; ++j) {
                         const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
@@ -921,12 +1010,10 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                         const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
                         const bool big = valid && (tr - sr) > 64u;
                         xs = xe; ys += ay[j];
-                        if (valid && !big) {
-                            if (ns == 0u) { a_st = sr | (tr << 16); a_q = q; }
-                            else if (ns == 1u) { b_st = sr | (tr << 16); b_q = q; }
-                            else run_direct(sr, tr, q);
-                            ns += 1u;
-                        }
+                        e_qb[j] = q + (uint32_t)kQualPad - sr;        // + 16 u = the unit's byte offset from qbase
+                        e_st[j] = sr | ((tr - 1u) << 11) | (rset >> 1);       // rset = set << 30 -> bit 29
+                        nu[j] = (valid && !big) ? (((tr - 1u) >> 4) - (sr >> 4) + 1u) : 0u;
+                        nl += nu[j];
                         const unsigned long long bm = __ballot(big);
                         if (bm) {                                    // wave-uniform: long runs go through the list
                             if (big) {
@@ -948,40 +1035,33 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                             if (n_full && lane < n_keep) list[lane] = carry;
                         }
                     }
-                    {   // the first two units of A and of B are requested together (a ~15-base run covers one or two)
-                        const uint32_t a_sr = a_st & 0xFFFFu, a_tr = a_st >> 16, b_sr = b_st & 0xFFFFu, b_tr = b_st >> 16;
-                        const uint32_t a_qb = a_q + (uint32_t)kQualPad - a_sr, b_qb = b_q + (uint32_t)kQualPad - b_sr;
-                        const uint32_t a_u0 = a_sr >> 4, a_u1 = ns >= 1u ? (a_tr - 1u) >> 4 : 0u;
-                        const uint32_t b_u0 = b_sr >> 4, b_u1 = ns >= 2u ? (b_tr - 1u) >> 4 : 0u;
-                        Q16 va0, va1, vb0, vb1;
-                        if (ns >= 1u) {
-                            __builtin_memcpy(&va0, qbase + (a_qb + (a_u0 << 4)), 16);
-                            __builtin_memcpy(&va1, qbase + (a_qb + ((a_u0 + 1u <= a_u1 ? a_u0 + 1u : a_u0) << 4)), 16);
+                    {   // emission: lane l's entries sit at wave index [base, base + nl); a trip that does not fit what is
+                        // left of the list goes in pieces, the list being consumed in between (rare)
+                        const uint32_t inc = dpp_incl_scan_u32(nl);
+                        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+                        const uint32_t base = inc - nl, mx = dpp_wave_max_u32(nl);
+                        uint32_t lo_g = 0;
+                        while (lo_g < tot) {                              // wave-uniform
+                            if (n_ul == (uint32_t)kUCap) { consume_units(n_ul); n_ul = 0; }
+                            const uint32_t room = (uint32_t)kUCap - n_ul;
+                            const uint32_t hi_g = tot < lo_g + room ? tot : lo_g + room;
+                            for (uint32_t i = 0; i < mx; ++i) {
+                                const uint32_t g = base + i;
+                                if (i < nl && g >= lo_g && g < hi_g) {
+                                    uint32_t t = i, qb = e_qb[0], st = e_st[0];
+                                    if (t >= nu[0]) { t -= nu[0]; qb = e_qb[1]; st = e_st[1];
+                                        if (t >= nu[1]) { t -= nu[1]; qb = e_qb[2]; st = e_st[2];
+                                            if (t >= nu[2]) { t -= nu[2]; qb = e_qb[3]; st = e_st[3]; } } }
+                                    ul[n_ul + (g - lo_g)] = make_uint2(qb, st | ((((st & 2047u) >> 4) + t) << 22) | 0x80000000u);
+                                }
+                            }
+                            n_ul += hi_g - lo_g;
+                            lo_g = hi_g;
+                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                            __builtin_amdgcn_wave_barrier();
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                         }
-                        if (ns >= 2u) {
-                            __builtin_memcpy(&vb0, qbase + (b_qb + (b_u0 << 4)), 16);
-                            __builtin_memcpy(&vb1, qbase + (b_qb + ((b_u0 + 1u <= b_u1 ? b_u0 + 1u : b_u0) << 4)), 16);
-                        }
-                        if (ns >= 1u) {
-                            unit(va0, a_u0, a_sr, a_tr);
-                            if (a_u0 + 1u <= a_u1) unit(va1, a_u0 + 1u, a_sr, a_tr);
-                        }
-                        if (ns >= 2u) {
-                            unit(vb0, b_u0, b_sr, b_tr);
-                            if (b_u0 + 1u <= b_u1) unit(vb1, b_u0 + 1u, b_sr, b_tr);
-                        }
-                        // what is left of runs longer than two units (few lanes): one loop for both runs, a lane
-                        // takes A's next unit, then B's
-                        uint32_t ua = ns >= 1u ? a_u0 + 2u : 1u, ub2 = ns >= 2u ? b_u0 + 2u : 1u;
-                        const uint32_t ea = ns >= 1u ? a_u1 : 0u, eb = ns >= 2u ? b_u1 : 0u;
-                        while (ua <= ea || ub2 <= eb) {
-                            const bool fa = ua <= ea;
-                            const uint32_t u = fa ? ua : ub2;
-                            Q16 v;
-                            __builtin_memcpy(&v, qbase + ((fa ? a_qb : b_qb) + (u << 4)), 16);
-                            unit(v, u, fa ? a_sr : b_sr, fa ? a_tr : b_tr);
-                            if (fa) ++ua; else ++ub2;
-                        }
+                        if (n_ul >= (uint32_t)kUFlush) { consume_units(n_ul); n_ul = 0; }
                     }
                     cur = nxt; on = on_n; cw_c = cw_n; cx_c = cx_n; cy_c = cy_n;
                     tb = tbn;
@@ -1201,6 +1281,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         consume_list(n_keep);
         sumq += sq32; sq32 = 0;
     }
+    if constexpr (LONG == 4) {
+        if (n_ul) { consume_units(n_ul); n_ul = 0; sumq += sq32; sq32 = 0; }
+    }
     __syncthreads();
 
     // ---- final phase: depths, low-MAPQ rule, state, counts (8 positions per thread) ----
@@ -1383,6 +1466,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 t[3] = pk[1] & 1023u; t[4] = (pk[1] >> 10) & 1023u; t[5] = pk[1] >> 20;
                 t[6] = pk[2] & 1023u; t[9] = pk[2] >> 10;
                 t[7] = pk[3]; t[8] = pk[4];
+                t[10] = win_len; t[11] = win_mq;
             }
         } else {
             // denser windows: totals may pass 2^32
@@ -1395,6 +1479,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
                 const unsigned long long r = wave_sum_u64(v[c]);
                 if (lane == 0) s_wtot[wv][c] = r;
             }
+            if (lane == 0) { s_wtot[wv][10] = win_len; s_wtot[wv][11] = win_mq; }
         }
         __syncthreads();
         // the window's run list: every run start strictly inside the window, in position order
@@ -1417,10 +1502,11 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
     }
     if (tid == 0) {
         WinPartial wp;
-        unsigned long long tot[10];
-        for (int c = 0; c < 10; ++c) { tot[c] = 0; for (int i = 0; i < kWaves; ++i) tot[c] += s_wtot[i][c]; }
+        unsigned long long tot[12];
+        for (int c = 0; c < 12; ++c) { tot[c] = 0; for (int i = 0; i < kWaves; ++i) tot[c] += s_wtot[i][c]; }
         for (int c = 0; c < 6; ++c) wp.cnt[c] = tot[c];
         wp.n_cov = tot[6]; wp.sum_qc = tot[7]; wp.sum_q = tot[8];
+        wp.sum_reflen = tot[10]; wp.sum_mapq_reflen = tot[11];
         wp.n_inner = (uint32_t)tot[9];
         uint32_t m = 0;
         for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
@@ -1438,7 +1524,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
 constexpr int kFinBlock = 1024;
 
 struct FinPartial {
-    unsigned long long acc[9];       // cnt[6], n_cov, sum_qc, sum_q
+    unsigned long long acc[11];      // cnt[6], n_cov, sum_qc, sum_q, sum_reflen, sum_mapq_reflen
     uint32_t n_runs;
     uint32_t max_raw;
 };
@@ -1451,10 +1537,10 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
                                                             FinPartial *__restrict__ fin)
 {
     __shared__ uint32_t s_w[kFinBlock / 64], s_m[kFinBlock / 64];
-    __shared__ unsigned long long s_red[9][kFinBlock / 64];
+    __shared__ unsigned long long s_red[11][kFinBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint32_t w = blockIdx.x * kFinBlock + tid;
-    unsigned long long acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long acc[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t c = 0, maxraw = 0;
     if (w < n_win) {
         const WinPartial wp = winpart[w];
@@ -1463,12 +1549,13 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
         if (p < extent) c += (w == 0) ? 1u : (first_state[w] != last_state[w - 1] ? 1u : 0u);
         for (int i = 0; i < 6; ++i) acc[i] = wp.cnt[i];
         acc[6] = wp.n_cov; acc[7] = wp.sum_qc; acc[8] = wp.sum_q;
+        acc[9] = wp.sum_reflen; acc[10] = wp.sum_mapq_reflen;
         maxraw = wp.max_raw;
     }
     const uint32_t inc = dpp_incl_scan_u32(c);
     if (lane == 63) s_w[wv] = inc;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < 11; ++i) {
         const unsigned long long v = wave_sum_u64(acc[i]);
         if (lane == 0) s_red[i][wv] = v;
     }
@@ -1482,7 +1569,7 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
         FinPartial fp;
         fp.n_runs = 0; fp.max_raw = 0;
         for (int j = 0; j < kFinBlock / 64; ++j) { fp.n_runs += s_w[j]; fp.max_raw = s_m[j] > fp.max_raw ? s_m[j] : fp.max_raw; }
-        for (int i = 0; i < 9; ++i) { unsigned long long v = 0; for (int j = 0; j < kFinBlock / 64; ++j) v += s_red[i][j]; fp.acc[i] = v; }
+        for (int i = 0; i < 11; ++i) { unsigned long long v = 0; for (int j = 0; j < kFinBlock / 64; ++j) v += s_red[i][j]; fp.acc[i] = v; }
         fin[blockIdx.x] = fp;
     }
 }
@@ -1502,7 +1589,7 @@ __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, 
     for (uint32_t b = tid; b < n_fin; b += kBlock) {
         const FinPartial fp = fin[b];
         acc[11] += fp.n_runs;
-        for (int i = 0; i < 9; ++i) acc[i] += fp.acc[i];
+        for (int i = 0; i < 11; ++i) acc[i] += fp.acc[i];        // [9], [10]: the reads k_pileup's short-read form owned
         maxraw = fp.max_raw > maxraw ? fp.max_raw : maxraw;
     }
     for (uint32_t i = tid; i < n_prep; i += kBlock) {

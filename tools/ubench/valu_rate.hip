@@ -30,6 +30,14 @@ template <int OP> __global__ __launch_bounds__(256) void k(uint32_t *out, uint32
                 else if (OP == 7) asm volatile("v_lshrrev_b32 %0, 7, %0" : "+v"(x[i]));
                 else if (OP == 8) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(x[i]) : "v"(b));
                 else if (OP == 9) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(b));
+                else if (OP == 14) asm volatile("v_lerp_u8 %0, %0, %1, %1" : "+v"(x[i]) : "v"(b));
+                else if (OP == 15) asm volatile("v_sad_u8 %0, %0, %1, %0" : "+v"(x[i]) : "v"(b));
+                else if (OP == 16) asm volatile("v_and_or_b32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(b));
+                else if (OP == 17) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(x[i]) : "v"(b));
+                else if (OP == 18) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(x[i]) : "v"(b));
+                else if (OP == 19) asm volatile("v_bfe_u32 %0, %0, 3, 9" : "+v"(x[i]));
+                else if (OP == 20) asm volatile("v_min_u32 %0, %0, %1" : "+v"(x[i]) : "v"(b));
+                else if (OP == 21) asm volatile("v_alignbit_b32 %0, %0, %1, 7" : "+v"(x[i]) : "v"(b));
                 else if (OP == 11) atomicAdd(&lds[(threadIdx.x * 2 + i) & 2047], (unsigned long long)x[i]);          // ds_add_u64 conflict-free-ish
                 else if (OP == 12) atomicAdd(reinterpret_cast<uint32_t *>(lds) + ((threadIdx.x + 64 * i) & 4095), x[i]); // ds_add_u32 conflict-free
                 else if (OP == 13) x[i] += (uint32_t)lds[(threadIdx.x + i * 7) & 2047];                               // ds_read_b64
@@ -72,10 +80,24 @@ int main(int argc, char **argv)
     case 7: run<7>("v_lshr", 1, d); break;
     case 8: run<8>("v_mul_lo_u32", 1, d); break;
     case 9: run<9>("v_cndmask", 1, d); break;
+    case 14: run<14>("v_lerp_u8", 1, d); break;
+    case 15: run<15>("v_sad_u8", 1, d); break;
+    case 16: run<16>("v_and_or", 1, d); break;
+    case 17: run<17>("v_lshl_add", 1, d); break;
+    case 18: run<18>("v_add3", 1, d); break;
+    case 19: run<19>("v_bfe", 1, d); break;
+    case 20: run<20>("v_min_u32", 1, d); break;
+    case 21: run<21>("v_alignbit", 1, d); break;
     case 11: run<11>("ds_add_u64", 1, d); break;
     case 12: run<12>("ds_add_u32", 1, d); break;
     case 13: run<13>("ds_read_b64", 1, d); break;
-    default: printf("usage: valu_rate <case>\n");
+    default:
+        if (which == -1) {      // every case, one process each would be cleaner; the kernels are independent
+            run<1>("v_and", 1, d); run<2>("v_add", 1, d); run<3>("v_bitop3", 1, d); run<4>("v_dot4_u8", 1, d); run<5>("v_mul_u24", 1, d);
+            run<6>("v_perm", 1, d); run<7>("v_lshr", 1, d); run<9>("v_cndmask", 1, d); run<14>("v_lerp_u8", 1, d); run<15>("v_sad_u8", 1, d);
+            run<16>("v_and_or", 1, d); run<17>("v_lshl_add", 1, d); run<18>("v_add3", 1, d); run<19>("v_bfe", 1, d); run<20>("v_min_u32", 1, d);
+            run<21>("v_alignbit", 1, d); run<11>("ds_add_u64", 1, d); run<12>("ds_add_u32", 1, d); run<13>("ds_read_b64", 1, d);
+        } else printf("usage: valu_rate [case]\n");
     }
     hipDeviceSynchronize();
     return 0;

@@ -99,6 +99,7 @@ SYMBOLS = [
     ("cl_last_error", C.c_char_p, [C.c_void_p]),
     ("cl_contig_begin", C.c_int, [C.c_void_p, C.c_int32, C.c_uint32, C.c_void_p, C.c_uint64]),
     ("cl_contig_reserve", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
+    ("cl_contig_prefetch_qual", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("cl_push_reads", C.c_int, [C.c_void_p, C.POINTER(cl_read_tile)]),
     ("cl_contig_finish", C.c_int, [C.c_void_p, C.POINTER(cl_contig_summary),
                                    C.POINTER(C.POINTER(cl_interval)), C.POINTER(C.c_size_t)]),

@@ -10,6 +10,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -93,8 +94,22 @@ struct cl_ctx {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint64_t host_max_end = 0;         // largest pos + reference span over the pushed reads (32-bit clamped spans), for the extent
-    static constexpr int kCopyStreams = 4;
-    hipStream_t copy_stream[kCopyStreams] = {nullptr, nullptr, nullptr, nullptr};   // large pageable H2D copies, one host thread each (created on first use)
+    // Pinned staging ring for host-to-device copies: kCopyThreads host threads, each with its own stream and two
+    // pinned buffers; a thread fills one buffer (memcpy from the caller's pageable memory, or records built in
+    // place) while the DMA of its other buffer runs, so the link sees pinned memory only and the fills of all
+    // threads overlap all transfers.  Created on first use, kept for the context's life.
+    static constexpr int kCopyThreads = 8;
+    static constexpr size_t kPinBytes = 8u << 20;
+    hipStream_t copy_stream[kCopyThreads] = {};
+    uint8_t *pin[kCopyThreads][2] = {};
+    hipEvent_t pin_ev[kCopyThreads][2] = {};
+    bool pins_made = false;
+    std::vector<dut::Thread> copiers;                 // a transfer in flight (joined by ring_finish)
+    hipError_t copy_err[kCopyThreads] = {};
+    // cl_contig_prefetch_qual: quality bytes on their way to d_qual + kQualPad + pf_off before their tile is pushed
+    const uint8_t *pf_src = nullptr;
+    uint64_t pf_n = 0, pf_off = 0;
+    bool pf_active = false;
     cl_options opt{};
     Opts dopt{};
     std::string err;
@@ -152,7 +167,6 @@ struct cl_ctx {
     uint32_t n_reads = 0;
     uint64_t n_cigar = 0, n_qual = 0;
     uint32_t extent = 0, n_win = 0;
-    uint64_t ref_len_dev = 0;
 
     std::vector<cl_interval> h_iv;
     DevSummary h_sum{};
@@ -214,6 +228,75 @@ void build_lut(double frac, std::vector<uint32_t> &lut)
     }
 }
 
+cl_status ensure_pins(cl_ctx *c)
+{
+    if (c->pins_made) return CL_OK;
+    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[t], hipStreamNonBlocking));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->pin[t][b]), cl_ctx::kPinBytes, hipHostMallocDefault));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[t][b], hipEventDisableTiming));
+        }
+    }
+    c->pins_made = true;
+    return CL_OK;
+}
+
+// n bytes to `dst` through the ring: fill(off, len, out) writes the bytes [off, off + len) of the transfer into the
+// pinned buffer `out`.  Chunks are dealt round-robin to the copier threads.  Returns at once; ring_finish joins.
+template <class Fill>
+cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
+{
+    cl_status s = ensure_pins(c);
+    if (s != CL_OK) return s;
+    const uint64_t CH = cl_ctx::kPinBytes, nch = (n + CH - 1) / CH;
+    const int nt = (int)std::min<uint64_t>(cl_ctx::kCopyThreads, nch);
+    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
+    for (int t = 0; t < nt; ++t) {
+        c->copiers.push_back(dut::spawn_or_run([c, dst, n, fill, t, nch, CH]() {
+            hipError_t e = hipSetDevice(c->device);
+            int k = 0;
+            for (uint64_t ch = (uint64_t)t; ch < nch && e == hipSuccess; ch += cl_ctx::kCopyThreads, ++k) {
+                const int b = k & 1;
+                const uint64_t off = ch * CH, len = std::min<uint64_t>(CH, n - off);
+                if (k >= 2) e = hipEventSynchronize(c->pin_ev[t][b]);          // the buffer's previous transfer is done
+                if (e != hipSuccess) break;
+                fill(off, len, c->pin[t][b]);
+                e = hipMemcpyAsync(dst + off, c->pin[t][b], len, hipMemcpyHostToDevice, c->copy_stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(c->pin_ev[t][b], c->copy_stream[t]);
+            }
+            const hipError_t e2 = hipStreamSynchronize(c->copy_stream[t]);
+            c->copy_err[t] = e != hipSuccess ? e : e2;
+        }));
+    }
+    return CL_OK;
+}
+
+cl_status ring_finish(cl_ctx *c)
+{
+    c->copiers.clear();                                   // dut::Thread joins in its destructor
+    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) HIP_TRY(c, c->copy_err[t]);
+    return CL_OK;
+}
+
+// plain bytes through the ring, start to finish
+cl_status ring_copy(cl_ctx *c, void *dst, const void *src, uint64_t n)
+{
+    if (n == 0) return CL_OK;
+    const uint8_t *s8 = static_cast<const uint8_t *>(src);
+    cl_status s = ring_start(c, static_cast<uint8_t *>(dst), n, [s8](uint64_t off, uint64_t len, uint8_t *out) { memcpy(out, s8 + off, len); });
+    if (s != CL_OK) return s;
+    return ring_finish(c);
+}
+
+// a prefetch that was started and never claimed by a tile: wait for it, its bytes are simply overwritten later
+void drop_prefetch(cl_ctx *c)
+{
+    if (!c->pf_active) return;
+    (void)ring_finish(c);
+    c->pf_active = false; c->pf_src = nullptr; c->pf_n = 0;
+}
+
 cl_status ensure_events(cl_ctx *c)
 {
     if (c->ev_made) return CL_OK;
@@ -266,7 +349,40 @@ Reads device_reads(const cl_ctx *c)
     return R;
 }
 
-// allocate everything that depends on extent
+// The windows' candidate ranges: an index of the resident reads (binary searches over the sorted positions), built on
+// the host at upload -- where the positions still are -- instead of in every run.  Same rules as the device's
+// window_bounds() (kernels.hip.h), which the tests hold against this one through the results.
+void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &flags)
+{
+    const uint32_t n = (uint32_t)c->h_pos.size(), n_wide = (uint32_t)c->h_wide_pos.size();
+    const int32_t *pos = c->h_pos.data(), *wpos = c->h_wide_pos.data();
+    auto lb = [](const int32_t *p, uint32_t cnt, long long key) {
+        return (uint32_t)(std::lower_bound(p, p + cnt, key, [](int32_t v, long long k) { return (long long)v < k; }) - p);
+    };
+    std::atomic<uint32_t> fl{0};
+    win.resize((size_t)c->n_win + 1);
+    dut::parallel_for(c->n_win, 512, [&](size_t w) {
+        const long long W = (long long)w * kT;
+        WinMeta m;
+        m.lo = lb(pos, n, W - (long long)c->span_n + 1);
+        m.hi = lb(pos, n, W + (long long)kT);
+        m.wlo = 0; m.wn = 0;
+        if (n_wide) {
+            m.wlo = lb(wpos, n_wide, W - (long long)c->span_w + 1);
+            m.wn = lb(wpos, n_wide, W - (long long)c->span_n + 1) - m.wlo;
+        }
+        const uint32_t first = m.wn ? c->h_wide_idx[m.wlo] : m.lo;      // lo <= n: the offsets array has n + 1 entries
+        m.q0 = c->h_qual_off[first]; m.pad[0] = 0; m.pad[1] = 0;
+        // k_pileup addresses the quality bytes of a window with 32-bit offsets
+        if (m.hi > first && c->h_qual_off[m.hi] - c->h_qual_off[first] > 0xFFFF0000ull) fl.fetch_or(kErrRange);
+        // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
+        if ((m.hi - m.lo) + m.wn > 32767u) fl.fetch_or(kNeedDeep);
+        win[w] = m;
+    });
+    flags = fl.load();
+}
+
+// allocate and lay out everything that depends on the extent (called by cl_contig_upload, the staged arrays still there)
 cl_status size_for_extent(cl_ctx *c, uint32_t extent)
 {
     c->extent = extent;
@@ -282,29 +398,27 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_win_wide.reserve(c->n_win + 1));
     HIP_TRY(c, hipMemsetAsync(c->d_win_wide.p, 0, c->n_win + 1, c->stream));
     // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80)
-    if (c->d_ref.cap < padded + 16 || c->ref_len_dev == UINT64_MAX) {
-        HIP_TRY(c, c->d_ref.reserve(padded + 16));
+    HIP_TRY(c, c->d_ref.reserve(padded + 16));
+    {
+        const uint8_t *ref = c->h_ref.data();
+        const uint64_t nref = std::min<uint64_t>(c->h_ref.size(), padded);
+        cl_status rs = ring_start(c, c->d_ref.p, padded + 16, [ref, nref](uint64_t off, uint64_t len, uint8_t *out) {
+            const uint64_t have = off < nref ? std::min<uint64_t>(len, nref - off) : 0;
+            if (have) memcpy(out, ref + off, have);
+            if (have < len) memset(out + have, 'N', len - have);
+        });
+        // ... beside it, the windows' candidate ranges
+        std::vector<WinMeta> win;
+        uint32_t flags = 0;
+        host_window_bounds(c, win, flags);
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+        if (c->n_win) HIP_TRY(c, hipMemcpyAsync(c->d_win.p, win.data(), (size_t)c->n_win * sizeof(WinMeta), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        // a window with more candidates than the 16-bit counters / differences hold: the 32-bit form from the start
+        c->deep = (flags & kNeedDeep) != 0;
+        c->bounds_err = flags & kErrRange;
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_ref.p, 'N', padded + 16, c->stream));
-    const size_t nref = std::min<size_t>(c->h_ref.size(), padded);
-    if (nref) HIP_TRY(c, hipMemcpyAsync(c->d_ref.p, c->h_ref.data(), nref, hipMemcpyHostToDevice, c->stream));
-    // the windows' candidate ranges: an index of the resident reads for this extent (binary searches over the sorted
-    // positions), built here once instead of in every run
-    if (c->n_win) {
-        BoundsArgs B;
-        B.span_n = c->span_n; B.span_w = c->span_w; B.wide_pos = c->d_wide_pos.p; B.wide_idx = c->d_wide_idx.p;
-        B.n_wide = c->n_wide; B.T = kT; B.n_win = c->n_win;
-        B.win = c->d_win.p; B.err_flag = c->d_errflag.p;
-        hipLaunchKernelGGL(k_window_bounds, dim3((c->n_win + kBlock - 1) / kBlock), dim3(kBlock), 0, c->stream, device_reads(c), B);
-        HIP_TRY(c, hipGetLastError());
-    }
-    uint32_t flags[2] = {0, 0};
-    HIP_TRY(c, hipMemcpyAsync(flags, c->d_errflag.p, sizeof(flags), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    // a window with more candidates than the 16-bit counters / differences hold: the 32-bit form from the start
-    if (flags[0] & kNeedDeep) c->deep = true;
-    c->bounds_err = flags[0] & kErrRange;
     return CL_OK;
 }
 
@@ -457,7 +571,14 @@ void cl_destroy(cl_ctx *c)
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
-    for (int i = 0; i < cl_ctx::kCopyStreams; ++i) if (c->copy_stream[i]) (void)hipStreamDestroy(c->copy_stream[i]);
+    drop_prefetch(c);
+    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) {
+        for (int b = 0; b < 2; ++b) {
+            if (c->pin_ev[t][b]) (void)hipEventDestroy(c->pin_ev[t][b]);
+            if (c->pin[t][b]) (void)hipHostFree(c->pin[t][b]);
+        }
+        if (c->copy_stream[t]) (void)hipStreamDestroy(c->copy_stream[t]);
+    }
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -470,6 +591,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     if (!c) return CL_ERR_INVALID;
     if (contig_len > 0xFFF00000u) return fail(c, CL_ERR_RANGE, "contig length beyond the engine's 32-bit range");
     if (ref_len && !ref_bases) return fail(c, CL_ERR_INVALID, "ref_bases is null");
+    drop_prefetch(c);
     c->tid = tid; c->contig_len = contig_len;
     const uint64_t nref = std::min<uint64_t>(ref_len, contig_len);
     c->h_ref.assign(ref_bases, ref_bases + nref);
@@ -509,9 +631,31 @@ cl_status flush_staged_qual(cl_ctx *c)
 constexpr uint64_t kDirectQual = 4u << 20;   // tiles with at least this many quality bytes skip the host staging copy
 } // namespace
 
+cl_status cl_contig_prefetch_qual(cl_ctx *c, const uint8_t *qual, uint64_t n_bytes)
+{
+    if (!c || !c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_prefetch_qual outside cl_contig_begin .. upload");
+    if (!qual || n_bytes < kDirectQual) return CL_OK;            // small tiles are staged on the host anyway
+    try {
+        drop_prefetch(c);
+        cl_status fs = flush_staged_qual(c);
+        if (fs != CL_OK) return fs;
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, c->d_qual.grow_keep(c->q_dev + n_bytes + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        cl_status rs = ring_start(c, c->d_qual.p + kQualPad + c->q_dev, n_bytes,
+                                  [qual](uint64_t off, uint64_t len, uint8_t *out) { memcpy(out, qual + off, len); });
+        if (rs != CL_OK) { (void)ring_finish(c); return rs; }
+        c->pf_src = qual; c->pf_n = n_bytes; c->pf_off = c->q_dev; c->pf_active = true;
+        return CL_OK;
+    }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
 cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes)
 {
     if (!c || !c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_reserve outside cl_contig_begin .. upload");
+    drop_prefetch(c);                                        // the quality buffer may move below
     try {
         c->h_pos.reserve(n_reads); c->h_mapq.reserve(n_reads);
         c->h_cigar_off.reserve(n_reads + 1); c->h_qual_off.reserve(n_reads + 1);
@@ -544,36 +688,33 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     const uint32_t cbase = (uint32_t)c->h_cigar.size();
     const uint64_t rbase = c->h_pos.size();
 
-    // ---- a large tile: its quality bytes go from the caller's buffer straight to the device, and they start
-    //      now.  A copy from pageable memory is staged by the runtime on the calling thread: the tile is cut into
-    //      slices that go down side by side, one host thread and stream each, while this thread validates the
-    //      tile and stages the small arrays.  All are joined before the call returns (the caller's buffer is
-    //      free again then); nothing of the context changes if the tile turns out to be invalid. ----
-    std::vector<dut::Thread> copiers;                          // joined when they go out of scope, whichever way
-    hipError_t copy_err[cl_ctx::kCopyStreams] = {hipSuccess, hipSuccess, hipSuccess, hipSuccess};
+    // ---- a large tile: its quality bytes go from the caller's buffer to the device through the pinned staging
+    //      ring, and they start now (unless cl_contig_prefetch_qual already sent exactly these bytes): the copier
+    //      threads fill pinned buffers and queue their transfers while this thread validates the tile and stages
+    //      the small arrays.  All are joined before the call returns (the caller's buffer is free again then);
+    //      nothing of the context changes if the tile turns out to be invalid. ----
+    struct RingGuard { cl_ctx *c; bool active = false; ~RingGuard() { if (active) (void)ring_finish(c); } } ring{c};
     const bool direct = nq >= kDirectQual;
     if (direct) {
-        cl_status fs = flush_staged_qual(c);
-        if (fs != CL_OK) return fs;
-        HIP_TRY(c, hipSetDevice(c->device));
-        HIP_TRY(c, c->d_qual.grow_keep(c->q_dev + nq + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));          // the (re)allocation above is done
-        uint8_t *dst = c->d_qual.p + kQualPad + c->q_dev;
         const uint8_t *src = t->qual + q0;
-        const int nsl = nq >= (64ull << 20) ? cl_ctx::kCopyStreams : 1;
-        for (int i = 0; i < nsl; ++i)
-            if (!c->copy_stream[i]) HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[i], hipStreamNonBlocking));
-        const uint64_t per = ((nq + nsl - 1) / nsl + 4095ull) & ~4095ull;
-        for (int i = 0; i < nsl; ++i) {
-            const uint64_t a = std::min<uint64_t>(nq, per * i), b = std::min<uint64_t>(nq, per * (i + 1));
-            if (b <= a) continue;
-            copiers.push_back(dut::spawn_or_run([c, dst, src, a, b, i, &copy_err]() {
-                hipError_t e = hipSetDevice(c->device);
-                if (e == hipSuccess) e = hipMemcpyAsync(dst + a, src + a, b - a, hipMemcpyHostToDevice, c->copy_stream[i]);
-                if (e == hipSuccess) e = hipStreamSynchronize(c->copy_stream[i]);
-                copy_err[i] = e;
-            }));
+        const bool prefetched = c->pf_active && c->pf_src == src && c->pf_n == nq && c->h_qual.empty() && c->pf_off == c->q_dev;
+        if (prefetched) {
+            c->pf_active = false; c->pf_src = nullptr; c->pf_n = 0;
+            ring.active = true;                               // the transfer in flight is this tile's
+        } else {
+            drop_prefetch(c);
+            cl_status fs = flush_staged_qual(c);
+            if (fs != CL_OK) return fs;
+            HIP_TRY(c, hipSetDevice(c->device));
+            HIP_TRY(c, c->d_qual.grow_keep(c->q_dev + nq + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));          // the (re)allocation above is done
+            cl_status rs = ring_start(c, c->d_qual.p + kQualPad + c->q_dev, nq,
+                                      [src](uint64_t off, uint64_t len, uint8_t *out) { memcpy(out, src + off, len); });
+            if (rs != CL_OK) return rs;
+            ring.active = true;
         }
+    } else if (c->pf_active) {
+        drop_prefetch(c);
     }
     const unsigned long long qbase = c->q_dev + c->h_qual.size();
 
@@ -650,8 +791,11 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     } catch (const std::bad_alloc &) {
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
-    for (auto &x : copiers) if (x.joinable()) x.join();
-    for (int i = 0; i < cl_ctx::kCopyStreams; ++i) HIP_TRY(c, copy_err[i]);      // a failed copy: the staged arrays are rolled back
+    if (ring.active) {
+        ring.active = false;
+        cl_status rs = ring_finish(c);                         // a failed copy: the staged arrays are rolled back
+        if (rs != CL_OK) return rs;
+    }
     if (direct) c->q_dev += nq;
     undo.armed = false;
     return CL_OK;
@@ -671,6 +815,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     Range rg("cl_contig_upload");
     if (!c || !c->in_contig) return fail(c, CL_ERR_INVALID, "cl_contig_upload without cl_contig_begin");
     HIP_TRY(c, hipSetDevice(c->device));
+    drop_prefetch(c);
     c->n_reads = (uint32_t)c->h_pos.size();
     c->n_cigar = c->h_cigar.size();
     {
@@ -678,43 +823,62 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if (fs != CL_OK) return fs;
     }
     c->n_qual = c->q_dev;
-    const size_t n = c->n_reads;
-    HIP_TRY(c, c->d_pos.reserve(n + 1));
-    HIP_TRY(c, c->d_mapq.reserve(n + 1));
-    HIP_TRY(c, c->d_end.reserve(n + 1));
-    HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
-    HIP_TRY(c, c->d_qual_off.reserve(n + 1));
-    HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));          // k_read_prep loads four words at a read's first op
     c->n_long = (uint32_t)c->h_long_list.size();
+    c->n_wide = (uint32_t)c->h_wide_idx.size();
+    const size_t n = c->n_reads;
+    const Variant vr = pick_variant(c);
+    // What the device needs of the per-read fields depends on the form of k_pileup the contig gets: the short-read form
+    // reads one packed record per read; the long-read forms, k_read_prep and k_read_prep_long read the arrays as pushed.
+    const bool need_soa = vr.lng || c->n_long > 0;
+    HIP_TRY(c, c->d_end.reserve(n + 1));
+    HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));          // four words are loaded at a read's first op
     HIP_TRY(c, c->d_long_list.reserve(c->n_long + 1));
-    HIP_TRY(c, c->d_rec.reserve(n + 1));
-    // the packed records of the short-read form: pos, CIGAR offset, low half of the quality offset, mapq and the
-    // two lengths when they fit their fields (else the marker: the kernel takes them from the next record)
-    std::vector<ReadRec> h_rec(n + 1);
-    dut::parallel_for(n, 262144, [&](size_t i) {
-        const uint32_t nc = c->h_cigar_off[i + 1] - c->h_cigar_off[i];
-        const unsigned long long ql = c->h_qual_off[i + 1] - c->h_qual_off[i];
-        ReadRec r;
-        r.pos = c->h_pos[i]; r.cigar_off = c->h_cigar_off[i]; r.qual_lo = (uint32_t)c->h_qual_off[i];
-        r.meta = (uint32_t)c->h_mapq[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<unsigned long long>(ql, 0xFFFFull) << 16);
-        h_rec[i] = r;
-    });
-    h_rec[n].pos = 0; h_rec[n].cigar_off = c->h_cigar_off[n]; h_rec[n].qual_lo = (uint32_t)c->h_qual_off[n]; h_rec[n].meta = 0;
     HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
-    if (n) {
-        HIP_TRY(c, hipMemcpyAsync(c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_mapq.p, c->h_mapq.data(), n, hipMemcpyHostToDevice, c->stream));
-    }
-    HIP_TRY(c, hipMemcpyAsync(c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-    if (c->n_cigar) HIP_TRY(c, hipMemcpyAsync(c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->d_rec.p, h_rec.data(), (n + 1) * sizeof(ReadRec), hipMemcpyHostToDevice, c->stream));
-    if (c->n_long) HIP_TRY(c, hipMemcpyAsync(c->d_long_list.p, c->h_long_list.data(), (size_t)c->n_long * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    c->n_wide = (uint32_t)c->h_wide_idx.size();
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    // everything goes through the pinned staging ring (pageable vectors -> pinned buffers -> HBM, the fills overlapping
+    // the transfers)
+    cl_status rs = CL_OK;
+    if (need_soa) {
+        HIP_TRY(c, c->d_pos.reserve(n + 1));
+        HIP_TRY(c, c->d_mapq.reserve(n + 1));
+        HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
+        HIP_TRY(c, c->d_qual_off.reserve(n + 1));
+        if ((rs = ring_copy(c, c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t))) != CL_OK) return rs;
+        if ((rs = ring_copy(c, c->d_mapq.p, c->h_mapq.data(), n)) != CL_OK) return rs;
+        if ((rs = ring_copy(c, c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t))) != CL_OK) return rs;
+        if ((rs = ring_copy(c, c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long))) != CL_OK) return rs;
+    }
+    if (!vr.lng) {
+        // the packed records of the short-read form: pos, CIGAR offset, low half of the quality offset, mapq and the two
+        // lengths when they fit their fields (else the marker: the kernel takes them from the next record); rec[n] is the
+        // sentinel with the totals.  Built straight into the pinned buffers.
+        HIP_TRY(c, c->d_rec.reserve(n + 1));
+        const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data();
+        const uint32_t *hc = c->h_cigar_off.data(); const unsigned long long *hq = c->h_qual_off.data();
+        rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), (uint64_t)(n + 1) * sizeof(ReadRec),
+                        [hp, hm, hc, hq, n](uint64_t off, uint64_t len, uint8_t *out) {
+            ReadRec *o = reinterpret_cast<ReadRec *>(out);
+            const size_t i0 = off / sizeof(ReadRec), i1 = (off + len) / sizeof(ReadRec);
+            for (size_t i = i0; i < i1; ++i) {
+                ReadRec r;
+                if (i < n) {
+                    const uint32_t nc = hc[i + 1] - hc[i];
+                    const unsigned long long ql = hq[i + 1] - hq[i];
+                    r.pos = hp[i]; r.cigar_off = hc[i]; r.qual_lo = (uint32_t)hq[i];
+                    r.meta = (uint32_t)hm[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<unsigned long long>(ql, 0xFFFFull) << 16);
+                } else { r.pos = 0; r.cigar_off = hc[n]; r.qual_lo = (uint32_t)hq[n]; r.meta = 0; }
+                o[i - i0] = r;
+            }
+        });
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+    }
+    if ((rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
+    if (c->n_long) HIP_TRY(c, hipMemcpyAsync(c->d_long_list.p, c->h_long_list.data(), (size_t)c->n_long * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_pos.p, c->h_wide_pos.data(), c->n_wide * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -723,21 +887,19 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
     HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->ref_len_dev = UINT64_MAX;            // force the reference to be re-laid out
-    c->deep = false;                        // size_for_extent decides (the window bounds know)
     // a read overhanging the contig end makes the reference walk (and classify as REF_N, mod.rs:100-101) positions
     // up to its end: the extent is known from the spans computed at cl_push_reads
     cl_status s = size_for_extent(c, (uint32_t)std::max<uint64_t>(c->contig_len, c->host_max_end));
     if (s != CL_OK) return s;
-    c->ref_len_dev = c->h_ref.size();
     if (c->d_iv.cap == 0) HIP_TRY(c, c->d_iv.reserve(1u << 20));
-    // the staged copy is no longer needed except the reference (kept for an extent re-run)
+    // the staged copy is no longer needed
     std::vector<int32_t>().swap(c->h_pos);
     std::vector<uint8_t>().swap(c->h_mapq);
     std::vector<uint32_t>().swap(c->h_cigar);
     std::vector<uint8_t>().swap(c->h_qual);
     std::vector<uint32_t>().swap(c->h_cigar_off);
     std::vector<unsigned long long>().swap(c->h_qual_off);
+    std::vector<uint8_t>().swap(c->h_ref);
     c->uploaded = true; c->ran = false;
     return CL_OK;
 }
@@ -807,15 +969,10 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
             if (s != CL_OK) return s;
             continue;
         }
-        // a read that overhangs the contig end makes the reference walk (and classify as REF_N,
-        // mod.rs:100-101) positions up to its end: redo the contig with the larger extent
-        if (c->h_sum.max_end > c->extent) {
-            s = size_for_extent(c, (uint32_t)c->h_sum.max_end);
-            if (s != CL_OK) return s;
-            s = enqueue(c, false, nullptr, nullptr, nullptr);
-            if (s != CL_OK) return s;
-            continue;
-        }
+        // (a read that overhangs the contig end makes the reference walk, and classify as REF_N, positions up to its
+        // end, mod.rs:100-101: the extent was sized for that at upload from the spans computed at cl_push_reads; the
+        // device's own maximum can only agree)
+        if (c->h_sum.max_end > c->extent) return fail(c, CL_ERR_DEVICE, "a read ends beyond the extent computed at upload");
         if (c->h_sum.n_intervals > c->d_iv.cap) {
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
             launch_rle(c);

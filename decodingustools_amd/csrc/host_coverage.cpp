@@ -323,6 +323,62 @@ static void dut_stage_time(const char *what, double &t0)
     t0 = t1;
 }
 
+// distinct read names among the accepted reads (contig_profiler.rs:54-57: the HashSet of qnames), exactly
+static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accepted, uint64_t nacc)
+{
+    double tm = dut_now();
+    uint64_t total = 0;
+    {
+        // the reads are split into classes by the top bits of a 64-bit hash of the name, every class gets its own
+        // exact set (full comparison on a hash match), classes are counted in parallel and the counts add up
+        if (rec->qname_off && nacc) {
+            std::vector<uint64_t> h(rec->n);
+            NameSet hasher; hasher.rec = rec;
+            dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = accepted[i] ? hasher.hash_of(i) : 0; });
+            dut_stage_time("  admit: name hashes", tm);
+            // the accepted reads are bucketed by the top bits of their hash (counting sort: per-chunk histograms,
+            // offsets, scatter -- all parallel); every class then has a few thousand names and a table that
+            // stays in cache
+            const int bits = nacc > (1u << 22) ? 12 : (nacc > (1u << 16) ? 8 : 0);
+            const size_t kClasses = (size_t)1 << bits;
+            const size_t grain = 1u << 18, nchunk = (rec->n + grain - 1) / grain;
+            auto cls = [&](uint64_t hv) -> size_t { return bits ? (size_t)(hv >> (64 - bits)) : 0; };
+            std::vector<uint32_t> hist(nchunk * kClasses, 0);
+            dut::parallel_for(nchunk, 1, [&](size_t c) {
+                uint32_t *hc = hist.data() + c * kClasses;
+                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
+                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) hc[cls(h[i])] += 1;
+            });
+            std::vector<uint64_t> cstart(kClasses + 1, 0);
+            {   // class-major, chunk-minor exclusive prefix: hist[c][k] becomes the write offset of chunk c in class k
+                uint64_t run = 0;
+                for (size_t k = 0; k < kClasses; ++k) {
+                    cstart[k] = run;
+                    for (size_t c = 0; c < nchunk; ++c) { const uint32_t v = hist[c * kClasses + k]; hist[c * kClasses + k] = (uint32_t)(run - cstart[k]); run += v; }
+                }
+                cstart[kClasses] = run;
+            }
+            std::vector<uint32_t> order(nacc);                // read indices, class by class (the host refuses >= 2^29 reads per contig)
+            dut::parallel_for(nchunk, 1, [&](size_t c) {
+                uint32_t *hc = hist.data() + c * kClasses;
+                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
+                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) { const size_t k = cls(h[i]); order[cstart[k] + hc[k]++] = (uint32_t)i; }
+            });
+            std::vector<uint64_t> per(kClasses, 0);
+            dut::parallel_for(kClasses, 16, [&](size_t k) {
+                const uint64_t a = cstart[k], b = cstart[k + 1];
+                if (a == b) return;
+                NameSet set; set.rec = rec; set.presize(b - a);
+                for (uint64_t q = a; q < b; ++q) set.insert_hashed(order[q], h[order[q]]);
+                per[k] = set.count;
+            });
+            for (uint64_t v : per) total += v;
+            dut_stage_time("  admit: name sets", tm);
+        }
+    }
+    return (uint32_t)total;
+}
+
 static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t contig_len, const dut_records *rec,
                     uint8_t *accepted, uint32_t *n_unique_names, uint64_t *n_accepted)
 {
@@ -440,57 +496,7 @@ static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t con
     }
     dut_stage_time("  admit: cap rule", tm);
     if (n_accepted) *n_accepted = nacc;
-    if (n_unique_names) {
-        // distinct names among the accepted reads, exactly: the reads are split into 64 classes by the
-        // top bits of a 64-bit hash of the name, every class gets its own exact set (full comparison
-        // on a hash match), classes are counted in parallel and the counts add up
-        uint64_t total = 0;
-        if (rec->qname_off && nacc) {
-            std::vector<uint64_t> h(rec->n);
-            NameSet hasher; hasher.rec = rec;
-            dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = accepted[i] ? hasher.hash_of(i) : 0; });
-            dut_stage_time("  admit: name hashes", tm);
-            // the accepted reads are bucketed by the top bits of their hash (counting sort: per-chunk histograms,
-            // offsets, scatter -- all parallel); every class then has a few thousand names and a table that
-            // stays in cache
-            const int bits = nacc > (1u << 22) ? 12 : (nacc > (1u << 16) ? 8 : 0);
-            const size_t kClasses = (size_t)1 << bits;
-            const size_t grain = 1u << 18, nchunk = (rec->n + grain - 1) / grain;
-            auto cls = [&](uint64_t hv) -> size_t { return bits ? (size_t)(hv >> (64 - bits)) : 0; };
-            std::vector<uint32_t> hist(nchunk * kClasses, 0);
-            dut::parallel_for(nchunk, 1, [&](size_t c) {
-                uint32_t *hc = hist.data() + c * kClasses;
-                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
-                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) hc[cls(h[i])] += 1;
-            });
-            std::vector<uint64_t> cstart(kClasses + 1, 0);
-            {   // class-major, chunk-minor exclusive prefix: hist[c][k] becomes the write offset of chunk c in class k
-                uint64_t run = 0;
-                for (size_t k = 0; k < kClasses; ++k) {
-                    cstart[k] = run;
-                    for (size_t c = 0; c < nchunk; ++c) { const uint32_t v = hist[c * kClasses + k]; hist[c * kClasses + k] = (uint32_t)(run - cstart[k]); run += v; }
-                }
-                cstart[kClasses] = run;
-            }
-            std::vector<uint32_t> order(nacc);                // read indices, class by class (the host refuses >= 2^29 reads per contig)
-            dut::parallel_for(nchunk, 1, [&](size_t c) {
-                uint32_t *hc = hist.data() + c * kClasses;
-                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
-                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) { const size_t k = cls(h[i]); order[cstart[k] + hc[k]++] = (uint32_t)i; }
-            });
-            std::vector<uint64_t> per(kClasses, 0);
-            dut::parallel_for(kClasses, 16, [&](size_t k) {
-                const uint64_t a = cstart[k], b = cstart[k + 1];
-                if (a == b) return;
-                NameSet set; set.rec = rec; set.presize(b - a);
-                for (uint64_t q = a; q < b; ++q) set.insert_hashed(order[q], h[order[q]]);
-                per[k] = set.count;
-            });
-            for (uint64_t v : per) total += v;
-            dut_stage_time("  admit: name sets", tm);
-        }
-        *n_unique_names = (uint32_t)total;
-    }
+    if (n_unique_names) *n_unique_names = count_unique_names(rec, accepted, nacc);
     return CL_OK;
 }
 
@@ -526,21 +532,31 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
 {
     if (!ctx || !stats || !opt || !rec || !state_counts || !intervals || !n_intervals) return CL_ERR_INVALID;
     double tm = dut_now();
+    int rc = cl_contig_begin(ctx, tid, contig_len, ref, ref_len);
+    if (rc != CL_OK) return rc;
+    // Reads at or past contig_len (never yielded by the region fetch) are the sorted tail and are cut off.  The quality
+    // bytes of the rest start towards the device now, beside the admission below (the tile is pushed as the records lie;
+    // should it turn out that it cannot be -- unsorted input, leading reads to drop -- the engine discards the prefetch).
+    uint64_t a0 = 0, n_keep = rec->n;
+    while (n_keep > 0 && (int64_t)rec->pos[n_keep - 1] >= (int64_t)contig_len) --n_keep;
+    if (n_keep > 0 && rec->pos[0] >= 0) {
+        rc = cl_contig_prefetch_qual(ctx, rec->qual + rec->qual_off[0], rec->qual_off[n_keep] - rec->qual_off[0]);
+        if (rc != CL_OK) return rc;
+    }
     std::vector<uint8_t> acc(rec->n ? rec->n : 1);
     uint32_t n_names = 0; uint64_t n_acc = 0;
-    int rc = dut_admit_reads(opt, tid, contig_len, rec, acc.data(), &n_names, &n_acc);
+    rc = dut_admit_reads(opt, tid, contig_len, rec, acc.data(), nullptr, &n_acc);
     if (rc != CL_OK) return rc;
-    dut_stage_time("admit + name set", tm);
-    rc = cl_contig_begin(ctx, tid, contig_len, ref, ref_len);
-    if (rc != CL_OK) return rc;
+    dut_stage_time("admit", tm);
+    // the distinct-name count is needed at the very end only: on its own thread beside the push, the kernels and the
+    // read-back (joined before this function returns, also on every error path: dut::Thread joins in its destructor)
+    bool names_done = false;
+    dut::Thread names = dut::spawn_or_run([&]() { n_names = count_unique_names(rec, acc.data(), n_acc); names_done = true; });
     // One tile, no copy of the quality bytes: the records of the contig are pushed as they lie in
     // `rec`.  Reads the pileup would not hold (FUNMAP, the depth cap, reads without a reference span)
     // stay in the tile with their CIGAR operations rewritten to hard clips, which consume neither
     // reference nor query: they then touch no position and add to no sum.  Reads at or past
-    // contig_len (never yielded by the region fetch) are the sorted tail and are cut off, so are
-    // unaccepted reads in front of position 0.
-    uint64_t a0 = 0, n_keep = rec->n;
-    while (n_keep > 0 && (int64_t)rec->pos[n_keep - 1] >= (int64_t)contig_len) --n_keep;
+    // contig_len were cut off above, so are unaccepted reads in front of position 0.
     while (a0 < n_keep && rec->pos[a0] < 0 && !acc[a0]) ++a0;
     bool in_order = true;
     uint64_t n_in = 0;
@@ -602,6 +618,9 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     rc = cl_contig_finish(ctx, &sum, &iv, &niv);
     if (rc != CL_OK) return rc;
     dut_stage_time("upload + kernels + collect", tm);
+    if (names.joinable()) names.join();
+    if (!names_done) return CL_ERR_NOMEM;
+    dut_stage_time("wait for the name count", tm);
     for (int i = 0; i < 6; ++i) state_counts[i] = sum.state_counts[i];
     *intervals = iv; *n_intervals = niv;
     stats->length = contig_len;

@@ -2,8 +2,8 @@
 //
 // Data flow of one contig (all arrays resident in HBM, layouts in DESIGN.md section 3):
 //
-//   k_window_bounds  (once per upload / extent: an index of the resident layout, like the offsets) per window of
-//                    T reference positions the [lo,hi) range of reads that can touch it
+//   (host, at upload: per window of T reference positions the [lo,hi) range of reads that can touch it -- an
+//                    index of the resident layout, like the offsets; WinMeta below)
 //   k_read_prep      contigs of long-read shape only (the LONG variants of k_pileup): per read the CIGAR walk
 //                    -> end[r] and block partials of the per-read separable sums (contig_profiler.rs:74,79-82 via
 //                    SURVEY 8a-7); for short-read contigs k_pileup does this itself (the window that holds a
@@ -187,71 +187,17 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
     return a + (b << 24) + (c << 48);
 }
 
-// ---------------------------------------------------------------------------------------------
-// window_bounds: thread per window (the first workgroups of the k_read_prep launch: the searches are
-// latency bound and hide under the bandwidth-bound CIGAR pass); the candidate reads of every window (binary searches over the
-// sorted positions).
-// ---------------------------------------------------------------------------------------------
-// (A K-ary search that loads K-1 pivots per round was tried for fewer dependent loads: K = 4 and 16 were
-// both slower than this binary search, whose first dozen levels hit the same few lines for every thread.)
-__device__ __forceinline__ uint32_t lower_bound_pos(const int32_t *pos, uint32_t n, long long key)
-{
-    uint32_t lo = 0, hi = n;                       // first r with pos[r] >= key
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        if ((long long)pos[mid] < key) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-}
-
-// what k_pileup needs to start on a window: one 32-byte record, one scalar load
+// What k_pileup needs to start on a window: one 32-byte record, one scalar load.  The candidate reads of a window --
+// reads [lo, hi) with pos < W + T and pos + span_n > W (span_n: the longest ordinary span), and the wide reads (span >
+// kWideSpan) that start before them -- depend on the resident reads and the extent only: the host builds the records at
+// upload (callable_loci.hip: host_window_bounds), flags windows whose candidates' quality bytes do not fit 32-bit
+// offsets (kErrRange) and windows with more than 32 767 candidates (kNeedDeep: the 32-bit counter form).
 struct __attribute__((aligned(32))) WinMeta {
     uint32_t lo, hi;                   // ordinary candidates: reads [lo, hi)
     uint32_t wlo, wn;                  // wide candidates: wide_idx[wlo .. wlo+wn)
     unsigned long long q0;             // qual_off of the window's first candidate read
     uint32_t pad[2];
 };
-
-struct BoundsArgs {
-    uint32_t span_n, span_w;
-    const int32_t *wide_pos;
-    const uint32_t *wide_idx;
-    uint32_t n_wide, T, n_win;
-    WinMeta *win;
-    uint32_t *err_flag;
-};
-
-__device__ __forceinline__ void window_bounds(const Reads &R, const BoundsArgs &B, uint32_t w)
-{
-    const uint32_t span_n = B.span_n, span_w = B.span_w, n_wide = B.n_wide, T = B.T, n_win = B.n_win;
-    const int32_t *__restrict__ wide_pos = B.wide_pos;
-    const uint32_t *__restrict__ wide_idx = B.wide_idx;
-    uint32_t *__restrict__ err_flag = B.err_flag;
-    if (w >= n_win) return;
-    const long long W = (long long)w * T;
-    const uint32_t lo = lower_bound_pos(R.pos, R.n, W - (long long)span_n + 1);
-    const uint32_t hi = lower_bound_pos(R.pos, R.n, W + (long long)T);
-    uint32_t wlo = 0, wn = 0;
-    if (n_wide) {
-        wlo = lower_bound_pos(wide_pos, n_wide, W - (long long)span_w + 1);
-        wn = lower_bound_pos(wide_pos, n_wide, W - (long long)span_n + 1) - wlo;
-    }
-    const uint32_t first = wn ? wide_idx[wlo] : lo;     // lo <= n: the offsets array has n+1 entries
-    WinMeta m;
-    m.lo = lo; m.hi = hi; m.wlo = wlo; m.wn = wn; m.q0 = R.qual_off[first]; m.pad[0] = 0; m.pad[1] = 0;
-    B.win[w] = m;
-    // k_pileup addresses the quality bytes of a window with 32-bit offsets
-    if (hi > first && R.qual_off[hi] - R.qual_off[first] > 0xFFFF0000ull) atomicOr(err_flag, kErrRange);
-    // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
-    if ((hi - lo) + wn > 32767u) atomicOr(err_flag, kNeedDeep);
-}
-
-// The windows' candidate ranges depend on the resident reads and on the extent only: computed once per upload
-// (and again when the extent grows), not per run.
-__global__ __launch_bounds__(kBlock) void k_window_bounds(Reads R, BoundsArgs B)
-{
-    window_bounds(R, B, blockIdx.x * kBlock + threadIdx.x);
-}
 
 // ---------------------------------------------------------------------------------------------
 // k_read_prep: one thread per read (grid-stride).

@@ -125,8 +125,15 @@ cl_status cl_contig_begin(cl_ctx *ctx, int32_t tid, uint32_t contig_len,
 /* Optional size hint for the contig that was just begun: totals over all tiles that will be pushed.
  * Saves regrowing the staging / device buffers; never required. */
 cl_status cl_contig_reserve(cl_ctx *ctx, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes);
+/* Optional: starts sending quality bytes to the device before their tile is pushed, so that the transfer runs
+ * beside the caller's own work on the records (the host driver's read admission, say).  `qual` must be exactly
+ * the bytes the NEXT cl_push_reads will present (tile.qual + tile.qual_off[0], tile.qual_off[n] - tile.qual_off[0]
+ * of them) and must stay valid until that call returns; a push that presents anything else simply sends its own
+ * bytes (the prefetch is dropped).  Blocks of less than 4 MiB are ignored.  Never required. */
+cl_status cl_contig_prefetch_qual(cl_ctx *ctx, const uint8_t *qual, uint64_t n_bytes);
 /* Appends a tile (coordinate order across tiles).  The caller's buffers are free again on return:
- * small tiles are copied to host staging, the quality bytes of tiles of >= 4 MiB go straight to HBM. */
+ * small tiles are copied to host staging, the quality bytes of tiles of >= 4 MiB go to HBM through a pinned staging
+ * ring (the fills of the pinned buffers overlap the transfers). */
 cl_status cl_push_reads(cl_ctx *ctx, const cl_read_tile *tile);
 /* upload + run + collect in one call.  *intervals points at context-owned memory, valid until
  * the next cl_contig_begin / cl_destroy. */

@@ -11,10 +11,14 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -55,6 +59,63 @@ struct Range {
 #endif
 constexpr uint32_t kT = CL_WINDOW;
 
+// Host staging array of a trivially copyable type that grows without value-initialising what it adds (a contig's
+// per-read arrays are hundreds of megabytes: zero-filling them before they are overwritten showed) and appends in
+// parallel chunks.  Throws std::bad_alloc like a vector.
+template <typename T> struct RawVec {
+    T *p = nullptr;
+    size_t n = 0, cap = 0;
+    RawVec() = default;
+    RawVec(const RawVec &) = delete;
+    RawVec &operator=(const RawVec &) = delete;
+    ~RawVec() { free(p); }
+    size_t size() const { return n; }
+    bool empty() const { return n == 0; }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    const T &back() const { return p[n - 1]; }
+    void clear() { n = 0; }
+    void release() { free(p); p = nullptr; n = cap = 0; }
+    void reserve(size_t want)
+    {
+        if (want <= cap) return;
+        size_t nc = std::max(want, cap + cap / 2 + 16);
+        T *q = static_cast<T *>(realloc(p, nc * sizeof(T)));
+        if (!q) throw std::bad_alloc();
+        p = q; cap = nc;
+    }
+    void resize(size_t m) { reserve(m); n = m; }                 // new elements are NOT initialised
+    void push_back(const T &v) { reserve(n + 1); p[n++] = v; }
+    void append(const T *src, size_t m)                          // parallel copy
+    {
+        reserve(n + m);
+        T *dst = p + n;
+        const size_t grain = (4u << 20) / sizeof(T);
+        dut::parallel_for((m + grain - 1) / grain, 1, [&](size_t k) {
+            const size_t a = k * grain, b = std::min(m, a + grain);
+            memcpy(dst + a, src + a, (b - a) * sizeof(T));
+        });
+        n += m;
+    }
+};
+
+// DUT_TIMING=1: wall-clock of the engine's host stages on stderr (tooling; off by default)
+struct StageTimer {
+    bool on;
+    double t0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    StageTimer() : on(getenv("DUT_TIMING") && *getenv("DUT_TIMING") == '1'), t0(on ? now() : 0.0) {}
+    void lap(const char *what)
+    {
+        if (!on) return;
+        const double t1 = now();
+        fprintf(stderr, "[dut-timing]     engine: %-24s %8.1f ms\n", what, (t1 - t0) * 1e3);
+        t0 = t1;
+    }
+};
+
 template <typename T> struct DevBuf {
     T *p = nullptr;
     size_t cap = 0;     // elements
@@ -89,23 +150,69 @@ template <typename T> struct DevBuf {
 
 } // namespace
 
+// Pinned staging ring for host-to-device copies, one per device and process (its contexts share it; a transfer holds
+// it from start to finish): kCopyThreads host threads, each with its own stream and two pinned buffers; a thread fills
+// one buffer (memcpy from the caller's pageable memory, or records built in place) while the DMA of its other buffer
+// runs, so the link sees pinned memory only and the fills of all threads overlap all transfers.
+struct PinRing {
+    static constexpr int kCopyThreads = 8;
+    static constexpr size_t kPinBytes = 8u << 20;
+    int device = 0;
+    hipStream_t copy_stream[kCopyThreads] = {};
+    uint8_t *pin[kCopyThreads][2] = {};
+    hipEvent_t pin_ev[kCopyThreads][2] = {};
+    std::mutex busy;
+    bool ok = false;
+    explicit PinRing(int dev) : device(dev)
+    {
+        if (hipSetDevice(dev) != hipSuccess) return;
+        for (int t = 0; t < kCopyThreads; ++t) {
+            if (hipStreamCreateWithFlags(&copy_stream[t], hipStreamNonBlocking) != hipSuccess) return;
+            for (int b = 0; b < 2; ++b) {
+                if (hipHostMalloc(reinterpret_cast<void **>(&pin[t][b]), kPinBytes, hipHostMallocDefault) != hipSuccess) return;
+                if (hipEventCreateWithFlags(&pin_ev[t][b], hipEventDisableTiming) != hipSuccess) return;
+            }
+        }
+        ok = true;
+    }
+    ~PinRing()
+    {
+        (void)hipSetDevice(device);
+        for (int t = 0; t < kCopyThreads; ++t) {
+            for (int b = 0; b < 2; ++b) {
+                if (pin_ev[t][b]) (void)hipEventDestroy(pin_ev[t][b]);
+                if (pin[t][b]) (void)hipHostFree(pin[t][b]);
+            }
+            if (copy_stream[t]) (void)hipStreamDestroy(copy_stream[t]);
+        }
+    }
+    PinRing(const PinRing &) = delete;
+    PinRing &operator=(const PinRing &) = delete;
+};
+
+static std::shared_ptr<PinRing> acquire_ring(int device)
+{
+    static std::mutex mu;
+    static std::map<int, std::weak_ptr<PinRing>> rings;
+    std::lock_guard<std::mutex> g(mu);
+    std::shared_ptr<PinRing> r = rings[device].lock();
+    if (!r) {
+        r = std::make_shared<PinRing>(device);
+        if (!r->ok) return nullptr;
+        rings[device] = r;
+    }
+    return r;
+}
+
 struct cl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     uint64_t host_max_end = 0;         // largest pos + reference span over the pushed reads (32-bit clamped spans), for the extent
-    // Pinned staging ring for host-to-device copies: kCopyThreads host threads, each with its own stream and two
-    // pinned buffers; a thread fills one buffer (memcpy from the caller's pageable memory, or records built in
-    // place) while the DMA of its other buffer runs, so the link sees pinned memory only and the fills of all
-    // threads overlap all transfers.  Created on first use, kept for the context's life.
-    static constexpr int kCopyThreads = 8;
-    static constexpr size_t kPinBytes = 8u << 20;
-    hipStream_t copy_stream[kCopyThreads] = {};
-    uint8_t *pin[kCopyThreads][2] = {};
-    hipEvent_t pin_ev[kCopyThreads][2] = {};
-    bool pins_made = false;
+    std::shared_ptr<PinRing> ring;                    // the device's pinned staging ring (shared by its contexts)
     std::vector<dut::Thread> copiers;                 // a transfer in flight (joined by ring_finish)
-    hipError_t copy_err[kCopyThreads] = {};
+    hipError_t copy_err[PinRing::kCopyThreads] = {};
+    bool ring_held = false;                           // this context holds the ring's lock (ring_start .. ring_finish)
     // cl_contig_prefetch_qual: quality bytes on their way to d_qual + kQualPad + pf_off before their tile is pushed
     const uint8_t *pf_src = nullptr;
     uint64_t pf_n = 0, pf_off = 0;
@@ -120,12 +227,12 @@ struct cl_ctx {
     bool has_long = false;           // some read has more than kLongOps CIGAR ops (k_read_prep_long needed)
     int32_t tid = 0;
     uint32_t contig_len = 0;
-    std::vector<uint8_t> h_ref;
-    std::vector<int32_t> h_pos;
-    std::vector<uint8_t> h_mapq;
-    std::vector<uint32_t> h_cigar_off;
-    std::vector<uint32_t> h_cigar;
-    std::vector<unsigned long long> h_qual_off;
+    RawVec<uint8_t> h_ref;
+    RawVec<int32_t> h_pos;
+    RawVec<uint8_t> h_mapq;
+    RawVec<uint32_t> h_cigar_off;
+    RawVec<uint32_t> h_cigar;
+    RawVec<unsigned long long> h_qual_off;
     std::vector<uint8_t> h_qual;     // quality bytes of small tiles, not yet on the device
     uint64_t q_dev = 0;              // quality bytes of this contig that already are (d_qual + kQualPad ..)
     // reads whose reference span exceeds kWideSpan (ascending read index = ascending position)
@@ -230,15 +337,9 @@ void build_lut(double frac, std::vector<uint32_t> &lut)
 
 cl_status ensure_pins(cl_ctx *c)
 {
-    if (c->pins_made) return CL_OK;
-    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream[t], hipStreamNonBlocking));
-        for (int b = 0; b < 2; ++b) {
-            HIP_TRY(c, hipHostMalloc(reinterpret_cast<void **>(&c->pin[t][b]), cl_ctx::kPinBytes, hipHostMallocDefault));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->pin_ev[t][b], hipEventDisableTiming));
-        }
-    }
-    c->pins_made = true;
+    if (c->ring) return CL_OK;
+    c->ring = acquire_ring(c->device);
+    if (!c->ring) return fail(c, CL_ERR_DEVICE, "cannot create the pinned staging ring (hipHostMalloc)");
     return CL_OK;
 }
 
@@ -249,23 +350,26 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
 {
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
-    const uint64_t CH = cl_ctx::kPinBytes, nch = (n + CH - 1) / CH;
-    const int nt = (int)std::min<uint64_t>(cl_ctx::kCopyThreads, nch);
-    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
+    PinRing *R = c->ring.get();
+    R->busy.lock();                                       // another context of this device may be using the ring
+    c->ring_held = true;
+    const uint64_t CH = PinRing::kPinBytes, nch = (n + CH - 1) / CH;
+    const int nt = (int)std::min<uint64_t>(PinRing::kCopyThreads, nch);
+    for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
     for (int t = 0; t < nt; ++t) {
-        c->copiers.push_back(dut::spawn_or_run([c, dst, n, fill, t, nch, CH]() {
+        c->copiers.push_back(dut::spawn_or_run([c, R, dst, n, fill, t, nch, CH]() {
             hipError_t e = hipSetDevice(c->device);
             int k = 0;
-            for (uint64_t ch = (uint64_t)t; ch < nch && e == hipSuccess; ch += cl_ctx::kCopyThreads, ++k) {
+            for (uint64_t ch = (uint64_t)t; ch < nch && e == hipSuccess; ch += PinRing::kCopyThreads, ++k) {
                 const int b = k & 1;
                 const uint64_t off = ch * CH, len = std::min<uint64_t>(CH, n - off);
-                if (k >= 2) e = hipEventSynchronize(c->pin_ev[t][b]);          // the buffer's previous transfer is done
+                if (k >= 2) e = hipEventSynchronize(R->pin_ev[t][b]);           // the buffer's previous transfer is done
                 if (e != hipSuccess) break;
-                fill(off, len, c->pin[t][b]);
-                e = hipMemcpyAsync(dst + off, c->pin[t][b], len, hipMemcpyHostToDevice, c->copy_stream[t]);
-                if (e == hipSuccess) e = hipEventRecord(c->pin_ev[t][b], c->copy_stream[t]);
+                fill(off, len, R->pin[t][b]);
+                e = hipMemcpyAsync(dst + off, R->pin[t][b], len, hipMemcpyHostToDevice, R->copy_stream[t]);
+                if (e == hipSuccess) e = hipEventRecord(R->pin_ev[t][b], R->copy_stream[t]);
             }
-            const hipError_t e2 = hipStreamSynchronize(c->copy_stream[t]);
+            const hipError_t e2 = hipStreamSynchronize(R->copy_stream[t]);
             c->copy_err[t] = e != hipSuccess ? e : e2;
         }));
     }
@@ -275,7 +379,8 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
 cl_status ring_finish(cl_ctx *c)
 {
     c->copiers.clear();                                   // dut::Thread joins in its destructor
-    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) HIP_TRY(c, c->copy_err[t]);
+    if (c->ring_held) { c->ring_held = false; c->ring->busy.unlock(); }
+    for (int t = 0; t < PinRing::kCopyThreads; ++t) HIP_TRY(c, c->copy_err[t]);
     return CL_OK;
 }
 
@@ -550,7 +655,7 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepParts) == hipSuccess &&
               c->d_summary.reserve(1) == hipSuccess && c->d_errflag.reserve(2) == hipSuccess &&
               hipMemcpy(c->d_lut.p, lut.data(), kLutSize * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
-    if (!ok) { cl_destroy(c); return CL_ERR_DEVICE; }
+    if (!ok || ensure_pins(c) != CL_OK) { cl_destroy(c); return CL_ERR_DEVICE; }
     *out = c;
     return CL_OK;
 }
@@ -572,13 +677,7 @@ void cl_destroy(cl_ctx *c)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
     drop_prefetch(c);
-    for (int t = 0; t < cl_ctx::kCopyThreads; ++t) {
-        for (int b = 0; b < 2; ++b) {
-            if (c->pin_ev[t][b]) (void)hipEventDestroy(c->pin_ev[t][b]);
-            if (c->pin[t][b]) (void)hipHostFree(c->pin[t][b]);
-        }
-        if (c->copy_stream[t]) (void)hipStreamDestroy(c->copy_stream[t]);
-    }
+    c->ring.reset();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -594,9 +693,9 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     drop_prefetch(c);
     c->tid = tid; c->contig_len = contig_len;
     const uint64_t nref = std::min<uint64_t>(ref_len, contig_len);
-    c->h_ref.assign(ref_bases, ref_bases + nref);
+    c->h_ref.clear(); c->h_ref.append(ref_bases, nref);
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_qual.clear();
-    c->h_cigar_off.assign(1, 0u); c->h_qual_off.assign(1, 0ull);
+    c->h_cigar_off.clear(); c->h_cigar_off.push_back(0u); c->h_qual_off.clear(); c->h_qual_off.push_back(0ull);
     c->h_iv.clear();
     c->q_dev = 0;
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
@@ -717,6 +816,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         drop_prefetch(c);
     }
     const unsigned long long qbase = c->q_dev + c->h_qual.size();
+    StageTimer tmr;
 
     // ---- validation that protects the kernels' indexing, and the reference span of every read (what
     //      k_read_prep computes as end - pos): the longest ordinary span bounds every window's candidate
@@ -748,6 +848,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             else o.span_n = std::max(o.span_n, sp);
         }
     });
+    tmr.lap("push: validate + spans");
     for (const Chunk &o : ch) {                                // the first offence in tile order decides the message
         if (o.bad == 1) return fail(c, CL_ERR_INVALID, "read position outside [0, contig_len): the region fetch (mod.rs:53) never yields it");
         if (o.bad == 2) return fail(c, CL_ERR_UNSORTED, "reads are not coordinate sorted");
@@ -775,9 +876,9 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
             for (uint32_t i : o.longs) c->h_long_list.push_back((uint32_t)(rbase + i));
         }
-        c->h_pos.insert(c->h_pos.end(), t->pos, t->pos + n);
-        c->h_mapq.insert(c->h_mapq.end(), t->mapq, t->mapq + n);
-        c->h_cigar.insert(c->h_cigar.end(), t->cigar + cig0, t->cigar + cig0 + ncig);
+        c->h_pos.append(t->pos, n);
+        c->h_mapq.append(t->mapq, n);
+        c->h_cigar.append(t->cigar + cig0, ncig);
         if (!direct) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
         const size_t o0 = c->h_cigar_off.size();               // == rbase + 1: entry r+1 closes read r
         c->h_cigar_off.resize(o0 + n);
@@ -791,11 +892,13 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     } catch (const std::bad_alloc &) {
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
+    tmr.lap("push: stage small arrays");
     if (ring.active) {
         ring.active = false;
         cl_status rs = ring_finish(c);                         // a failed copy: the staged arrays are rolled back
         if (rs != CL_OK) return rs;
     }
+    tmr.lap("push: wait for the qualities");
     if (direct) c->q_dev += nq;
     undo.armed = false;
     return CL_OK;
@@ -827,6 +930,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     c->n_wide = (uint32_t)c->h_wide_idx.size();
     const size_t n = c->n_reads;
     const Variant vr = pick_variant(c);
+    StageTimer tmr0;
     // What the device needs of the per-read fields depends on the form of k_pileup the contig gets: the short-read form
     // reads one packed record per read; the long-read forms, k_read_prep and k_read_prep_long read the arrays as pushed.
     const bool need_soa = vr.lng || c->n_long > 0;
@@ -839,6 +943,8 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tmr0.lap("upload: device buffers");
+    StageTimer tmr;
     // everything goes through the pinned staging ring (pageable vectors -> pinned buffers -> HBM, the fills overlapping
     // the transfers)
     cl_status rs = CL_OK;
@@ -877,7 +983,9 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
     }
+    tmr.lap("upload: records");
     if ((rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
+    tmr.lap("upload: cigar");
     if (c->n_long) HIP_TRY(c, hipMemcpyAsync(c->d_long_list.p, c->h_long_list.data(), (size_t)c->n_long * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -889,17 +997,16 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // a read overhanging the contig end makes the reference walk (and classify as REF_N, mod.rs:100-101) positions
     // up to its end: the extent is known from the spans computed at cl_push_reads
+    tmr.lap("upload: small + sync");
     cl_status s = size_for_extent(c, (uint32_t)std::max<uint64_t>(c->contig_len, c->host_max_end));
     if (s != CL_OK) return s;
+    tmr.lap("upload: extent, ref, bounds");
     if (c->d_iv.cap == 0) HIP_TRY(c, c->d_iv.reserve(1u << 20));
-    // the staged copy is no longer needed
-    std::vector<int32_t>().swap(c->h_pos);
-    std::vector<uint8_t>().swap(c->h_mapq);
-    std::vector<uint32_t>().swap(c->h_cigar);
+    // The staged copy is no longer needed; its memory is kept for the context's next contig (giving back and
+    // re-faulting a few hundred megabytes per contig was a fifth of a contig's host time).  cl_destroy frees it.
+    c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     std::vector<uint8_t>().swap(c->h_qual);
-    std::vector<uint32_t>().swap(c->h_cigar_off);
-    std::vector<unsigned long long>().swap(c->h_qual_off);
-    std::vector<uint8_t>().swap(c->h_ref);
+    tmr.lap("upload: done");
     c->uploaded = true; c->ran = false;
     return CL_OK;
 }
@@ -944,6 +1051,7 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
     Range rg("cl_contig_collect");
     if (!c || !c->ran) return fail(c, CL_ERR_INVALID, "cl_contig_collect before cl_contig_run");
     HIP_TRY(c, hipSetDevice(c->device));
+    StageTimer tmr;
     // every `continue` below re-runs the contig for one distinct reason (32-bit counters: once; 16-bit fields in the
     // marked windows: the marks are sticky, at most twice; a larger extent: once per overhang level), so a handful of
     // rounds always suffices -- if they do not, the device state and h_sum disagree and nothing may be returned
@@ -981,6 +1089,7 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
         converged = true;
     }
     if (!converged) return fail(c, CL_ERR_DEVICE, "cl_contig_collect: the re-run loop (counter width / extent) did not converge");
+    tmr.lap("collect: kernels + summary");
     const size_t niv = c->h_sum.n_intervals;
     static_assert(sizeof(cl_interval) == sizeof(Interval), "interval layout");
     try { c->h_iv.resize(niv); } catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "interval buffer"); }
@@ -988,6 +1097,7 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
         HIP_TRY(c, hipMemcpyAsync(c->h_iv.data(), c->d_iv.p, niv * sizeof(Interval), hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
     }
+    tmr.lap("collect: intervals D2H");
     if (out) {
         static_assert(offsetof(DevSummary, max_end) == sizeof(cl_contig_summary), "summary layout");
         memcpy(out, &c->h_sum, sizeof(cl_contig_summary));
@@ -1129,34 +1239,56 @@ static cl_status cl_site_pileup_impl(cl_ctx *c, uint8_t min_quality, uint32_t co
             bucket[bk] = (uint32_t)j;
         }
     }
-    DevBuf<int32_t> d_pos; DevBuf<uint8_t> d_mapq, d_seq; DevBuf<uint32_t> d_coff, d_cig, d_p0, d_ix, d_hist, d_bk;
-    DevBuf<unsigned long long> d_soff;
+    // one packed record per read (+ the sentinel with the totals) and the 64-bit base offset of every workgroup's reads
+    const uint64_t n_blocks = (n + kBlock - 1) / kBlock;
+    std::unique_ptr<SiteRec[]> h_rec(new SiteRec[n + 1]);
+    std::unique_ptr<unsigned long long[]> h_base(new unsigned long long[n_blocks + 1]);
+    {
+        SiteRec *hr = h_rec.get();
+        unsigned long long *hb = h_base.get();
+        dut::parallel_for(n, 262144, [&](size_t i) {
+            const uint32_t nc = t->cigar_off[i + 1] - t->cigar_off[i];
+            const uint64_t sl = t->seq_off[i + 1] - t->seq_off[i];
+            SiteRec r;
+            r.pos = t->pos[i]; r.cigar_off = t->cigar_off[i]; r.seq_lo = (uint32_t)t->seq_off[i];
+            r.meta = (uint32_t)t->mapq[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<uint64_t>(sl, 0xFFFFull) << 16);
+            hr[i] = r;
+            if (i % kBlock == 0) hb[i / kBlock] = t->seq_off[i];
+        });
+        hr[n].pos = 0; hr[n].cigar_off = t->cigar_off[n]; hr[n].seq_lo = (uint32_t)t->seq_off[n]; hr[n].meta = 0;
+        hb[n_blocks] = t->seq_off[n];
+    }
+    // a workgroup's reads must lie within 2^32 bases of its first one (256 reads: always, short of 16 M-base reads)
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (t->seq_off[std::min<uint64_t>(n, (b + 1) * kBlock)] - t->seq_off[b * kBlock] > 0xFFFF0000ull)
+            return fail(c, CL_ERR_RANGE, "reads too long for the site pileup");
+    DevBuf<SiteRec> d_rec; DevBuf<uint8_t> d_seq; DevBuf<uint32_t> d_cig, d_p0, d_ix, d_hist, d_bk;
+    DevBuf<unsigned long long> d_base;
     cl_status rc = CL_OK;
-    auto cleanup = [&]() { d_pos.release(); d_mapq.release(); d_seq.release(); d_coff.release(); d_cig.release();
-                           d_p0.release(); d_ix.release(); d_hist.release(); d_soff.release(); d_bk.release(); };
+    auto cleanup = [&]() { d_rec.release(); d_seq.release(); d_cig.release(); d_p0.release(); d_ix.release(); d_hist.release();
+                           d_base.release(); d_bk.release(); };
 #define SITE_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = fail(c, CL_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); cleanup(); return rc; } } while (0)
-    SITE_TRY(d_pos.reserve(n)); SITE_TRY(d_mapq.reserve(n)); SITE_TRY(d_coff.reserve(n + 1)); SITE_TRY(d_soff.reserve(n + 1));
-    SITE_TRY(d_cig.reserve(ncig + 1)); SITE_TRY(d_seq.reserve((nbase + 1) / 2 + 1));
+#define SITE_RING(dst, src, bytes) do { rc = ring_copy(c, dst, src, bytes); if (rc != CL_OK) { cleanup(); return rc; } } while (0)
+    SITE_TRY(d_rec.reserve(n + 1)); SITE_TRY(d_base.reserve(n_blocks + 1));
+    SITE_TRY(d_cig.reserve(ncig + 8)); SITE_TRY(d_seq.reserve((nbase + 1) / 2 + 1));
     SITE_TRY(d_p0.reserve(pos0.size())); SITE_TRY(d_ix.reserve(pos0.size())); SITE_TRY(d_hist.reserve(n_sites * 16));
     SITE_TRY(d_bk.reserve(n_buckets));
-    SITE_TRY(hipMemcpy(d_bk.p, bucket.data(), (size_t)n_buckets * 4, hipMemcpyHostToDevice));
-    SITE_TRY(hipMemcpy(d_pos.p, t->pos, n * 4, hipMemcpyHostToDevice));
-    SITE_TRY(hipMemcpy(d_mapq.p, t->mapq, n, hipMemcpyHostToDevice));
-    SITE_TRY(hipMemcpy(d_coff.p, t->cigar_off, (n + 1) * 4, hipMemcpyHostToDevice));
-    SITE_TRY(hipMemcpy(d_soff.p, t->seq_off, (n + 1) * 8, hipMemcpyHostToDevice));
-    if (ncig) SITE_TRY(hipMemcpy(d_cig.p, t->cigar, ncig * 4, hipMemcpyHostToDevice));
-    if (nbase) SITE_TRY(hipMemcpy(d_seq.p, t->seq4, (nbase + 1) / 2, hipMemcpyHostToDevice));
-    SITE_TRY(hipMemcpy(d_p0.p, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice));
-    SITE_TRY(hipMemcpy(d_ix.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice));
     SITE_TRY(hipMemsetAsync(d_hist.p, 0, n_sites * 16 * 4, c->stream));
-    SiteReads R;
-    R.pos = d_pos.p; R.mapq = d_mapq.p; R.cigar_off = d_coff.p; R.cigar = d_cig.p; R.seq_off = d_soff.p;
-    R.seq4 = d_seq.p; R.n = (uint32_t)n;
-    const uint32_t grid = (uint32_t)std::min<uint64_t>((n + kBlock - 1) / kBlock, 8192);
+    SITE_RING(d_rec.p, h_rec.get(), (n + 1) * sizeof(SiteRec));
+    SITE_RING(d_base.p, h_base.get(), (n_blocks + 1) * sizeof(unsigned long long));
+    SITE_RING(d_cig.p, t->cigar, ncig * 4);
+    SITE_RING(d_seq.p, t->seq4, (nbase + 1) / 2);
+    SITE_RING(d_p0.p, pos0.data(), pos0.size() * 4);
+    SITE_RING(d_ix.p, idx.data(), idx.size() * 4);
+    SITE_RING(d_bk.p, bucket.data(), (size_t)n_buckets * 4);
+    SiteArgs A;
+    A.rec = d_rec.p; A.seq_base = d_base.p; A.cigar = d_cig.p; A.seq4 = d_seq.p; A.n = (uint32_t)n;
+    A.min_quality = min_quality; A.contig_len = contig_len; A.ref_len = ref_len;
+    A.sorted_pos0 = d_p0.p; A.sorted_idx = d_ix.p; A.bucket = d_bk.p; A.n_buckets = n_buckets; A.n_sites = (uint32_t)pos0.size();
+    A.hist = d_hist.p;
     if (!c->site_ev[0]) { SITE_TRY(hipEventCreate(&c->site_ev[0])); SITE_TRY(hipEventCreate(&c->site_ev[1])); }
     SITE_TRY(hipEventRecord(c->site_ev[0], c->stream));
-    hipLaunchKernelGGL(k_site_pileup, dim3(grid), dim3(kBlock), 0, c->stream, R, (uint32_t)min_quality, contig_len,
-                       (unsigned long long)ref_len, d_p0.p, d_ix.p, d_bk.p, n_buckets, (uint32_t)pos0.size(), d_hist.p);
+    hipLaunchKernelGGL(k_site_pileup, dim3((uint32_t)n_blocks), dim3(kBlock), 0, c->stream, A);
     SITE_TRY(hipGetLastError());
     SITE_TRY(hipEventRecord(c->site_ev[1], c->stream));
     SITE_TRY(hipMemcpyAsync(hist, d_hist.p, n_sites * 16 * 4, hipMemcpyDeviceToHost, c->stream));
@@ -1167,8 +1299,9 @@ static cl_status cl_site_pileup_impl(cl_ctx *c, uint8_t min_quality, uint32_t co
         c->site_ms = t;
         // 4-bit bases + per-read pos/mapq/offsets + CIGAR words read, the sites' positions /
         // indices read and their 16 counters written
-        c->site_bytes = (nbase + 1) / 2 + n * (4 + 1 + 4 + 8) + ncig * 4 + (uint64_t)pos0.size() * 8 + (uint64_t)n_sites * 64;
+        c->site_bytes = (nbase + 1) / 2 + n * sizeof(SiteRec) + ncig * 4 + (uint64_t)pos0.size() * 8 + (uint64_t)n_sites * 64;
     }
+#undef SITE_RING
 #undef SITE_TRY
     cleanup();
     return CL_OK;

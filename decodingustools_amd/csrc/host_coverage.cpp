@@ -13,6 +13,7 @@
 #include <cstring>
 #include <functional>
 #include <queue>
+#include <memory>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -110,11 +111,28 @@ struct dut_profiler {
     std::string out_dir;
     std::vector<PlotRange> ranges;
 
+    // The BED text is assembled in memory (a contig has hundreds of thousands of lines: one formatted-print call per
+    // line was a third of a contig's host time) and handed to the file a megabyte at a time.
+    std::string text;
+    static void put_u64(std::string &o, uint64_t v)
+    {
+        char d[20];
+        int n = 0;
+        do { d[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+        while (n) o.push_back(d[--n]);
+    }
+    void flush_text()
+    {
+        if (!text.empty()) { fwrite(text.data(), 1, text.size(), bed); text.clear(); }
+    }
     void write_state()                       // callable_profiler.rs:39-62
     {
         if (!has_state) return;
-        fprintf(bed, "%s\t%llu\t%llu\t%s\n", cur_contig.c_str(), (unsigned long long)cur_start,
-                (unsigned long long)cur_end, kStateNames[cur_state]);
+        text += cur_contig; text.push_back('\t');
+        put_u64(text, cur_start); text.push_back('\t');
+        put_u64(text, cur_end); text.push_back('\t');
+        text += kStateNames[cur_state]; text.push_back('\n');
+        if (text.size() >= (1u << 20)) flush_text();
         if (plots && (cur_state == CL_CALLABLE || cur_state == CL_POOR_MAPPING_QUALITY || cur_state == CL_REF_N))
             ranges.push_back({(uint32_t)cur_start, (uint32_t)cur_end, cur_state});      // `as u32`, :53-54
     }
@@ -260,7 +278,7 @@ int dut_profiler_finish_plot(dut_profiler *p, const char *contig, uint32_t conti
 void dut_profiler_free(dut_profiler *p)
 {
     if (!p) return;
-    if (p->bed) fclose(p->bed);
+    if (p->bed) { p->flush_text(); fclose(p->bed); }
     delete p;
 }
 
@@ -332,7 +350,8 @@ static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accept
         // the reads are split into classes by the top bits of a 64-bit hash of the name, every class gets its own
         // exact set (full comparison on a hash match), classes are counted in parallel and the counts add up
         if (rec->qname_off && nacc) {
-            std::vector<uint64_t> h(rec->n);
+            std::unique_ptr<uint64_t[]> h_buf(new uint64_t[rec->n]);
+            uint64_t *h = h_buf.get();
             NameSet hasher; hasher.rec = rec;
             dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = accepted[i] ? hasher.hash_of(i) : 0; });
             dut_stage_time("  admit: name hashes", tm);
@@ -407,7 +426,9 @@ static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t con
     };
     // reference spans of all reads up front, in parallel (the sequential rule below only compares numbers)
     double tm = dut_now();
-    std::vector<uint64_t> rlen(rec->n);
+    // (not value-initialised: the pages are first touched by the threads that fill them)
+    std::unique_ptr<uint64_t[]> rlen_buf(new uint64_t[rec->n ? rec->n : 1]);
+    uint64_t *rlen = rlen_buf.get();
     dut::parallel_for(rec->n, 65536, [&](size_t i) { rlen[i] = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]); });
     dut_stage_time("  admit: spans", tm);
     bool any_pushed = false;

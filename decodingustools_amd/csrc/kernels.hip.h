@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         consume_list(n_keep);
         sumq += sq32; sq32 = 0;
     }
-    if constexpr (LONG == 4) {
+    if constexpr (LONG == 4) {                      // ... and the unit entries still listed
         if (n_ul) { consume_units(n_ul); n_ul = 0; sumq += sq32; sq32 = 0; }
     }
     __syncthreads();
@@ -1623,59 +1623,122 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
 }
 
 // ---------------------------------------------------------------------------------------------
-// config 5: site-list pileup (src/haplogroup/caller.rs:62-152).  Thread per read; for every
-// M/=/X base whose 1-based position is a listed site, hist[site][4-bit code] += 1.
-// sorted_pos0 / sorted_idx: the sites sorted by 0-based position and their original indices;
-// bucket[b]: index of the first sorted site with position >= 256*b.
+// config 5: site-list pileup (src/haplogroup/caller.rs:62-152): for every M/=/X base of a read with
+// mapq >= min_quality whose 1-based position is a listed site, hist[site][4-bit base code] += 1.
+//
+// sorted_pos0 / sorted_idx: the sites sorted by 0-based position and their original indices; bucket[b]: index of
+// the first sorted site with position >= 256*b.  One packed record per read (built on the host per call, like
+// ReadRec): pos, CIGAR offset, low half of the base offset (the full offset = the block's 64-bit base + the 32-bit
+// difference), mapq | n_cigar << 8 | n_bases << 16 with 255 / 0xFFFF meaning "the next record's offsets".
+//
+// A workgroup takes 256 consecutive reads.  A thread walks its read's first four CIGAR words (one 16-byte load) for
+// the reference span and leaves at once when no site lies inside it (three reads in five at one site per ~300
+// bases: no per-operation walk, no base is touched); hits go to a histogram of the workgroup's own sites in LDS
+// (the reads are sorted, so they share a handful of sites) which is added to the global one once at the end --
+// hits outside that range (unsorted input, a very long read) add to the global histogram directly.
 // ---------------------------------------------------------------------------------------------
-struct SiteReads {
-    const int32_t  *pos;
-    const uint8_t  *mapq;
-    const uint32_t *cigar_off;
-    const uint32_t *cigar;
-    const unsigned long long *seq_off;
+struct __attribute__((aligned(16))) SiteRec {
+    int32_t  pos;
+    uint32_t cigar_off;
+    uint32_t seq_lo;
+    uint32_t meta;
+};
+constexpr int kSiteLds = 64;            // sites a workgroup privatises
+
+struct SiteArgs {
+    const SiteRec *rec;                 // n + 1
+    const unsigned long long *seq_base; // per workgroup of kBlock reads: base offset (in bases) of its first read
+    const uint32_t *cigar;              // padded by 8 words
     const uint8_t  *seq4;
     uint32_t n;
+    uint32_t min_quality, contig_len;
+    unsigned long long ref_len;
+    const uint32_t *sorted_pos0, *sorted_idx, *bucket;
+    uint32_t n_buckets, n_sites;
+    uint32_t *hist;
 };
 
-__global__ __launch_bounds__(kBlock) void k_site_pileup(SiteReads R, uint32_t min_quality, uint32_t contig_len,
-                                                         unsigned long long ref_len,
-                                                         const uint32_t *__restrict__ sorted_pos0,
-                                                         const uint32_t *__restrict__ sorted_idx,
-                                                         const uint32_t *__restrict__ bucket,
-                                                         uint32_t n_buckets, uint32_t n_sites,
-                                                         uint32_t *__restrict__ hist)
+__global__ __launch_bounds__(kBlock) void k_site_pileup(SiteArgs a)
 {
-    for (uint32_t r = blockIdx.x * kBlock + threadIdx.x; r < R.n; r += gridDim.x * kBlock) {
-        if ((uint32_t)R.pos[r] >= contig_len) continue;          // fetch("chr:1-len"), caller.rs:33-36
-        if ((uint32_t)R.mapq[r] < min_quality) continue;         // caller.rs:80
-        unsigned long long x = (uint32_t)R.pos[r];
-        unsigned long long y = 0;
-        const unsigned long long s0 = R.seq_off[r], slen = R.seq_off[r + 1] - s0;
-        for (uint32_t k = R.cigar_off[r]; k < R.cigar_off[r + 1]; ++k) {
-            const uint32_t c = R.cigar[k], op = c & 15u, l = c >> 4;
-            if (op_match(op)) {
-                // sites with 0-based position in [x, x+l): bucket[b] = first site with position >= 256*b
-                const unsigned long long bx = x >> 8;
-                uint32_t lo = bx < n_buckets ? bucket[bx] : n_sites;
-                while (lo < n_sites && sorted_pos0[lo] < x) ++lo;
-                for (; lo < n_sites && sorted_pos0[lo] < x + l; ++lo) {
-                    const unsigned long long p = sorted_pos0[lo];
-                    const unsigned long long qi = y + (p - x);
-                    if (qi < slen && p < ref_len) {               // caller.rs:105,110-113
-                        const unsigned long long bi = s0 + qi;
-                        const uint32_t byte = R.seq4[bi >> 1];
-                        const uint32_t code = (bi & 1ull) ? (byte & 15u) : (byte >> 4);
-                        atomicAdd(&hist[(unsigned long long)sorted_idx[lo] * 16ull + code], 1u);
+    __shared__ uint32_t s_hist[kSiteLds * 16];
+    __shared__ uint32_t s_first;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t r0 = blockIdx.x * kBlock;
+    for (uint32_t i = tid; i < (uint32_t)kSiteLds * 16u; i += kBlock) s_hist[i] = 0;
+    auto first_site_at = [&](unsigned long long x) {             // first sorted site with position >= x
+        const unsigned long long bx = x >> 8;
+        uint32_t lo = bx < a.n_buckets ? a.bucket[bx] : a.n_sites;
+        while (lo < a.n_sites && a.sorted_pos0[lo] < x) ++lo;
+        return lo;
+    };
+    if (tid == 0) {
+        const int32_t p0 = a.rec[r0].pos;
+        s_first = first_site_at(p0 < 0 ? 0ull : (unsigned long long)p0);
+    }
+    __syncthreads();
+    const uint32_t first = s_first;
+    const uint32_t r = r0 + tid;
+    if (r < a.n) {
+        const uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
+        const uint32_t mq = rr.w & 255u;
+        // fetch("chr:1-len"), caller.rs:33-36; the mapping-quality gate, caller.rs:80
+        if ((uint32_t)rr.x < a.contig_len && mq >= a.min_quality) {
+            uint32_t k = rr.y, k1 = k + ((rr.w >> 8) & 255u);
+            unsigned long long slen = rr.w >> 16;
+            if (((rr.w >> 8) & 255u) == 255u || slen == 0xFFFFull) {
+                const uint4 nx = *reinterpret_cast<const uint4 *>(a.rec + r + 1);
+                k1 = nx.y; slen = (uint32_t)(nx.z - rr.z);
+            }
+            const unsigned long long base = a.seq_base[blockIdx.x];
+            const unsigned long long s0 = base + (uint32_t)(rr.z - (uint32_t)base);
+            Q16 c4;
+            __builtin_memcpy(&c4, a.cigar + k, 16);
+            const uint32_t n = k1 - k;
+            unsigned long long x = (uint32_t)rr.x, reflen = 0;
+#pragma unroll
+            for (uint32_t d = 0; d < 4u; ++d) {
+                const uint32_t c = d < n ? c4.w[d] : 5u;
+                reflen += ((0x18Du >> (c & 15u)) & 1u) ? (c >> 4) : 0u;
+            }
+            for (uint32_t kk = k + 4u; kk < k1; ++kk) {
+                const uint32_t c = a.cigar[kk];
+                reflen += ((0x18Du >> (c & 15u)) & 1u) ? (c >> 4) : 0u;
+            }
+            uint32_t lo = first_site_at(x);
+            if (lo < a.n_sites && a.sorted_pos0[lo] < x + reflen) {      // some site inside the read's span: walk it
+                unsigned long long y = 0;
+                for (uint32_t kk = k; kk < k1; ++kk) {
+                    const uint32_t d = kk - k;
+                    const uint32_t c = d == 0 ? c4.w[0] : d == 1 ? c4.w[1] : d == 2 ? c4.w[2] : d == 3 ? c4.w[3] : a.cigar[kk];
+                    const uint32_t op = c & 15u, l = c >> 4;
+                    if (op_match(op)) {
+                        while (lo < a.n_sites && a.sorted_pos0[lo] < x) ++lo;
+                        for (; lo < a.n_sites && a.sorted_pos0[lo] < x + l; ++lo) {
+                            const unsigned long long p = a.sorted_pos0[lo];
+                            const unsigned long long qi = y + (p - x);
+                            if (qi < slen && p < a.ref_len) {           // caller.rs:105,110-113
+                                const unsigned long long bi = s0 + qi;
+                                const uint32_t byte = a.seq4[bi >> 1];
+                                const uint32_t code = (bi & 1ull) ? (byte & 15u) : (byte >> 4);
+                                const uint32_t slot = lo - first;       // below `first`: wraps, goes to the global one
+                                if (slot < (uint32_t)kSiteLds) atomicAdd(&s_hist[slot * 16u + code], 1u);
+                                else atomicAdd(&a.hist[(unsigned long long)a.sorted_idx[lo] * 16ull + code], 1u);
+                            }
+                        }
+                        x += l; y += l;
+                    } else if (op_del(op)) {
+                        x += l;
+                    } else if (op_ins(op)) {
+                        y += l;
                     }
                 }
-                x += l; y += l;
-            } else if (op_del(op)) {
-                x += l;
-            } else if (op_ins(op)) {
-                y += l;
             }
         }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)kSiteLds * 16u; i += kBlock) {
+        const uint32_t v = s_hist[i], si = first + (i >> 4);
+        if (v && si < a.n_sites) atomicAdd(&a.hist[(unsigned long long)a.sorted_idx[si] * 16ull + (i & 15u)], v);
     }
 }
 

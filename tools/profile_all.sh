@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: the un-profiled bench line, then one rocprofv3 pass per counter group (never combined).
 mkdir -p gpurun_out
-timeout -k 10 600 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 1500 gpurun_out/bench_final.json
+timeout -k 10 900 python bench.py > gpurun_out/bench_final.json 2> gpurun_out/bench_final.err; tail -c 1500 gpurun_out/bench_final.json
 tools/rocprof_pass.sh trace --kernel-trace --stats > /dev/null && echo trace ok
 tools/rocprof_pass.sh fetch --pmc FETCH_SIZE > /dev/null && echo fetch ok
 tools/rocprof_pass.sh write --pmc WRITE_SIZE > /dev/null && echo write ok

@@ -540,8 +540,9 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 #ifndef CL_MINWAVES
 #define CL_MINWAVES 8
 #endif
+
 template <int T, bool DEBUG, bool ORF, bool DEEP, int LONG>
-__global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
+__global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4 : CL_MINWAVES)) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
@@ -658,7 +659,11 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG) ? 4 : CL_MINWAVES) void k_pi
         constexpr int UPL = decltype(upl_tag)::value;
         const uint32_t Q = (n_use + 15u) >> 4;
         for (uint32_t i = 0; i < Q; ++i) {
+#ifdef CL_QUAD_INTERLEAVE                                    /* timing experiment: neighbouring reads in the same trip */
+            const uint32_t idx = i * 16u + quad;
+#else
             const uint32_t idx = quad * Q + i;
+#endif
             uint2 d = make_uint2(0u, 0u);
             if (idx < n_use) d = list[idx];
             const SegView sv = seg_view(d, ql);

@@ -32,6 +32,7 @@ extern "C" {
     pub fn cl_last_error(ctx: *const ClCtx) -> *const c_char;
     pub fn cl_contig_begin(ctx: *mut ClCtx, tid: i32, contig_len: u32, ref_bases: *const u8, ref_len: u64) -> c_int;
     pub fn cl_contig_reserve(ctx: *mut ClCtx, n_reads: u64, n_cigar_ops: u64, n_qual_bytes: u64) -> c_int; // optional hint
+    pub fn cl_contig_prefetch_qual(ctx: *mut ClCtx, qual: *const u8, n_bytes: u64) -> c_int;             // optional overlap
     pub fn cl_push_reads(ctx: *mut ClCtx, tile: *const ClReadTile) -> c_int;
     pub fn cl_contig_finish(ctx: *mut ClCtx, out: *mut ClContigSummary,
                             iv: *mut *const ClInterval, n_iv: *mut usize) -> c_int;

@@ -223,3 +223,45 @@ def test_resident_shard_steps_and_gathers_summaries_through_rccl(tmp_path):
         shard.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_long_read_chrY_full_size_properties_and_oracle_windows(tmp_path):
+    """BASELINE.json configs[2] at full size (chrY-shaped 57.2 Mb, 50x, 1-60 kb reads with an indel every ~15 bases:
+    354 M CIGAR operations): the size-independent properties of the result and per-position counters / states against
+    the oracle on windows (the oracle gets the reads that can reach the window: those starting within the longest
+    reference span before it)."""
+    L = 57_227_415
+    seed = synth.seed_for(3, 23)
+    rec = synth.long_read_contig(L, 50, seed)
+    ref = synth.make_reference(L, seed)
+    opt = CallableOptions()
+    acc, n_names = admit_reads(opt, 23, L, rec)
+    with Engine(opt, 0) as eng:
+        counter = CallableProfiler(str(tmp_path / "g.bed"))
+        st = ContigProfiler("chrY", L)
+        process_single_contig(eng, counter, st, opt, 23, rec, ref)
+        counts = counter.get_contig_counts("chrY")
+        counter.close()
+        r1 = eng.contig_collect()
+        eng.contig_run()
+        r2 = eng.contig_collect()
+        raw, qc, low, state = eng.debug_depths(L)
+    assert r1.as_dict() == r2.as_dict() and np.array_equal(r1.intervals, r2.intervals)        # idempotent re-run
+    _property_checks("chrY", L, rec, ref, opt, acc, n_names, st, counts, r1.intervals)
+    assert np.bincount(state, minlength=6).tolist() == counts
+    assert st.summed_coverage == int(raw.astype(np.int64).sum()) and st.n_covered_bases == int(np.count_nonzero(raw))
+    assert st.quality_bases == int(qc.astype(np.int64).sum()) and np.all(qc <= raw) and np.all(low <= raw)
+    # the longest reference span of a read bounds how far before a window a read that reaches it can start
+    ops = rec.cigar & 15
+    cs = np.concatenate([[0], np.cumsum(np.where(np.isin(ops, [0, 2, 3, 7, 8]), (rec.cigar >> 4).astype(np.int64), 0))])
+    span = cs[rec.cigar_off[1:].astype(np.int64)] - cs[rec.cigar_off[:-1].astype(np.int64)]
+    margin = int(span.max()) + 1
+    rng = np.random.default_rng(7)
+    for a in rng.integers(200_000, L - 300_000, size=3).tolist() + [0, L - 40_000]:
+        b = min(a + 40_000, L)
+        sub = _window_records(rec, a, b, margin=margin)
+        prof = oracle.Profiler(str(tmp_path / "s.bed"))
+        _, d = oracle.process_single_contig(prof, make_options({}), "chrY", 23, b, ref[:b], sub, dump=True)
+        prof.close()
+        for nm, arr_o, arr_g in (("raw", d[0], raw), ("qc", d[1], qc), ("low", d[2], low), ("state", d[3], state)):
+            assert np.array_equal(arr_o[a:b], arr_g[a:b]), (nm, a)

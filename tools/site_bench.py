@@ -17,4 +17,5 @@ for i in range(3):
     t0 = time.perf_counter()
     hist = eng.site_pileup(20, L, L, rec, sites)
     dt = time.perf_counter() - t0
-    print(json.dumps(dict(call_s=round(dt, 4), sites_hit=int((hist.sum(1) > 0).sum()), total=int(hist.sum()))), flush=True)
+    kms, nb = eng.site_pileup_stats()
+    print(json.dumps(dict(call_s=round(dt, 4), kernel_ms=round(kms, 4), gb_s=round(nb / kms / 1e6, 1), sites_hit=int((hist.sum(1) > 0).sum()), total=int(hist.sum()))), flush=True)

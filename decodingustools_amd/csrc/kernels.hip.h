@@ -921,7 +921,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                 bool on = tb + g < nb;
                 if (on) locate(tb + g, cur);
                 request(cur, on, cw_c, cx_c, cy_c);
-                while (tb < nb) {                                     // wave-uniform
+                while (tb < nb && !(a.ablate & 8u)) {               // wave-uniform (bit 8: timing experiment, no trips)
                     const uint32_t tbn = tb + 4u * (uint32_t)kWaves;
                     const bool on_n = tbn + g < nb;
                     if (on_n) locate(tbn + g, nxt);

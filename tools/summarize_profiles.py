@@ -27,8 +27,14 @@ json.dump(summ, open(os.path.join(P, f"{tag}_pmc_summary.json"), "w"), indent=1)
 pile = [v for k, v in summ.items() if "k_pileup" in k]
 if pile and "FETCH_SIZE" in pile[0] and "WRITE_SIZE" in pile[0]:
     f_kb, w_kb = pile[0]["FETCH_SIZE"], pile[0]["WRITE_SIZE"]
-    json.dump({"k_pileup_hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024),
-               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py --steps 5 --warmup 2 --cpu-sample 0; "
+    import subprocess
+    try:
+        build = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+    except Exception:
+        build = None
+    json.dump({"k_pileup_hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "build": build, "round": tag,
+               "workload": "chr21 30x (bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-secondary --min-time 0)",
+               "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py; "
                       "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a wide streaming read)",
                "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb}, open(os.path.join(P, "traffic.json"), "w"), indent=1)
 b = os.path.join(G, "bench_final.json")

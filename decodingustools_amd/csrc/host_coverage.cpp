@@ -341,8 +341,20 @@ static void dut_stage_time(const char *what, double &t0)
     t0 = t1;
 }
 
-// distinct read names among the accepted reads (contig_profiler.rs:54-57: the HashSet of qnames), exactly
-static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accepted, uint64_t nacc)
+// 64-bit hashes of every record's name (not value-initialised: first touched by the threads that fill it)
+static std::unique_ptr<uint64_t[]> hash_all_names(const dut_records *rec)
+{
+    std::unique_ptr<uint64_t[]> h_buf(new uint64_t[rec->n ? rec->n : 1]);
+    if (!rec->qname_off) return h_buf;
+    uint64_t *h = h_buf.get();
+    NameSet hasher; hasher.rec = rec;
+    dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = hasher.hash_of(i); });
+    return h_buf;
+}
+
+// distinct read names among the accepted reads (contig_profiler.rs:54-57: the HashSet of qnames), exactly.
+// h: the names' hashes (hash_all_names), which do not depend on the admission and can be had beside it.
+static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accepted, uint64_t nacc, const uint64_t *h)
 {
     double tm = dut_now();
     uint64_t total = 0;
@@ -350,11 +362,6 @@ static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accept
         // the reads are split into classes by the top bits of a 64-bit hash of the name, every class gets its own
         // exact set (full comparison on a hash match), classes are counted in parallel and the counts add up
         if (rec->qname_off && nacc) {
-            std::unique_ptr<uint64_t[]> h_buf(new uint64_t[rec->n]);
-            uint64_t *h = h_buf.get();
-            NameSet hasher; hasher.rec = rec;
-            dut::parallel_for(rec->n, 65536, [&](size_t i) { h[i] = accepted[i] ? hasher.hash_of(i) : 0; });
-            dut_stage_time("  admit: name hashes", tm);
             // the accepted reads are bucketed by the top bits of their hash (counting sort: per-chunk histograms,
             // offsets, scatter -- all parallel); every class then has a few thousand names and a table that
             // stays in cache
@@ -377,7 +384,8 @@ static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accept
                 }
                 cstart[kClasses] = run;
             }
-            std::vector<uint32_t> order(nacc);                // read indices, class by class (the host refuses >= 2^29 reads per contig)
+            std::unique_ptr<uint32_t[]> order_buf(new uint32_t[nacc]);     // read indices, class by class (the host refuses >= 2^29 reads per contig)
+            uint32_t *order = order_buf.get();
             dut::parallel_for(nchunk, 1, [&](size_t c) {
                 uint32_t *hc = hist.data() + c * kClasses;
                 const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
@@ -517,7 +525,10 @@ static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t con
     }
     dut_stage_time("  admit: cap rule", tm);
     if (n_accepted) *n_accepted = nacc;
-    if (n_unique_names) *n_unique_names = count_unique_names(rec, accepted, nacc);
+    if (n_unique_names) {
+        const std::unique_ptr<uint64_t[]> h = hash_all_names(rec);
+        *n_unique_names = count_unique_names(rec, accepted, nacc, h.get());
+    }
     return CL_OK;
 }
 
@@ -566,13 +577,22 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     }
     std::vector<uint8_t> acc(rec->n ? rec->n : 1);
     uint32_t n_names = 0; uint64_t n_acc = 0;
+    // the names' hashes do not depend on the admission: beside it, on their own thread
+    std::unique_ptr<uint64_t[]> name_hash;
+    bool hashed = false;
+    dut::Thread hasher = dut::spawn_or_run([&]() { name_hash = hash_all_names(rec); hashed = true; });
     rc = dut_admit_reads(opt, tid, contig_len, rec, acc.data(), nullptr, &n_acc);
     if (rc != CL_OK) return rc;
     dut_stage_time("admit", tm);
     // the distinct-name count is needed at the very end only: on its own thread beside the push, the kernels and the
     // read-back (joined before this function returns, also on every error path: dut::Thread joins in its destructor)
     bool names_done = false;
-    dut::Thread names = dut::spawn_or_run([&]() { n_names = count_unique_names(rec, acc.data(), n_acc); names_done = true; });
+    dut::Thread names = dut::spawn_or_run([&]() {
+        if (hasher.joinable()) hasher.join();
+        if (!hashed) return;
+        n_names = count_unique_names(rec, acc.data(), n_acc, name_hash.get());
+        names_done = true;
+    });
     // One tile, no copy of the quality bytes: the records of the contig are pushed as they lie in
     // `rec`.  Reads the pileup would not hold (FUNMAP, the depth cap, reads without a reference span)
     // stay in the tile with their CIGAR operations rewritten to hard clips, which consume neither

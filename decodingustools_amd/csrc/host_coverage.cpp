@@ -354,55 +354,90 @@ static std::unique_ptr<uint64_t[]> hash_all_names(const dut_records *rec)
 
 // distinct read names among the accepted reads (contig_profiler.rs:54-57: the HashSet of qnames), exactly.
 // h: the names' hashes (hash_all_names), which do not depend on the admission and can be had beside it.
+//
+// The accepted reads are partitioned by the top bits of their hash -- per-chunk histograms, offsets, scatter, all
+// parallel -- and the scatter moves the names themselves: every class gets its hashes and its names as contiguous
+// arrays (a few thousand names, some tens of kilobytes), so that the exact set of a class (open addressing on the
+// hash, full comparison of the bytes on a hash match) works in cache instead of reaching into the contig's name
+// array at random twice per insert.  Classes are counted in parallel and the counts add up.
 static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accepted, uint64_t nacc, const uint64_t *h)
 {
     double tm = dut_now();
-    uint64_t total = 0;
+    if (!rec->qname_off || !nacc) return 0;
+    const int bits = nacc > (1u << 22) ? 12 : (nacc > (1u << 16) ? 8 : 0);
+    const size_t kClasses = (size_t)1 << bits;
+    const size_t grain = 1u << 18, nchunk = (rec->n + grain - 1) / grain;
+    auto cls = [&](uint64_t hv) -> size_t { return bits ? (size_t)(hv >> (64 - bits)) : 0; };
+    // reads and name bytes per (chunk, class)
+    std::vector<uint32_t> cnt(nchunk * kClasses, 0);
+    std::vector<uint64_t> byt(nchunk * kClasses, 0);
+    dut::parallel_for(nchunk, 1, [&](size_t c) {
+        uint32_t *cc = cnt.data() + c * kClasses;
+        uint64_t *bc = byt.data() + c * kClasses;
+        const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
+        for (size_t i = c * grain; i < b; ++i)
+            if (accepted[i]) { const size_t k = cls(h[i]); cc[k] += 1; bc[k] += rec->qname_off[i + 1] - rec->qname_off[i]; }
+    });
+    // class-major, chunk-minor exclusive prefixes: where chunk c writes its reads / bytes of class k
+    std::vector<uint64_t> rstart(kClasses + 1, 0), bstart(kClasses + 1, 0);
+    std::vector<uint64_t> roff(nchunk * kClasses), boff(nchunk * kClasses);
     {
-        // the reads are split into classes by the top bits of a 64-bit hash of the name, every class gets its own
-        // exact set (full comparison on a hash match), classes are counted in parallel and the counts add up
-        if (rec->qname_off && nacc) {
-            // the accepted reads are bucketed by the top bits of their hash (counting sort: per-chunk histograms,
-            // offsets, scatter -- all parallel); every class then has a few thousand names and a table that
-            // stays in cache
-            const int bits = nacc > (1u << 22) ? 12 : (nacc > (1u << 16) ? 8 : 0);
-            const size_t kClasses = (size_t)1 << bits;
-            const size_t grain = 1u << 18, nchunk = (rec->n + grain - 1) / grain;
-            auto cls = [&](uint64_t hv) -> size_t { return bits ? (size_t)(hv >> (64 - bits)) : 0; };
-            std::vector<uint32_t> hist(nchunk * kClasses, 0);
-            dut::parallel_for(nchunk, 1, [&](size_t c) {
-                uint32_t *hc = hist.data() + c * kClasses;
-                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
-                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) hc[cls(h[i])] += 1;
-            });
-            std::vector<uint64_t> cstart(kClasses + 1, 0);
-            {   // class-major, chunk-minor exclusive prefix: hist[c][k] becomes the write offset of chunk c in class k
-                uint64_t run = 0;
-                for (size_t k = 0; k < kClasses; ++k) {
-                    cstart[k] = run;
-                    for (size_t c = 0; c < nchunk; ++c) { const uint32_t v = hist[c * kClasses + k]; hist[c * kClasses + k] = (uint32_t)(run - cstart[k]); run += v; }
-                }
-                cstart[kClasses] = run;
-            }
-            std::unique_ptr<uint32_t[]> order_buf(new uint32_t[nacc]);     // read indices, class by class (the host refuses >= 2^29 reads per contig)
-            uint32_t *order = order_buf.get();
-            dut::parallel_for(nchunk, 1, [&](size_t c) {
-                uint32_t *hc = hist.data() + c * kClasses;
-                const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
-                for (size_t i = c * grain; i < b; ++i) if (accepted[i]) { const size_t k = cls(h[i]); order[cstart[k] + hc[k]++] = (uint32_t)i; }
-            });
-            std::vector<uint64_t> per(kClasses, 0);
-            dut::parallel_for(kClasses, 16, [&](size_t k) {
-                const uint64_t a = cstart[k], b = cstart[k + 1];
-                if (a == b) return;
-                NameSet set; set.rec = rec; set.presize(b - a);
-                for (uint64_t q = a; q < b; ++q) set.insert_hashed(order[q], h[order[q]]);
-                per[k] = set.count;
-            });
-            for (uint64_t v : per) total += v;
-            dut_stage_time("  admit: name sets", tm);
+        uint64_t rr = 0, bb = 0;
+        for (size_t k = 0; k < kClasses; ++k) {
+            rstart[k] = rr; bstart[k] = bb;
+            for (size_t c = 0; c < nchunk; ++c) { roff[c * kClasses + k] = rr; boff[c * kClasses + k] = bb; rr += cnt[c * kClasses + k]; bb += byt[c * kClasses + k]; }
         }
+        rstart[kClasses] = rr; bstart[kClasses] = bb;
     }
+    const uint64_t total_bytes = bstart[kClasses];
+    std::unique_ptr<uint64_t[]> ch_buf(new uint64_t[nacc]);               // hashes, class by class
+    std::unique_ptr<uint64_t[]> cn_buf(new uint64_t[nacc + 1]);           // offsets of the names in cbytes (global)
+    std::unique_ptr<uint8_t[]> cb_buf(new uint8_t[total_bytes ? total_bytes : 1]);
+    uint64_t *ch = ch_buf.get(), *cn = cn_buf.get();
+    uint8_t *cb = cb_buf.get();
+    dut::parallel_for(nchunk, 1, [&](size_t c) {
+        uint64_t *ro = roff.data() + c * kClasses, *bo = boff.data() + c * kClasses;
+        const size_t b = std::min<size_t>(rec->n, (c + 1) * grain);
+        for (size_t i = c * grain; i < b; ++i) {
+            if (!accepted[i]) continue;
+            const size_t k = cls(h[i]);
+            const uint32_t nl = rec->qname_off[i + 1] - rec->qname_off[i];
+            ch[ro[k]] = h[i]; cn[ro[k]] = bo[k];
+            memcpy(cb + bo[k], rec->qname + rec->qname_off[i], nl);
+            ro[k] += 1; bo[k] += nl;
+        }
+    });
+    dut_stage_time("  names: partition", tm);
+    std::vector<uint64_t> per(kClasses, 0);
+    dut::parallel_for(kClasses, 16, [&](size_t k) {
+        const uint64_t a = rstart[k], b = rstart[k + 1];
+        if (a == b) return;
+        const uint64_t bend = bstart[k + 1];
+        size_t cap = 1024;
+        while (cap < (b - a) * 2 + 2) cap *= 2;
+        std::vector<uint64_t> th(cap, 0);                                  // hash per slot (0 = empty; hashes are never 0)
+        std::vector<uint32_t> ti(cap, 0);                                  // class-local index of the slot's name
+        uint64_t distinct = 0;
+        for (uint64_t q = a; q < b; ++q) {
+            const uint64_t hv = ch[q];
+            const uint64_t o = cn[q], ol = (q + 1 < b ? cn[q + 1] : bend) - o;
+            size_t j = hv & (cap - 1);
+            bool found = false;
+            while (th[j]) {
+                if (th[j] == hv) {
+                    const uint64_t p = a + ti[j];
+                    const uint64_t po = cn[p], pl = (p + 1 < b ? cn[p + 1] : bend) - po;
+                    if (pl == ol && memcmp(cb + po, cb + o, ol) == 0) { found = true; break; }
+                }
+                j = (j + 1) & (cap - 1);
+            }
+            if (!found) { th[j] = hv; ti[j] = (uint32_t)(q - a); ++distinct; }
+        }
+        per[k] = distinct;
+    });
+    uint64_t total = 0;
+    for (uint64_t v : per) total += v;
+    dut_stage_time("  names: sets", tm);
     return (uint32_t)total;
 }
 

@@ -242,6 +242,54 @@ def test_engine_errors_are_reported():
             Engine(opt, 0).contig_run()
 
 
+def test_quality_prefetch_is_claimed_by_the_matching_tile_and_harmless_otherwise():
+    """cl_contig_prefetch_qual: the bytes travel before their tile is pushed; the push that presents exactly them does
+    not send them again, any other sequence of calls (another tile first, a reserve in between, no push at all, a
+    second prefetch) just drops the prefetch -- the result is the same every time."""
+    import ctypes as C
+    from decodingustools_amd import _lib
+    lib = _lib.load()
+    opt = CallableOptions()
+    L = 300_000
+    rec = synth.short_read_contig(L, 30, 123)
+    ref = synth.make_reference(L, 123)
+    h = rec.n // 2
+    a, b = rec.slice(0, h), rec.slice(h, rec.n)
+    assert a.qual.shape[0] > (4 << 20) and b.qual.shape[0] > (4 << 20)
+
+    def push(eng, r):
+        eng.push_reads(r.pos, r.mapq, r.cigar_off, r.cigar, r.qual_off, r.qual)
+
+    def prefetch(eng, r):
+        q = np.ascontiguousarray(r.qual, np.uint8)
+        assert lib.cl_contig_prefetch_qual(eng._h, q.ctypes.data_as(C.c_void_p), q.shape[0]) == 0
+        return q                                      # must stay alive until the push that claims it
+
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref); push(eng, a); push(eng, b)
+        want = eng.contig_finish()
+        results = []
+        # claimed: prefetch a, push a (same buffer), prefetch b, push b
+        eng.contig_begin(0, L, ref)
+        qa = prefetch(eng, a); eng.push_reads(a.pos, a.mapq, a.cigar_off, a.cigar, a.qual_off, qa)
+        qb = prefetch(eng, b); eng.push_reads(b.pos, b.mapq, b.cigar_off, b.cigar, b.qual_off, qb)
+        results.append(eng.contig_finish())
+        # not claimed: the prefetch names b's bytes, a is pushed first; then a reserve; then a prefetch nobody claims
+        eng.contig_begin(0, L, ref)
+        qb = prefetch(eng, b); push(eng, a)
+        qb2 = prefetch(eng, b); eng.contig_reserve(rec.n, rec.cigar.shape[0], rec.qual.shape[0]); push(eng, b)
+        results.append(eng.contig_finish())
+        eng.contig_begin(0, L, ref)
+        push(eng, a); push(eng, b); qa2 = prefetch(eng, a)
+        results.append(eng.contig_finish())
+        # a prefetch, then the contig is abandoned for another one
+        eng.contig_begin(0, L, ref); qa3 = prefetch(eng, a)
+        eng.contig_begin(0, L, ref); push(eng, a); push(eng, b)
+        results.append(eng.contig_finish())
+    for r in results:
+        assert r.as_dict() == want.as_dict() and np.array_equal(r.intervals, want.intervals)
+
+
 def test_a_refused_tile_leaves_the_contig_as_it_was():
     """cl_push_reads either takes a tile whole or leaves the context untouched: a contig pushed as good tile,
     refused tile (unsorted / out of range / broken offsets, small and large), good tile gives what the two good

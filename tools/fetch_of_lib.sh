@@ -1,6 +1,6 @@
 #!/bin/bash
 # GPU box: k_pileup time and HBM fetch of an alternative build of the library.  usage: tools/fetch_of_lib.sh <lib.so> <tag>
-export DUT_CALLABLE_LIB=$1
+export DUT_CALLABLE_LIB=$(readlink -f $1)
 KB_ABLATES=0 timeout -k 10 200 python tools/kbench.py 2>&1 | tail -1
 tools/rocprof_pass.sh $2 --pmc FETCH_SIZE > /dev/null
 python - <<PY

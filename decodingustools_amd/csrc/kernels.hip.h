@@ -436,8 +436,8 @@ struct PileupArgs {
 // list (the positions inside the window where the state changes).
 // Neither the per-position counters nor the per-position states ever exist in HBM.
 //
-// Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave) so that the segments a
-// wave's 16 quads work on at the same time are ~16 reads apart and rarely share a counter word.
+// Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave): a wave's list holds every fourth
+// read, and consecutive candidates alternate between the two 8-bit counter sets.
 //
 // LONG = 1 or 4 (contigs with >= 8 CIGAR operations per read on average): the lane-serial CIGAR walk is
 // replaced by an operation-parallel one -- live reads are compacted; LONG = 1: a wave takes 64 operations
@@ -648,8 +648,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     uint2 *list = s_list[wv];
     uint32_t n_keep = 0;                            // list entries carried over from the previous round (< 16)
     unsigned long long win_len = 0, win_mq = 0;     // LONG = 0: wave-uniform sums over the reads this window owns
-    // quads consume list entries [0, n_use): quad q takes entries q*Q .. q*Q+Q-1 (Q = n_use/16 rounded
-    // up), i.e. concurrently active quads are Q entries (~4Q reads) apart.  Three units per lane and
+    // quads consume list entries [0, n_use), Q = n_use/16 (rounded up) entries each.  Three units per lane and
     // trip: u, u+4, u+8; a unit past the end is clamped onto the last one and gets an empty mask.
     // MODE 0: 8-bit two-set counters, 1: 16-bit fields, 2: 32-bit words (DEEP)
     // UPL units per lane and trip: 3 (12 unit slots per quad: fits a 150-base read) or 2 (8 slots: reads of
@@ -659,10 +658,14 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
         constexpr int UPL = decltype(upl_tag)::value;
         const uint32_t Q = (n_use + 15u) >> 4;
         for (uint32_t i = 0; i < Q; ++i) {
-#ifdef CL_QUAD_INTERLEAVE                                    /* timing experiment: neighbouring reads in the same trip */
-            const uint32_t idx = i * 16u + quad;
-#else
+            // quad q takes entries q, q + 16, ...: the 16 quads of a trip work on 16 neighbouring segments, so the
+            // 128-byte line that holds the end of one read's qualities and the start of the next is touched by two
+            // quads of the same trip instead of microseconds apart (measured: 1 714 instead of 1 798 MB fetched per
+            // launch, time equal within the run-to-run spread; CL_QUAD_BLOCKED: quad q takes entries q*Q .. q*Q+Q-1)
+#ifdef CL_QUAD_BLOCKED
             const uint32_t idx = quad * Q + i;
+#else
+            const uint32_t idx = i * 16u + quad;
 #endif
             uint2 d = make_uint2(0u, 0u);
             if (idx < n_use) d = list[idx];

@@ -265,3 +265,29 @@ def test_long_read_chrY_full_size_properties_and_oracle_windows(tmp_path):
         prof.close()
         for nm, arr_o, arr_g in (("raw", d[0], raw), ("qc", d[1], qc), ("low", d[2], low), ("state", d[3], state)):
             assert np.array_equal(arr_o[a:b], arr_g[a:b]), (nm, a)
+
+
+def test_bench_whole_genome_line_over_two_ranks(tmp_path):
+    """The harness the driver runs for N > 1 (`bench.py --gpus N` under torch.distributed.run), rehearsed with two ranks
+    on the box's one GPU (gloo for the collectives; nccl needs one device per rank) at 1/64 scale: one JSON line from
+    rank 0, strong scaling over the fixed 25-contig input, both ranks' bases adding up to it, the gathered summaries
+    checked against every rank's own first pass inside the run."""
+    import json
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--backend", "gloo", "--wgs-scale", str(1.0 / 64), "--min-time", "0.05"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    genome = wgs.genome(1.0 / 64)
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 3 and d["warmup"] == 1
+    assert d["config"]["contigs"] == 25 and d["config"]["total_bases"] == sum(L for _, _, L in genome)
+    assert sum(d["sharding"]["per_rank_bases"]) == d["config"]["total_bases"]
+    assert sorted(sum(d["sharding"]["contigs_of_rank"], [])) == sorted(n for _, n, _ in genome)
+    assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
+    assert d["sharding"]["lpt_imbalance"] < 1.05

@@ -155,8 +155,17 @@ template <typename T> struct DevBuf {
 // one buffer (memcpy from the caller's pageable memory, or records built in place) while the DMA of its other buffer
 // runs, so the link sees pinned memory only and the fills of all threads overlap all transfers.
 struct PinRing {
-    static constexpr int kCopyThreads = 8;
+    static constexpr int kCopyThreads = 16;                 // buffers exist for this many; threads() of them are used
     static constexpr size_t kPinBytes = 8u << 20;
+    static int threads()                                    // DUT_COPY_THREADS (1..16), default 8
+    {
+        static const int n = [] {
+            const char *e = getenv("DUT_COPY_THREADS");
+            const int v = e ? atoi(e) : 8;
+            return v < 1 ? 1 : (v > kCopyThreads ? kCopyThreads : v);
+        }();
+        return n;
+    }
     int device = 0;
     hipStream_t copy_stream[kCopyThreads] = {};
     uint8_t *pin[kCopyThreads][2] = {};
@@ -166,7 +175,7 @@ struct PinRing {
     explicit PinRing(int dev) : device(dev)
     {
         if (hipSetDevice(dev) != hipSuccess) return;
-        for (int t = 0; t < kCopyThreads; ++t) {
+        for (int t = 0; t < threads(); ++t) {
             if (hipStreamCreateWithFlags(&copy_stream[t], hipStreamNonBlocking) != hipSuccess) return;
             for (int b = 0; b < 2; ++b) {
                 if (hipHostMalloc(reinterpret_cast<void **>(&pin[t][b]), kPinBytes, hipHostMallocDefault) != hipSuccess) return;
@@ -354,13 +363,14 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
     R->busy.lock();                                       // another context of this device may be using the ring
     c->ring_held = true;
     const uint64_t CH = PinRing::kPinBytes, nch = (n + CH - 1) / CH;
-    const int nt = (int)std::min<uint64_t>(PinRing::kCopyThreads, nch);
+    const int T = PinRing::threads();
+    const int nt = (int)std::min<uint64_t>((uint64_t)T, nch);
     for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
     for (int t = 0; t < nt; ++t) {
-        c->copiers.push_back(dut::spawn_or_run([c, R, dst, n, fill, t, nch, CH]() {
+        c->copiers.push_back(dut::spawn_or_run([c, R, dst, n, fill, t, nch, CH, T]() {
             hipError_t e = hipSetDevice(c->device);
             int k = 0;
-            for (uint64_t ch = (uint64_t)t; ch < nch && e == hipSuccess; ch += PinRing::kCopyThreads, ++k) {
+            for (uint64_t ch = (uint64_t)t; ch < nch && e == hipSuccess; ch += (uint64_t)T, ++k) {
                 const int b = k & 1;
                 const uint64_t off = ch * CH, len = std::min<uint64_t>(CH, n - off);
                 if (k >= 2) e = hipEventSynchronize(R->pin_ev[t][b]);           // the buffer's previous transfer is done

@@ -465,8 +465,9 @@ def main():
     # only -- the library itself is loaded further down, after the device is set.
     from decodingustools_amd import build as _native_build
     _native_build.build()
-    import oracle
-    oracle.build()
+    if world == 1:                               # the checker of the N = 1 line; no other rank configuration uses it
+        import oracle
+        oracle.build()
     n_dev = torch.cuda.device_count()
     dev_id = local_rank % max(n_dev, 1)          # one GPU per rank on a real node
     torch.cuda.set_device(dev_id)

@@ -19,7 +19,9 @@ def build(force=False):
     if os.environ.get("ORACLE_LIB"):
         return LIB
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in src):
-        subprocess.run(["gcc", "-O2", "-g", "-fPIC", "-std=c11", "-shared", "-o", LIB, src[0]], check=True)
+        tmp = f"{LIB}.tmp{os.getpid()}"                 # several processes may find the library stale at once
+        subprocess.run(["gcc", "-O2", "-g", "-fPIC", "-std=c11", "-shared", "-o", tmp, src[0]], check=True)
+        os.replace(tmp, LIB)
     return LIB
 
 

@@ -1,9 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- callable-loci hot path on MI355X: reference bases classified per second.
 
-A step = one pass of the whole device path (read prep + window bounds -> pileup/classify ->
-run-length intervals + summary) over the rank's resident input.  Inputs are resident in HBM when the
-timed region starts.
+A step = one pass of the whole device path (pileup/classify per window -> run-length intervals + summary:
+three launches) over the rank's resident input.  Inputs are resident in HBM when the timed region starts.
 
   --gpus 1 (default)   BASELINE.json configs[1], the configuration the metric is quoted on: ONE
                        chr21-shaped contig (46 709 983 bp, 30x, 2x150 bp paired reads).  The whole contig

@@ -233,7 +233,7 @@ struct cl_ctx {
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
     bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
-    bool has_long = false;           // some read has more than kLongOps CIGAR ops (k_read_prep_long needed)
+    bool has_long = false;           // some read has more than kLongOps CIGAR ops (its checkpoints are in h_ck_x / h_ck_y)
     int32_t tid = 0;
     uint32_t contig_len = 0;
     RawVec<uint8_t> h_ref;
@@ -247,8 +247,12 @@ struct cl_ctx {
     // reads whose reference span exceeds kWideSpan (ascending read index = ascending position)
     std::vector<uint32_t> h_wide_idx;
     std::vector<int32_t> h_wide_pos;
-    std::vector<uint32_t> h_long_list;   // reads with more than kLongOps CIGAR operations (k_read_prep_long's work list)
-    uint32_t n_long = 0;
+    // the index over the CIGARs, built by the one host walk that validates a tile (cl_push_reads): every read's end,
+    // and for reads with more than kLongOps operations the (reference, query) position before every 64th operation
+    // of the contig's CIGAR array
+    RawVec<uint32_t> h_end, h_ck_x, h_ck_y;
+    uint32_t n_long = 0;                 // reads with more than kLongOps operations
+    uint32_t host_err = 0;               // kErrCigar / kErrRange found by that walk (reported by cl_contig_collect)
     uint32_t bounds_err = 0;             // kErrRange raised by the window bounds (reported by cl_contig_collect)
     uint32_t span_n = 0, span_w = 0; // longest span among the ordinary / the wide reads
     uint32_t n_wide = 0;
@@ -271,10 +275,9 @@ struct cl_ctx {
     DevBuf<uint8_t> d_first_state, d_last_state;
     DevBuf<uint8_t> d_win_wide;      // per window: sticky "needs 16-bit counter fields" mark (k_pileup)
     DevBuf<WinPartial> d_winpart;
-    DevBuf<PrepPartial> d_prep;
     DevBuf<FinPartial> d_fin;
     DevBuf<uint32_t> d_errflag;        // [0] error bits raised by the kernels of a run, [1] unused
-    DevBuf<uint32_t> d_long_list, d_ck_x, d_ck_y;
+    DevBuf<uint32_t> d_ck_x, d_ck_y;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
     DevBuf<Interval> d_iv;
@@ -425,8 +428,9 @@ cl_status harvest_events(cl_ctx *c)
 {
     for (int s = 0; s < c->ev_pending; ++s) {
         HIP_TRY(c, hipEventSynchronize(c->ev[s][CL_K_COUNT]));
-        // events 0,1,3,4: the window bounds run inside the prep launch (CL_K_BOUNDS stays 0; ev[2] is unused)
-        static const int from[CL_K_COUNT] = {0, -1, 1, 3}, to[CL_K_COUNT] = {1, -1, 3, 4};
+        // events 0,3,4: the per-read and per-window indexes are built on the host at upload (CL_K_PREP and CL_K_BOUNDS
+        // stay 0; ev[1], ev[2] are unused)
+        static const int from[CL_K_COUNT] = {-1, -1, 0, 3}, to[CL_K_COUNT] = {-1, -1, 3, 4};
         for (int i = 0; i < CL_K_COUNT; ++i) {
             if (from[i] < 0) continue;
             float t = 0.f;
@@ -537,17 +541,13 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     return CL_OK;
 }
 
-// run lists -> intervals, one wave per window; the extra last workgroup reduces the summary (the read partials it
-// adds: k_read_prep's blocks for the long-read forms, k_read_prep_long's when there are such reads)
+// run lists -> intervals, one wave per window; the extra last workgroup reduces the summary
 void launch_rle(cl_ctx *c)
 {
     const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
-    const Variant vr = pick_variant(c);
-    const PrepPartial *parts = vr.lng ? c->d_prep.p : c->d_prep.p + kPrepBlocks;
-    const uint32_t n_parts = (vr.lng ? (uint32_t)kPrepBlocks : 0u) + (c->n_long ? (uint32_t)kLongBlocks : 0u);
     hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
                        c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
-                       parts, n_parts, c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
+                       c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
                        (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
 }
 
@@ -578,18 +578,11 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     }
     hipEvent_t *ev = c->ev[c->ev_pending < cl_ctx::kEvSets ? c->ev_pending : 0];
     const Reads R = device_reads(c);
-    const Variant vr = pick_variant(c);
 
     // d_errflag is zero here: cleared at upload, and by the summary workgroup at the end of every run
+    // (a run has no per-read kernel: the read ends and CIGAR checkpoints the long-read forms need are an index the host
+    // built at upload; CL_K_PREP stays in the timing table as an empty slot)
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    // long-read forms: every read's end and separable sums come from k_read_prep; the short-read form of k_pileup
-    // walks its reads' whole CIGARs itself.  Reads with more than kLongOps operations: k_read_prep_long either way.
-    if (vr.lng)
-        hipLaunchKernelGGL(k_read_prep, dim3(kPrepBlocks), dim3(kBlock), 0, c->stream, R, c->dopt, c->d_end.p, c->d_prep.p);
-    if (c->n_long)
-        hipLaunchKernelGGL(k_read_prep_long, dim3(kLongBlocks), dim3(kBlock), 0, c->stream, R, c->dopt,
-                           c->d_end.p, c->d_prep.p, c->n_long, c->d_long_list.p, c->d_ck_x.p, c->d_ck_y.p);
-    if (prof) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     PileupArgs a;
     a.R = R; a.o = c->dopt; a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
     a.wide_idx = c->d_wide_idx.p;
@@ -662,7 +655,7 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     make_ge_consts((uint8_t)(o.xd_on ? opt->max_depth + 1 : 255), o.xd_add, o.xd_or, o.xd_and);
     std::vector<uint32_t> lut;
     build_lut(opt->max_low_mapq_fraction, lut);
-    bool ok = c->d_lut.reserve(kLutSize) == hipSuccess && c->d_prep.reserve(kPrepParts) == hipSuccess &&
+    bool ok = c->d_lut.reserve(kLutSize) == hipSuccess &&
               c->d_summary.reserve(1) == hipSuccess && c->d_errflag.reserve(2) == hipSuccess &&
               hipMemcpy(c->d_lut.p, lut.data(), kLutSize * sizeof(uint32_t), hipMemcpyHostToDevice) == hipSuccess;
     if (!ok || ensure_pins(c) != CL_OK) { cl_destroy(c); return CL_ERR_DEVICE; }
@@ -680,8 +673,8 @@ void cl_destroy(cl_ctx *c)
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
     c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
-    c->d_winpart.release(); c->d_prep.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_long_list.release(); c->d_ck_x.release(); c->d_ck_y.release();
+    c->d_winpart.release(); c->d_lut.release(); c->d_summary.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_ck_x.release(); c->d_ck_y.release();
     for (int i = 0; i < 2; ++i) if (c->site_ev[i]) (void)hipEventDestroy(c->site_ev[i]);
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
@@ -709,7 +702,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->h_iv.clear();
     c->q_dev = 0;
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
-    c->h_long_list.clear(); c->n_long = 0; c->bounds_err = 0;
+    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->n_long = 0; c->host_err = 0; c->bounds_err = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -828,13 +821,25 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     const unsigned long long qbase = c->q_dev + c->h_qual.size();
     StageTimer tmr;
 
-    // ---- validation that protects the kernels' indexing, and the reference span of every read (what
-    //      k_read_prep computes as end - pos): the longest ordinary span bounds every window's candidate
-    //      range, reads wider than kWideSpan get their own list.  In chunks, on all host threads. ----
+    // ---- the one walk over every CIGAR of the tile: validation that protects the kernels' indexing; the end of every
+    //      read (pos + bam_cigar2rlen, the pileup node span) -- the longest ordinary span bounds every
+    //      window's candidate range, reads wider than kWideSpan get their own list; the CIGAR shapes htslib's
+    //      resolve_cigar2 asserts on or indexes out of bounds for; and, for reads with more than kLongOps operations,
+    //      the (reference, query) position before every operation whose index in the contig's CIGAR array is a multiple
+    //      of 64, where k_pileup starts its walk of such a read instead of at its first operation.  In chunks, on all
+    //      host threads. ----
     const size_t grain = 65536, nchunk = (n + grain - 1) / grain;
-    struct Chunk { int bad = 0; bool has_long = false; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide, longs; };
+    struct Chunk { int bad = 0; uint32_t n_long = 0, err = 0; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide; };
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
+    try {
+        c->h_end.reserve(rbase + n);                           // entries [rbase, rbase + n) are written below; the
+        c->h_ck_x.reserve(((cbase + ncig) >> 6) + 2);          // sizes follow when the tile is accepted (a refused
+        c->h_ck_y.reserve(((cbase + ncig) >> 6) + 2);          // tile leaves only unused capacity behind)
+    } catch (const std::bad_alloc &) {
+        return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
+    }
+    uint32_t *const h_end = c->h_end.data() + rbase, *const h_ck_x = c->h_ck_x.data(), *const h_ck_y = c->h_ck_y.data();
     dut::parallel_for(nchunk, 1, [&](size_t k) {
         Chunk &o = ch[k];
         const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
@@ -844,16 +849,42 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             if (p < 0 || (uint32_t)p >= c->contig_len) { if (!o.bad) o.bad = 1; }
             else if (p < last) { if (!o.bad) o.bad = 2; }
             last = p;
+            h_end[i] = (uint32_t)p;
             if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i]) { if (!o.bad) o.bad = 3; continue; }
-            if (t->cigar_off[i + 1] - t->cigar_off[i] > kLongOps) { o.has_long = true; o.longs.push_back((uint32_t)i); }
             if (t->cigar_off[i] < cig0 || t->cigar_off[i + 1] > cig0 + ncig) { if (!o.bad) o.bad = 3; continue; }
+            const uint32_t q0i = t->cigar_off[i], q1i = t->cigar_off[i + 1], nops = q1i - q0i;
             unsigned long long l = 0;
-            for (uint32_t q = t->cigar_off[i]; q < t->cigar_off[i + 1]; ++q) {
-                const uint32_t op = t->cigar[q] & 15u;
-                if (op == 0 || op == 2 || op == 3 || op == 7 || op == 8) l += t->cigar[q] >> 4;
+            if (nops <= kLongOps) {
+                for (uint32_t q = q0i; q < q1i; ++q) {
+                    const uint32_t cw = t->cigar[q], len = cw >> 4;
+                    const bool radv = ((0x18Du >> (cw & 15u)) & 1u) != 0u;      // M D N = X consume the reference
+                    l += radv ? len : 0u;
+                    if (radv && len == 0u) o.err |= kErrCigar;                 // zero-length reference-consuming op
+                }
+                // a read that reaches a column with a single non-match op is undefined in htslib
+                if (l > 0 && nops == 1u && !(((0x181u >> (t->cigar[q0i] & 15u)) & 1u) != 0u)) o.err |= kErrCigar;
+            } else {
+                o.n_long += 1;
+                uint32_t yq = 0;                                               // query advance (M I S = X), modulo 2^32
+                const uint32_t shift = cbase - cig0;                           // tile op index -> contig op index (mod 2^32)
+                for (uint32_t q = q0i; q < q1i; ++q) {
+                    const uint32_t kc = q + shift;
+                    if ((kc & 63u) == 0u) {
+                        const unsigned long long cx = (unsigned long long)(uint32_t)p + l;
+                        h_ck_x[kc >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
+                        h_ck_y[kc >> 6] = yq;
+                    }
+                    const uint32_t cw = t->cigar[q], len = cw >> 4, op = cw & 15u;
+                    const bool radv = ((0x18Du >> op) & 1u) != 0u, qadv = ((0x193u >> op) & 1u) != 0u;
+                    l += radv ? len : 0u;
+                    yq += qadv ? len : 0u;
+                    if (radv && len == 0u) o.err |= kErrCigar;
+                }
             }
-            const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;      // k_read_prep flags spans beyond the 32-bit range
-            if (l <= 0xFFFF0000ull - (uint64_t)p) o.max_end = std::max<uint64_t>(o.max_end, (uint64_t)p + l);   // beyond that: kErrRange from the device
+            const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+            // an end beyond the engine's 32-bit coordinate range: flagged; the read then spans nothing
+            if (l <= 0xFFFF0000ull - (uint64_t)p) { h_end[i] = (uint32_t)((uint64_t)p + l); o.max_end = std::max<uint64_t>(o.max_end, (uint64_t)p + l); }
+            else o.err |= kErrRange;
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
         }
@@ -868,24 +899,26 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     // ---- staging of the small arrays (offsets rebased onto the contig's); undone if anything below fails, so that
     //      a refused tile leaves the context as it was ----
     struct Undo {
-        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide, n_long; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
+        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; uint32_t n_long, host_err; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
         ~Undo()
         {
             if (!armed) return;
             c->h_pos.resize(n_pos); c->h_mapq.resize(n_pos); c->h_cigar.resize(n_cig); c->h_qual.resize(n_qual);
             c->h_cigar_off.resize(n_pos + 1); c->h_qual_off.resize(n_pos + 1);
-            c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide); c->h_long_list.resize(n_long);
+            c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide); c->n_long = n_long; c->host_err = host_err;
+            c->h_end.resize(n_pos); c->h_ck_x.resize((n_cig >> 6) + 2); c->h_ck_y.resize((n_cig >> 6) + 2);
             c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end;
         }
-    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->h_long_list.size(), c->has_long, c->span_n, c->span_w, c->host_max_end};
+    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->n_long, c->host_err, c->has_long, c->span_n, c->span_w, c->host_max_end};
     try {
         for (const Chunk &o : ch) {
-            if (o.has_long) c->has_long = true;
+            if (o.n_long) c->has_long = true;
+            c->n_long += o.n_long; c->host_err |= o.err;
             c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
             c->host_max_end = std::max(c->host_max_end, o.max_end);
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
-            for (uint32_t i : o.longs) c->h_long_list.push_back((uint32_t)(rbase + i));
         }
+        c->h_end.resize(rbase + n); c->h_ck_x.resize(((cbase + ncig) >> 6) + 2); c->h_ck_y.resize(((cbase + ncig) >> 6) + 2);
         c->h_pos.append(t->pos, n);
         c->h_mapq.append(t->mapq, n);
         c->h_cigar.append(t->cigar + cig0, ncig);
@@ -936,17 +969,16 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if (fs != CL_OK) return fs;
     }
     c->n_qual = c->q_dev;
-    c->n_long = (uint32_t)c->h_long_list.size();
     c->n_wide = (uint32_t)c->h_wide_idx.size();
     const size_t n = c->n_reads;
     const Variant vr = pick_variant(c);
     StageTimer tmr0;
     // What the device needs of the per-read fields depends on the form of k_pileup the contig gets: the short-read form
-    // reads one packed record per read; the long-read forms, k_read_prep and k_read_prep_long read the arrays as pushed.
-    const bool need_soa = vr.lng || c->n_long > 0;
+    // reads one packed record per read (and the ends of its reads with more than kLongOps operations); the long-read
+    // forms read the arrays as pushed, and every read's end.
+    const bool need_soa = vr.lng;
     HIP_TRY(c, c->d_end.reserve(n + 1));
     HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));          // four words are loaded at a read's first op
-    HIP_TRY(c, c->d_long_list.reserve(c->n_long + 1));
     HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
     HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
@@ -967,6 +999,13 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if ((rs = ring_copy(c, c->d_mapq.p, c->h_mapq.data(), n)) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long))) != CL_OK) return rs;
+    }
+    if (vr.lng || c->n_long)
+        if ((rs = ring_copy(c, c->d_end.p, c->h_end.data(), n * sizeof(uint32_t))) != CL_OK) return rs;
+    if (c->n_long) {                                         // entries of operations inside other reads are never read
+        const size_t nck = (c->n_cigar >> 6) + 1;
+        if ((rs = ring_copy(c, c->d_ck_x.p, c->h_ck_x.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
+        if ((rs = ring_copy(c, c->d_ck_y.p, c->h_ck_y.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
     }
     if (!vr.lng) {
         // the packed records of the short-read form: pos, CIGAR offset, low half of the quality offset, mapq and the two
@@ -996,7 +1035,6 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     tmr.lap("upload: records");
     if ((rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
     tmr.lap("upload: cigar");
-    if (c->n_long) HIP_TRY(c, hipMemcpyAsync(c->d_long_list.p, c->h_long_list.data(), (size_t)c->n_long * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_pos.p, c->h_wide_pos.data(), c->n_wide * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
@@ -1015,6 +1053,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // The staged copy is no longer needed; its memory is kept for the context's next contig (giving back and
     // re-faulting a few hundred megabytes per contig was a fifth of a contig's host time).  cl_destroy frees it.
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
+    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear();
     std::vector<uint8_t>().swap(c->h_qual);
     tmr.lap("upload: done");
     c->uploaded = true; c->ran = false;
@@ -1049,8 +1088,8 @@ cl_status cl_sync(cl_ctx *c)
 
 static cl_status check_summary(cl_ctx *c)
 {
-    if ((c->h_sum.err | c->bounds_err) & kErrRange) return fail(c, CL_ERR_RANGE, "a read ends beyond the engine's 32-bit coordinate range");
-    if (c->h_sum.err & kErrCigar)
+    if ((c->h_sum.err | c->bounds_err | c->host_err) & kErrRange) return fail(c, CL_ERR_RANGE, "a read ends beyond the engine's 32-bit coordinate range");
+    if ((c->h_sum.err | c->host_err) & kErrCigar)
         return fail(c, CL_ERR_CIGAR, "malformed CIGAR: zero-length reference-consuming operation, or a single non-match "
                                      "operation on a read that spans reference positions (undefined in htslib's pileup)");
     return CL_OK;
@@ -1088,9 +1127,7 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
             continue;
         }
         // (a read that overhangs the contig end makes the reference walk, and classify as REF_N, positions up to its
-        // end, mod.rs:100-101: the extent was sized for that at upload from the spans computed at cl_push_reads; the
-        // device's own maximum can only agree)
-        if (c->h_sum.max_end > c->extent) return fail(c, CL_ERR_DEVICE, "a read ends beyond the extent computed at upload");
+        // end, mod.rs:100-101: the extent was sized for that at upload from the ends computed at cl_push_reads)
         if (c->h_sum.n_intervals > c->d_iv.cap) {
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
             launch_rle(c);

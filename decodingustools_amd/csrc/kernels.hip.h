@@ -4,11 +4,9 @@
 //
 //   (host, at upload: per window of T reference positions the [lo,hi) range of reads that can touch it -- an
 //                    index of the resident layout, like the offsets; WinMeta below)
-//   k_read_prep      contigs of long-read shape only (the LONG variants of k_pileup): per read the CIGAR walk
-//                    -> end[r] and block partials of the per-read separable sums (contig_profiler.rs:74,79-82 via
-//                    SURVEY 8a-7); for short-read contigs k_pileup does this itself (the window that holds a
-//                    read's start owns its sums) and only reads with more than kLongOps operations go through
-//                    k_read_prep_long (end[r] + CIGAR checkpoints)
+//   (host, at upload, in the one walk over every CIGAR that validates a tile: every read's end, and for reads of
+//                    more than kLongOps operations a (reference, query) checkpoint before every 64th operation --
+//                    an index over the CIGARs, like the window records)
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
 //                    (callable_profiler.rs:100-116) and reduced to the window's run list (the
@@ -27,27 +25,14 @@
 namespace clk {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
-constexpr int kPrepBlocks = 4096;    // grid of k_read_prep (grid-stride)
-constexpr int kLongBlocks = 2048;    // grid of k_read_prep_long (one wave per long read)
-constexpr int kPrepParts = kPrepBlocks + kLongBlocks;
-constexpr uint32_t kLongOps = 64;    // reads with more CIGAR ops are scanned by a whole wave and get a
-                                     // checkpoint (reference, query position) before every 64th op
+constexpr uint32_t kLongOps = 64;    // reads with more CIGAR ops get a checkpoint (reference, query position) before
+                                     // every 64th op (op numbering of the contig's CIGAR array), built on the host
 constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
 constexpr uint32_t kWideSpan = 16384; // reads spanning more reference than this are "wide": looked up per window
                                       // in their own list instead of widening every window's candidate range
 constexpr uint32_t kLutSize = 65536; // low-MAPQ threshold table entries (raw depth 0..65535)
 
 enum : uint32_t { kErrCigar = 1u, kErrRange = 2u, kNeedDeep = 4u, kNeedWide8 = 8u };
-
-// per-block output of k_read_prep
-struct PrepPartial {
-    unsigned long long sum_reflen;       // -> summed_coverage
-    unsigned long long sum_mapq_reflen;  // -> summed_mapq
-    uint32_t max_span;
-    uint32_t max_end;
-    uint32_t err;
-    uint32_t pad;
-};
 
 // per-window output of k_pileup
 struct WinPartial {
@@ -56,7 +41,7 @@ struct WinPartial {
     unsigned long long sum_qc;       // -> quality_bases
     unsigned long long sum_q;        // -> summed_baseq
     unsigned long long sum_reflen;   // reads that START in this window: sum of reference spans (-> summed_coverage) ...
-    unsigned long long sum_mapq_reflen;   // ... and of mapq * span over those with mapq >= min (-> summed_mapq); short-read form only
+    unsigned long long sum_mapq_reflen;   // ... and of mapq * span over those with mapq >= min (-> summed_mapq)
     uint32_t n_inner;                // run boundaries strictly inside the window
     uint32_t max_raw;
 };
@@ -200,183 +185,6 @@ struct __attribute__((aligned(32))) WinMeta {
 };
 
 // ---------------------------------------------------------------------------------------------
-// k_read_prep: one thread per read (grid-stride).
-//   end[r] = pos + bam_cigar2rlen  (the pileup node span)
-//   sum_reflen       = sum over reads of reflen                 == summed_coverage
-//   sum_mapq_reflen  = sum over reads with mapq >= min_mapq of mapq*reflen == summed_mapq
-// CIGAR shapes htslib's resolve_cigar2 asserts on / indexes out of bounds for are flagged.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_read_prep(Reads R, Opts o, uint32_t *__restrict__ end_out,
-                                                       PrepPartial *__restrict__ part)
-{
-    const uint32_t bid = blockIdx.x;
-    __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
-    __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
-    unsigned long long sum_len = 0, sum_mq = 0;
-    uint32_t max_span = 0, max_end = 0, err = 0;
-    // four reads per thread and trip: all their loads are issued before any is used
-    constexpr int U = 4;
-    const uint32_t stride = kPrepBlocks * kBlock;
-    for (uint32_t r0 = bid * kBlock + threadIdx.x; r0 < R.n; r0 += U * stride) {
-        uint32_t k0[U], k1[U], ps[U], mq[U], c0[U];
-        Q16 cw[U];                                   // the first four CIGAR words of each read, one 16-byte load
-        bool in[U];
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            const uint32_t r = r0 + i * stride;
-            in[i] = r < R.n;
-            const uint32_t rr = in[i] ? r : r0;
-            k0[i] = R.cigar_off[rr]; k1[i] = R.cigar_off[rr + 1]; ps[i] = (uint32_t)R.pos[rr]; mq[i] = R.mapq[rr];
-        }
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            // reads past the read's own words (the next reads' or the array's padding) are never used
-            __builtin_memcpy(&cw[i], R.cigar + k0[i], 16);
-            c0[i] = k0[i] < k1[i] ? cw[i].w[0] : 0u;
-        }
-#pragma unroll
-        for (int i = 0; i < U; ++i) {
-            if (!in[i]) continue;
-            if (k1[i] - k0[i] > kLongOps) continue;     // left to k_read_prep_long (the host listed it at cl_push_reads)
-            unsigned long long reflen = 0;
-            for (uint32_t k = k0[i]; k < k1[i]; ++k) {
-                const uint32_t d = k - k0[i];
-                const uint32_t c = d == 0 ? c0[i] : d == 1 ? cw[i].w[1] : d == 2 ? cw[i].w[2] : d == 3 ? cw[i].w[3] : R.cigar[k];
-                const uint32_t op = c & 15u, l = c >> 4;
-                if (op_match(op) || op_del(op)) {
-                    reflen += l;
-                    if (l == 0) err |= kErrCigar;          // zero-length reference-consuming op
-                }
-            }
-            // a read that reaches a column with a single non-match op is undefined in htslib
-            if (reflen > 0 && k1[i] - k0[i] == 1 && !op_match(c0[i] & 15u)) err |= kErrCigar;
-            const unsigned long long e = (unsigned long long)ps[i] + reflen;
-            if (e > 0xFFFF0000ull) { err |= kErrRange; }
-            const uint32_t e32 = e > 0xFFFF0000ull ? ps[i] : (uint32_t)e;
-            end_out[r0 + i * stride] = e32;
-            const uint32_t span = e32 - ps[i];
-            sum_len += span;
-            if (mq[i] >= o.min_mapq) sum_mq += (unsigned long long)mq[i] * span;
-            max_span = span > max_span ? span : max_span;
-            max_end = e32 > max_end ? e32 : max_end;
-        }
-    }
-    sum_len = wave_sum_u64(sum_len);
-    sum_mq = wave_sum_u64(sum_mq);
-    max_span = wave_max_u32(max_span);
-    max_end = wave_max_u32(max_end);
-    err = wave_or_u32(err);
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) {
-        s_a[wv] = sum_len; s_b[wv] = sum_mq; s_c[wv] = max_span; s_d[wv] = max_end; s_e[wv] = err;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        PrepPartial p;
-        p.sum_reflen = 0; p.sum_mapq_reflen = 0; p.max_span = 0; p.max_end = 0; p.err = 0; p.pad = 0;
-        for (int i = 0; i < kBlock / 64; ++i) {
-            p.sum_reflen += s_a[i]; p.sum_mapq_reflen += s_b[i];
-            p.max_span = s_c[i] > p.max_span ? s_c[i] : p.max_span;
-            p.max_end = s_d[i] > p.max_end ? s_d[i] : p.max_end;
-            p.err |= s_e[i];
-        }
-        part[bid] = p;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_read_prep_long: the reads with more than kLongOps CIGAR ops (listed by the host at cl_push_reads; e.g. long reads
-// with an indel every ~15 bases), one wave per read.  The wave scans the CIGAR 256 ops at a time
-// (four consecutive ops per lane, wave prefix sums of the reference / query advance) and stores, for
-// every op index k that is a multiple of 64 inside the read, the reference and query position
-// before op k: ck_x[k/64], ck_y[k/64].  k_pileup starts its walk at the checkpoint nearest to the
-// window instead of at the read's first op.  Same outputs as k_read_prep otherwise.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_read_prep_long(Reads R, Opts o, uint32_t *__restrict__ end_out,
-                                                            PrepPartial *__restrict__ part,
-                                                            uint32_t n_long,
-                                                            const uint32_t *__restrict__ long_list,
-                                                            uint32_t *__restrict__ ck_x, uint32_t *__restrict__ ck_y)
-{
-    __shared__ unsigned long long s_a[kBlock / 64], s_b[kBlock / 64];
-    __shared__ uint32_t s_c[kBlock / 64], s_d[kBlock / 64], s_e[kBlock / 64];
-    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
-    unsigned long long sum_len = 0, sum_mq = 0;          // meaningful in lane 0
-    uint32_t max_span = 0, max_end = 0, err = 0;
-    for (uint32_t i = blockIdx.x * (kBlock / 64) + wv; i < n_long; i += gridDim.x * (kBlock / 64)) {
-        const uint32_t r = long_list[i];
-        const uint32_t k0 = R.cigar_off[r], k1 = R.cigar_off[r + 1];
-        const uint32_t ps = (uint32_t)R.pos[r];
-        unsigned long long xc = 0;                       // reference / query advance before the chunk
-        uint32_t yc = 0;
-        // 256 ops per trip: four consecutive ops per lane (one 16-byte load; the next trip's is issued before
-        // this one is summed), lane-local sums, three DPP scans; the four checkpoints of the trip are the
-        // scan values in front of lanes 0, 16, 32, 48.  Lengths are 28-bit: their low 16 and high 12 bits are
-        // summed separately (a trip's sums stay below 2^24 / 2^20), exactly.
-        auto load4 = [&](uint32_t kb, Q16 &t) {
-            const uint32_t kl = kb + 4u * lane;
-            t.w[0] = 5u; t.w[1] = 5u; t.w[2] = 5u; t.w[3] = 5u;          // outside the read: H, advances nothing
-            if (kl < k1 && kl + 4u > k0) __builtin_memcpy(&t, R.cigar + kl, 16);   // at most 12 bytes past the read's words
-        };
-        const uint32_t kb0 = k0 & ~63u;
-        Q16 nxt;
-        load4(kb0, nxt);
-        for (uint32_t kb = kb0; kb < k1; kb += 256u) {
-            const Q16 cur = nxt;
-            if (kb + 256u < k1) load4(kb + 256u, nxt);
-            const uint32_t kl = kb + 4u * lane;
-            uint32_t s_lo = 0, s_hi = 0, s_q = 0;
-#pragma unroll
-            for (uint32_t j = 0; j < 4u; ++j) {
-                const bool in = (kl + j) >= k0 && (kl + j) < k1;
-                const uint32_t c = in ? cur.w[j] : 5u, op = c & 15u, l = c >> 4;
-                const bool radv = ((0x18Du >> op) & 1u) != 0u, qadv = ((0x193u >> op) & 1u) != 0u;
-                if (radv && l == 0 && in) err |= kErrCigar;               // zero-length reference-consuming op
-                const uint32_t rl = radv ? l : 0u;
-                s_lo += rl & 0xFFFFu; s_hi += rl >> 16; s_q += qadv ? l : 0u;
-            }
-            const uint32_t i_lo = dpp_incl_scan_u32(s_lo), i_hi = dpp_incl_scan_u32(s_hi), i_q = dpp_incl_scan_u32(s_q);
-            // lanes 0, 16, 32, 48 hold the sums in front of the trip's four 64-op chunks
-            if ((lane & 15u) == 0u) {
-                const uint32_t kc = kb + 4u * lane;
-                if (kc >= k0 && kc < k1) {
-                    const unsigned long long cx = (unsigned long long)ps + xc + (((unsigned long long)(i_hi - s_hi) << 16) + (i_lo - s_lo));
-                    ck_x[kc >> 6] = cx > 0xFFFF0000ull ? 0xFFFF0000u : (uint32_t)cx;
-                    ck_y[kc >> 6] = yc + (i_q - s_q);
-                }
-            }
-            xc += ((unsigned long long)(uint32_t)__builtin_amdgcn_readlane((int)i_hi, 63) << 16) + (uint32_t)__builtin_amdgcn_readlane((int)i_lo, 63);
-            yc += (uint32_t)__builtin_amdgcn_readlane((int)i_q, 63);
-        }
-        if (lane == 0) {
-            const unsigned long long e = (unsigned long long)ps + xc;
-            if (e > 0xFFFF0000ull) err |= kErrRange;
-            const uint32_t e32 = e > 0xFFFF0000ull ? ps : (uint32_t)e;
-            end_out[r] = e32;
-            const uint32_t span = e32 - ps, mq = R.mapq[r];
-            sum_len += span;
-            if (mq >= o.min_mapq) sum_mq += (unsigned long long)mq * span;
-            max_span = span > max_span ? span : max_span;
-            max_end = e32 > max_end ? e32 : max_end;
-        }
-    }
-    err = wave_or_u32(err);
-    if (lane == 0) { s_a[wv] = sum_len; s_b[wv] = sum_mq; s_c[wv] = max_span; s_d[wv] = max_end; s_e[wv] = err; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        PrepPartial p;
-        p.sum_reflen = 0; p.sum_mapq_reflen = 0; p.max_span = 0; p.max_end = 0; p.err = 0; p.pad = 0;
-        for (int i = 0; i < kBlock / 64; ++i) {
-            p.sum_reflen += s_a[i]; p.sum_mapq_reflen += s_b[i];
-            p.max_span = s_c[i] > p.max_span ? s_c[i] : p.max_span;
-            p.max_end = s_d[i] > p.max_end ? s_d[i] : p.max_end;
-            p.err |= s_e[i];
-        }
-        part[kPrepBlocks + blockIdx.x] = p;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // byte-parallel ">= threshold" on four bytes at once, given the three constants of make_ge_consts()
 // (callable_loci.hip) for a threshold T: 0x80 in each byte >= T.
 //   T == 0        : always                    add = 0x80.., OR form
@@ -396,12 +204,12 @@ struct PileupArgs {
     Reads R;
     Opts o;
     const ReadRec *rec;           // n + 1 packed records (the short-read form reads these instead of R's per-read arrays)
-    const uint32_t *end;          // per read (short-read form: valid for reads with more than kLongOps operations only)
+    const uint32_t *end;          // per read, from the host (the short-read form reads it for reads of more than kLongOps operations only)
     const WinMeta *win;
     const uint32_t *wide_idx;           // read indices of the wide reads, ascending
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
-    const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (k_read_prep_long)
+    const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (host)
     uint8_t        *state;        // n_win*T bytes; written by the DEBUG instantiation only (test dumps)
     uint16_t       *runs;         // per window T entries: the run starts strictly inside the window, rel. position | state << 12
     uint8_t        *first_state, *last_state;   // per window: state of its first / last position (run seams)
@@ -647,7 +455,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     const uint32_t ql = lane & 3u, quad = lane >> 2;
     uint2 *list = s_list[wv];
     uint32_t n_keep = 0;                            // list entries carried over from the previous round (< 16)
-    unsigned long long win_len = 0, win_mq = 0;     // LONG = 0: wave-uniform sums over the reads this window owns
+    unsigned long long win_len = 0, win_mq = 0;     // wave-uniform sums over the reads this window owns
     // quads consume list entries [0, n_use), Q = n_use/16 (rounded up) entries each.  Three units per lane and
     // trip: u, u+4, u+8; a unit past the end is clamped onto the last one and gets an empty mask.
     // MODE 0: 8-bit two-set counters, 1: 16-bit fields, 2: 32-bit words (DEEP)
@@ -741,13 +549,13 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
         bool live = false;
         uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
         uint32_t nblk = 0, lim0 = 0, k0r = 0;        // LONG = 4
-        unsigned long long own_len = 0, own_mq = 0;  // LONG = 0: separable sums of the reads this window owns (this pass)
+        unsigned long long own_len = 0, own_mq = 0;  // separable sums of the reads this window owns (this pass)
         if (v < n_cand) {
             uint32_t e, mq;
             bool fetch_cw = true;                    // cw still has to be loaded from cigar[k]
             if constexpr (LONG == 0) {
                 // ---- short-read form: one packed record per read; the whole CIGAR is walked here once (what
-                //      k_read_prep does for the long-read forms): the read's end, the malformed shapes htslib asserts
+                //      the host does at upload for the long-read forms): the read's end, the malformed shapes htslib asserts
                 //      on, and -- in the window that holds the read's start -- its separable sums
                 //      (contig_profiler.rs:74: summed_coverage = sum of spans, summed_mapq over mapq >= min) ----
                 const uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
@@ -792,11 +600,19 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                     cw = n ? c4.w[0] : 0u;
                     fetch_cw = false;
                 } else {
-                    e = a.end[r];                                // k_read_prep_long's (it owns this read's sums too)
+                    e = a.end[r];                                // more than kLongOps operations: the host walked them
+                    if (x >= W) {
+                        own_len = e - x;
+                        own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
+                    }
                 }
             } else {
                 x = (uint32_t)a.R.pos[r];
                 e = a.end[r]; mq = a.R.mapq[r];
+                if (x >= W) {                                    // the window that holds the read's start owns its sums
+                    own_len = e - x;
+                    own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
+                }
                 k = a.R.cigar_off[r];
                 k0r = k;
                 k1 = a.R.cigar_off[r + 1];
@@ -852,7 +668,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                 }
             }
         }
-        if constexpr (LONG == 0) { win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq); }
+        win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq);
         if constexpr (LONG) {
             // ---- long-read shape: CIGAR operations in parallel.  The live reads of the pass are
             //      compacted into s_live; a wave takes a read and 64 of its operations at a time (one
@@ -1472,7 +1288,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
 
 // ---------------------------------------------------------------------------------------------
 // k_fin_windows / fin_summary: exclusive scan of the run starts per window inside blocks of kFinBlock
-// windows (inner boundaries + the seam with the previous window) and reduction of the window / read
+// windows (inner boundaries + the seam with the previous window) and reduction of the window
 // partials to the contig summary (fin_summary runs as the last workgroup of k_rle_write).
 // ---------------------------------------------------------------------------------------------
 constexpr int kFinBlock = 1024;
@@ -1528,41 +1344,36 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
     }
 }
 
-// The contig summary: reduction of the per-block window partials and of the read partials.  Run by
+// The contig summary: reduction of the per-block window partials.  Run by
 // one workgroup of kBlock threads (the extra, last workgroup of k_rle_write).
 __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
-                                            const PrepPartial *__restrict__ prep, uint32_t n_prep,
                                             uint32_t extent, uint32_t *__restrict__ err_flag,
                                             DevSummary *__restrict__ out)
 {
     __shared__ unsigned long long s_red[12][kBlock / 64];
-    __shared__ uint32_t s_u[3][kBlock / 64];
+    __shared__ uint32_t s_u[kBlock / 64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned long long acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // [11]: number of runs
-    uint32_t maxraw = 0, maxend = 0, err = 0;
+    uint32_t maxraw = 0;
     for (uint32_t b = tid; b < n_fin; b += kBlock) {
         const FinPartial fp = fin[b];
         acc[11] += fp.n_runs;
-        for (int i = 0; i < 11; ++i) acc[i] += fp.acc[i];        // [9], [10]: the reads k_pileup's short-read form owned
+        for (int i = 0; i < 11; ++i) acc[i] += fp.acc[i];        // [9], [10]: over the reads each window owns
         maxraw = fp.max_raw > maxraw ? fp.max_raw : maxraw;
-    }
-    for (uint32_t i = tid; i < n_prep; i += kBlock) {
-        acc[9] += prep[i].sum_reflen; acc[10] += prep[i].sum_mapq_reflen;
-        maxend = prep[i].max_end > maxend ? prep[i].max_end : maxend; err |= prep[i].err;
     }
 #pragma unroll
     for (int i = 0; i < 12; ++i) {
         const unsigned long long v = wave_sum_u64(acc[i]);
         if (lane == 0) s_red[i][wv] = v;
     }
-    maxraw = wave_max_u32(maxraw); maxend = wave_max_u32(maxend); err = wave_or_u32(err);
-    if (lane == 0) { s_u[0][wv] = maxraw; s_u[1][wv] = maxend; s_u[2][wv] = err; }
+    maxraw = wave_max_u32(maxraw);
+    if (lane == 0) s_u[wv] = maxraw;
     __syncthreads();
     if (tid == 0) {
         unsigned long long tot[12];
         for (int i = 0; i < 12; ++i) { tot[i] = 0; for (int j = 0; j < kBlock / 64; ++j) tot[i] += s_red[i][j]; }
-        uint32_t mr = 0, me = 0, er = 0;
-        for (int j = 0; j < kBlock / 64; ++j) { mr = s_u[0][j] > mr ? s_u[0][j] : mr; me = s_u[1][j] > me ? s_u[1][j] : me; er |= s_u[2][j]; }
+        uint32_t mr = 0;
+        for (int j = 0; j < kBlock / 64; ++j) mr = s_u[j] > mr ? s_u[j] : mr;
         for (int i = 0; i < 6; ++i) out->state_counts[i] = tot[i];
         out->n_covered_bases = tot[6];
         out->quality_bases = tot[7];
@@ -1572,8 +1383,8 @@ __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, 
         out->extent = extent;
         out->max_raw_depth = mr;
         out->n_intervals = tot[11];
-        out->max_end = me;
-        out->err = er | err_flag[0];
+        out->max_end = 0;                    // read ends come from the host's walk (cl_push_reads)
+        out->err = err_flag[0];
         // every kernel of the run is done with the flags: clear them for the next run (saves a memset launch)
         err_flag[0] = 0; err_flag[1] = 0;
     }
@@ -1590,14 +1401,13 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
                                                        const WinPartial *__restrict__ winpart,
                                                        const uint32_t *__restrict__ win_off,
                                                        const FinPartial *__restrict__ fin, uint32_t n_fin,
-                                                       const PrepPartial *__restrict__ prep, uint32_t n_prep,
                                                        uint32_t *__restrict__ err_flag,
                                                        DevSummary *__restrict__ summary,
                                                        uint32_t n_win, uint32_t extent,
                                                        Interval *__restrict__ iv, uint32_t iv_cap)
 {
     if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: the contig summary
-        fin_summary(fin, n_fin, prep, n_prep, extent, err_flag, summary);
+        fin_summary(fin, n_fin, extent, err_flag, summary);
         return;
     }
     // one wave per window: its seam run (if the first state differs from the previous window's last)

@@ -155,8 +155,9 @@ cl_status cl_device_summary(cl_ctx *ctx, void **dev_ptr, size_t *bytes);
 enum { CL_K_PREP = 0, CL_K_BOUNDS = 1, CL_K_PILEUP = 2, CL_K_RLE = 3, CL_K_COUNT = 4 };
 /* When on, every cl_contig_run brackets each kernel group with hipEvents on the stream. */
 cl_status cl_set_profiling(cl_ctx *ctx, int on);
-/* Accumulated milliseconds per kernel group and number of runs since the last reset.  The window
- * bounds ride in the prep launch: their time is part of CL_K_PREP and CL_K_BOUNDS reads 0. */
+/* Accumulated milliseconds per kernel group and number of runs since the last reset.  The per-read index (read
+ * ends, CIGAR checkpoints) and the window bounds are built on the host at cl_contig_upload, not in a run: CL_K_PREP
+ * and CL_K_BOUNDS read 0 (the slots are kept so that the table's layout does not change). */
 cl_status cl_get_kernel_ms(cl_ctx *ctx, double ms[CL_K_COUNT], uint64_t *n_runs);
 cl_status cl_reset_kernel_ms(cl_ctx *ctx);
 /* Bytes of the resident inputs the pileup kernel must read at least once (quality bytes, per-read fields, CIGAR

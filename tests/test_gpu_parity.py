@@ -242,6 +242,68 @@ def test_engine_errors_are_reported():
             Engine(opt, 0).contig_run()
 
 
+def _ops(*pairs):
+    code = {"M": 0, "I": 1, "D": 2, "N": 3, "S": 4, "H": 5, "P": 6, "=": 7, "X": 8}
+    return [(l << 4) | code[o] for o, l in pairs]
+
+
+@pytest.mark.parametrize("shape", ["short", "long"])
+def test_cigar_errors_found_by_the_upload_walk(shape):
+    """The read ends and the malformed-CIGAR flags of reads with more than 64 operations (and of every read of a
+    long-read shaped contig) come from the host's walk at cl_push_reads: a zero-length reference-consuming operation
+    deep inside such a read, and an end beyond the 32-bit coordinate range, are reported like the device-found ones."""
+    from decodingustools_amd import EngineError
+    opt = CallableOptions()
+    # a 101-operation read: 50 x (20M 1I) + 20M; the variant with a 0D at operation 70
+    good = _ops(*([("M", 20), ("I", 1)] * 50 + [("M", 20)]))
+    bad = list(good); bad[70] = (0 << 4) | 2
+    qn = 50 * 21 + 20
+    filler = ([5] * 40, [60] * 40, list(range(41)), _ops(*[("M", 10)] * 40), [10 * i for i in range(41)], np.full(400, 30, np.uint8))
+
+    def run(cig):
+        with Engine(opt, 0) as eng:
+            eng.contig_begin(0, 5000, None)
+            if shape == "short":                              # short-read shape: < 8 operations per read on average
+                eng.push_reads(*filler)
+            eng.push_reads([10], [60], [0, len(cig)], cig, [0, qn], np.full(qn, 30, np.uint8))
+            return eng.contig_finish()
+    ok = run(good)
+    assert ok.summary.summed_coverage == 1020 + (400 if shape == "short" else 0)
+    with pytest.raises(EngineError, match="CIGAR"):
+        run(bad)
+    far = _ops(*([("M", 20), ("I", 1)] * 40 + [("N", (1 << 28) - 1)] * 17 + [("M", 20)]))     # 17 x 2^28 > 2^32
+    with pytest.raises(EngineError, match="32-bit"):
+        run(far)
+
+
+def test_long_reads_in_tiles_with_a_refused_tile_between(tmp_path):
+    """The CIGAR checkpoints are indexed by the operation's number in the contig's CIGAR array: tiles that cut that
+    array at arbitrary places, and a refused tile between two good ones, give the single-push result."""
+    from decodingustools_amd import EngineError
+    opt = CallableOptions()
+    L = 200_000
+    rec = synth.long_read_contig(L, 40, 4242)
+    ref = synth.make_reference(L, 4242)
+    cuts = [0, rec.n // 5, rec.n // 5 + 1, rec.n // 2 + 3, rec.n]
+
+    def push(eng, r):
+        eng.push_reads(r.pos, r.mapq, r.cigar_off, r.cigar, r.qual_off, r.qual)
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref); push(eng, rec)
+        want = eng.contig_finish()
+        eng.contig_begin(0, L, ref)
+        for k in range(len(cuts) - 1):
+            t = rec.slice(cuts[k], cuts[k + 1])
+            if k == 2:
+                bad = rec.slice(cuts[k], cuts[k + 1])
+                bad.pos = bad.pos.copy(); bad.pos[-1] = 0                     # unsorted: refused after its walk
+                with pytest.raises(EngineError):
+                    push(eng, bad)
+            push(eng, t)
+        got = eng.contig_finish()
+    assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
+
+
 def test_quality_prefetch_is_claimed_by_the_matching_tile_and_harmless_otherwise():
     """cl_contig_prefetch_qual: the bytes travel before their tile is pushed; the push that presents exactly them does
     not send them again, any other sequence of calls (another tile first, a reserve in between, no push at all, a

@@ -278,6 +278,14 @@ def run_chr21(args, rank, world, dev_id, torch, dist, coll_dev):
     first = eng.contig_collect()
     log(f"[bench r{rank}] end-to-end first pass (host admission + PCIe + kernels + BED): {e2e:.2f}s "
         f"= {L / e2e / 1e9:.3f} Gbase/s; intervals {first.summary.n_intervals}")
+    # the same call once more: what every contig but a process's first costs (device and staging buffers exist,
+    # code objects are loaded); its BED goes to a scratch file
+    counter2 = CallableProfiler(os.path.join(tmpd, f"g{rank}_again.bed"))
+    t0 = time.perf_counter()
+    process_single_contig(eng, counter2, ContigProfiler("chr21", L), opt, tid, rec, ref)
+    counter2.close()
+    e2e_next = time.perf_counter() - t0
+    log(f"[bench r{rank}] end-to-end, the same contig again on the warm engine: {e2e_next:.3f}s")
 
     # ---- timed region: resident contig, blocks of K steps ----
     dts = timed_blocks(eng.contig_run, eng.sync, args, world, dist, torch, coll_dev)
@@ -316,6 +324,7 @@ def run_chr21(args, rank, world, dev_id, torch, dist, coll_dev):
                    "ms_per_step_min": min(dts) * 1e3 / args.steps, "ms_per_step_max": max(dts) * 1e3 / args.steps},
         "roofline": roofline(inb + outb, kms["pileup"], ms_step, kms),
         "end_to_end_first_pass_s": e2e,
+        "end_to_end_next_pass_s": e2e_next,
     }
     if world == 1 and args.cpu_sample != 0:
         Ls = L if args.cpu_sample < 0 else min(args.cpu_sample, L)

@@ -29,14 +29,18 @@ using namespace clk;
 namespace {
 
 // rocTX ranges around the host-visible phases (rocprofv3 --marker-trace shows them); bound at run time so
-// that the library does not depend on the profiler's marker library being installed
+// that the library does not depend on the profiler's marker library being installed -- and only when that library
+// is in the process already (a profiler brought it) or DUT_ROCTX=1 asks for it: loading it cold took 35 ms of a
+// process's first contig
 struct Roctx {
     int (*push)(const char *) = nullptr;
     int (*pop)() = nullptr;
     Roctx()
     {
+        const char *want = getenv("DUT_ROCTX");
+        const int mode = RTLD_NOW | RTLD_LOCAL | ((want && *want == '1') ? 0 : RTLD_NOLOAD);
         for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
-            void *h = dlopen(lib, RTLD_NOW | RTLD_LOCAL);
+            void *h = dlopen(lib, mode);
             if (!h) continue;
             push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
             pop = (int (*)())dlsym(h, "roctxRangePop");
@@ -78,6 +82,7 @@ template <typename T> struct RawVec {
     const T &back() const { return p[n - 1]; }
     void clear() { n = 0; }
     void release() { free(p); p = nullptr; n = cap = 0; }
+    void swap(RawVec &o) { std::swap(p, o.p); std::swap(n, o.n); std::swap(cap, o.cap); }
     void reserve(size_t want)
     {
         if (want <= cap) return;
@@ -179,7 +184,11 @@ struct PinRing {
             if (hipStreamCreateWithFlags(&copy_stream[t], hipStreamNonBlocking) != hipSuccess) return;
             for (int b = 0; b < 2; ++b) {
                 if (hipHostMalloc(reinterpret_cast<void **>(&pin[t][b]), kPinBytes, hipHostMallocDefault) != hipSuccess) return;
-                if (hipEventCreateWithFlags(&pin_ev[t][b], hipEventDisableTiming) != hipSuccess) return;
+                // blocking waits: a copier that spins on its buffer's event burns a core the host stages beside it
+                // need (DUT_PIN_SPIN=1: the runtime's default busy wait, for comparison)
+                const char *spin = getenv("DUT_PIN_SPIN");
+                const unsigned flags = hipEventDisableTiming | ((spin && *spin == '1') ? 0u : (unsigned)hipEventBlockingSync);
+                if (hipEventCreateWithFlags(&pin_ev[t][b], flags) != hipSuccess) return;
             }
         }
         ok = true;
@@ -212,6 +221,21 @@ static std::shared_ptr<PinRing> acquire_ring(int device)
     }
     return r;
 }
+
+// The host staging arrays of a contig (hundreds of megabytes) are only needed between cl_contig_begin and
+// cl_contig_upload.  A context hands them to this process-wide pool when its contig is uploaded and takes a set back
+// at its next cl_contig_begin -- so does a fresh context: memory that has been touched before is written at several
+// times the rate of newly mapped pages (staging a chr21-sized contig: 5 ms against 31 ms), and callers that keep one
+// context per resident contig would otherwise fault a new set in for every contig.  At most kStagingSets sets are kept.
+struct StagingSet {
+    RawVec<uint8_t> ref, mapq;
+    RawVec<int32_t> pos;
+    RawVec<uint32_t> cigar_off, cigar, end, ck_x, ck_y;
+    RawVec<unsigned long long> qual_off;
+};
+constexpr size_t kStagingSets = 2;
+static std::mutex g_staging_mu;
+static std::vector<std::unique_ptr<StagingSet>> g_staging;
 
 struct cl_ctx {
     int device = 0;
@@ -304,6 +328,38 @@ struct cl_ctx {
     uint64_t site_bytes = 0;
 };
 
+static void swap_staging(cl_ctx *c, StagingSet &o)
+{
+    c->h_ref.swap(o.ref); c->h_mapq.swap(o.mapq); c->h_pos.swap(o.pos); c->h_cigar_off.swap(o.cigar_off);
+    c->h_cigar.swap(o.cigar); c->h_end.swap(o.end); c->h_ck_x.swap(o.ck_x); c->h_ck_y.swap(o.ck_y); c->h_qual_off.swap(o.qual_off);
+}
+// a context without staging memory of its own takes a pooled set (cl_contig_begin) ...
+static void take_staging(cl_ctx *c)
+{
+    if (c->h_pos.cap || c->h_cigar.cap || c->h_qual_off.cap) return;
+    std::unique_ptr<StagingSet> s;
+    {
+        std::lock_guard<std::mutex> g(g_staging_mu);
+        if (g_staging.empty()) return;
+        s = std::move(g_staging.back()); g_staging.pop_back();
+    }
+    swap_staging(c, *s);                                   // what the context had (nothing) is freed with s
+}
+// ... and gives its set back once the contig is on the device (cl_contig_upload); a full pool keeps the larger sets
+static void give_staging(cl_ctx *c)
+{
+    std::unique_ptr<StagingSet> s(new (std::nothrow) StagingSet());
+    if (!s) return;
+    swap_staging(c, *s);
+    s->ref.clear(); s->mapq.clear(); s->pos.clear(); s->cigar_off.clear(); s->cigar.clear(); s->end.clear();
+    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear();
+    std::lock_guard<std::mutex> g(g_staging_mu);
+    if (g_staging.size() < kStagingSets) { g_staging.push_back(std::move(s)); return; }
+    size_t small = 0;
+    for (size_t i = 1; i < g_staging.size(); ++i) if (g_staging[i]->cigar_off.cap < g_staging[small]->cigar_off.cap) small = i;
+    if (g_staging[small]->cigar_off.cap < s->cigar_off.cap) g_staging[small].swap(s);      // s (the smaller one) is freed
+}
+
 namespace {
 
 cl_status fail(cl_ctx *c, cl_status s, const std::string &m)
@@ -382,7 +438,9 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
                 e = hipMemcpyAsync(dst + off, R->pin[t][b], len, hipMemcpyHostToDevice, R->copy_stream[t]);
                 if (e == hipSuccess) e = hipEventRecord(R->pin_ev[t][b], R->copy_stream[t]);
             }
-            const hipError_t e2 = hipStreamSynchronize(R->copy_stream[t]);
+            // the thread's last transfers (one per buffer it used), waited for on their events
+            hipError_t e2 = hipSuccess;
+            for (int b = 0; b < 2 && b < k; ++b) { const hipError_t w = hipEventSynchronize(R->pin_ev[t][b]); if (e2 == hipSuccess) e2 = w; }
             c->copy_err[t] = e != hipSuccess ? e : e2;
         }));
     }
@@ -694,6 +752,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     if (contig_len > 0xFFF00000u) return fail(c, CL_ERR_RANGE, "contig length beyond the engine's 32-bit range");
     if (ref_len && !ref_bases) return fail(c, CL_ERR_INVALID, "ref_bases is null");
     drop_prefetch(c);
+    take_staging(c);
     c->tid = tid; c->contig_len = contig_len;
     const uint64_t nref = std::min<uint64_t>(ref_len, contig_len);
     c->h_ref.clear(); c->h_ref.append(ref_bases, nref);
@@ -1050,10 +1109,12 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     if (s != CL_OK) return s;
     tmr.lap("upload: extent, ref, bounds");
     if (c->d_iv.cap == 0) HIP_TRY(c, c->d_iv.reserve(1u << 20));
-    // The staged copy is no longer needed; its memory is kept for the context's next contig (giving back and
-    // re-faulting a few hundred megabytes per contig was a fifth of a contig's host time).  cl_destroy frees it.
+    // The staged copy is no longer needed; its memory goes to the process's staging pool for the next contig, this
+    // context's or another's (giving back and re-faulting a few hundred megabytes per contig was a fifth of a contig's
+    // host time).
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear();
+    give_staging(c);
     std::vector<uint8_t>().swap(c->h_qual);
     tmr.lap("upload: done");
     c->uploaded = true; c->ran = false;
@@ -1165,11 +1226,16 @@ cl_status cl_contig_collect(cl_ctx *c, cl_contig_summary *out, const cl_interval
 
 cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *out, const cl_interval **intervals, size_t *n_intervals)
 {
+    StageTimer tmr;
     cl_status s = cl_contig_upload(c);
     if (s != CL_OK) return s;
+    tmr.lap("finish: upload");
     s = cl_contig_run(c);
     if (s != CL_OK) return s;
-    return cl_contig_collect(c, out, intervals, n_intervals);
+    tmr.lap("finish: run (launches)");
+    s = cl_contig_collect(c, out, intervals, n_intervals);
+    tmr.lap("finish: collect");
+    return s;
 }
 
 cl_status cl_device_summary(cl_ctx *c, void **dev_ptr, size_t *bytes)

@@ -299,7 +299,25 @@ int dut_profiler_feed_contig(dut_profiler *p, const char *contig, const cl_inter
         std::array<uint64_t, 6> &slot = p->counts[contig];      // value-initialised to zeros on first use
         for (int i = 0; i < 6; ++i) slot[i] += state_counts ? state_counts[i] : 0;
     }
-    for (size_t i = 0; i < n_iv; ++i) {
+    // The engine's intervals are maximal runs: neighbours differ in state.  Then, once the first interval has gone
+    // through the rules below, every further one just writes its predecessor and takes its place -- line i of the
+    // contig is interval i, whatever came before -- and the text of a contig with hundreds of thousands of lines is
+    // formatted in chunks on all host threads (it was a tenth of a contig's host time on one).  Anything else (equal
+    // neighbours, a malformed interval, the plot ranges wanted) takes the sequential loop.
+    size_t n_seq = n_iv;
+    if (n_iv >= 4096 && !p->plots) {
+        const size_t grain = 16384, nchunk = (n_iv + grain - 1) / grain;
+        std::vector<uint8_t> ok(nchunk, 1);
+        dut::parallel_for(nchunk, 1, [&](size_t c) {
+            const size_t a = c * grain, b = std::min(n_iv, a + grain);
+            bool good = true;
+            for (size_t i = a; i < b; ++i)
+                good = good && iv[i].state <= 5 && iv[i].end > iv[i].start && (i == 0 || iv[i].state != iv[i - 1].state);
+            ok[c] = good;
+        });
+        if (std::all_of(ok.begin(), ok.end(), [](uint8_t v) { return v != 0; })) n_seq = 1;
+    }
+    for (size_t i = 0; i < n_seq; ++i) {
         const uint64_t start = iv[i].start, end = iv[i].end;
         const uint32_t state = iv[i].state;
         if (state > 5 || end <= start) return CL_ERR_INVALID;
@@ -325,6 +343,30 @@ int dut_profiler_feed_contig(dut_profiler *p, const char *contig, const cl_inter
             p->write_state();                                 // :147-151
             p->cur_contig = contig; p->cur_start = start; p->cur_end = end; p->cur_state = state;
         }
+    }
+    if (n_seq < n_iv) {
+        // intervals 1 .. n-1: the current state (interval 0, as the rules above left it) is written, then every
+        // interval but the last; the last becomes the current state
+        p->write_state();
+        p->flush_text();
+        const size_t m = n_iv - 1 - n_seq;                    // lines of intervals n_seq .. n_iv - 2
+        const size_t grain = 16384, nchunk = (m + grain - 1) / grain;
+        const size_t name_len = strlen(contig);
+        std::vector<std::string> part(nchunk);
+        dut::parallel_for(nchunk, 1, [&](size_t c) {
+            const size_t a = n_seq + c * grain, b = std::min(n_seq + m, a + grain);
+            std::string &o = part[c];
+            o.reserve((b - a) * (name_len + 48));
+            for (size_t i = a; i < b; ++i) {
+                o.append(contig, name_len); o.push_back('\t');
+                dut_profiler::put_u64(o, iv[i].start); o.push_back('\t');
+                dut_profiler::put_u64(o, iv[i].end); o.push_back('\t');
+                o += kStateNames[iv[i].state]; o.push_back('\n');
+            }
+        });
+        for (const std::string &o : part) fwrite(o.data(), 1, o.size(), p->bed);
+        const cl_interval &last = iv[n_iv - 1];
+        p->cur_contig = contig; p->cur_start = last.start; p->cur_end = last.end; p->cur_state = last.state;
     }
     p->write_state();                                         // finish_contig, :64-66 (state kept)
     return CL_OK;
@@ -648,18 +690,29 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
         });
         for (size_t c = 0; c < nchunk; ++c) { n_in += c_in[c]; in_order = in_order && c_ok[c]; }
     }
+    dut_stage_time("  push: order check", tm);
     if (in_order && a0 < n_keep) {
-        std::vector<uint32_t> patched;
+        // the patched copy lives in a per-thread scratch buffer that is kept from contig to contig (a fresh,
+        // zero-filled vector of a contig's 40 MB of CIGAR words cost more than the patching)
+        struct Scratch { uint32_t *p = nullptr; size_t cap = 0; ~Scratch() { free(p); } };
+        static thread_local Scratch patched;
         const uint32_t *cig = rec->cigar;
         if (n_in != n_keep - a0) {
-            patched.resize(rec->cigar_off[n_keep]);
-            uint32_t *pp = patched.data();
+            const size_t need = rec->cigar_off[n_keep];
+            if (need > patched.cap) {
+                free(patched.p); patched.p = nullptr; patched.cap = 0;
+                patched.p = static_cast<uint32_t *>(malloc((need + need / 8 + 16) * sizeof(uint32_t)));
+                if (!patched.p) return CL_ERR_NOMEM;
+                patched.cap = need + need / 8 + 16;
+            }
+            uint32_t *pp = patched.p;
             dut::parallel_for(n_keep, 1u << 16, [&](size_t i) {           // reads in front of a0 keep their words: they are not in the tile
                 const bool keep = i < a0 || acc[i];
                 for (uint32_t k = rec->cigar_off[i]; k < rec->cigar_off[i + 1]; ++k) pp[k] = keep ? rec->cigar[k] : ((rec->cigar[k] & ~15u) | 5u);
             });
-            cig = patched.data();
+            cig = patched.p;
         }
+        dut_stage_time("  push: patched CIGARs", tm);
         cl_read_tile t;
         t.n_reads = n_keep - a0; t.pos = rec->pos + a0; t.mapq = rec->mapq + a0; t.cigar_off = rec->cigar_off + a0;
         t.cigar = cig; t.qual_off = rec->qual_off + a0; t.qual = rec->qual;

@@ -1,14 +1,18 @@
 // host_parallel.h -- the host side's thread helper: DUT_THREADS (default: the machine's cores, at
-// most 16) worker threads, work handed out in chunks through an atomic counter.
+// most 16) threads -- the caller and a pool of persistent workers --, work handed out in chunks through an atomic
+// counter.
 #pragma once
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
 #include <cstdlib>
 #include <exception>
 #include <mutex>
 #include <system_error>
 #include <thread>
 #include <vector>
+
+#include <pthread.h>
 
 namespace dut {
 
@@ -23,50 +27,133 @@ inline int worker_threads()
     return n;
 }
 
-// joins its threads when it goes out of scope, whichever way
-struct JoinAll {
-    std::vector<std::thread> &th;
-    ~JoinAll() { for (auto &t : th) if (t.joinable()) t.join(); }
+// The workers: worker_threads() - 1 threads that live as long as the process and sleep between jobs (a contig passes
+// through some twenty parallel loops; starting and joining fifteen threads for each was a tenth of its host time, and
+// much more whenever another thread of the process was faulting pages in at the time -- thread stacks are mapped under
+// the same lock).  A job is a counter of chunks; whoever is idle takes chunks of the first job that has some left, the
+// caller included, so loops started from several threads at once, or from inside a chunk, share the workers and always
+// make progress on the caller's own thread.
+namespace detail {
+struct Job {
+    std::atomic<size_t> next{0};
+    size_t chunks = 0;
+    void (*run)(void *ctx, size_t chunk) = nullptr;   // must not throw
+    void *ctx = nullptr;
+    int active = 0;                                   // workers inside the job (guarded by Pool::mu)
 };
+
+struct Pool {
+    std::mutex mu;
+    std::condition_variable work_cv, done_cv;
+    std::vector<Job *> jobs;                          // guarded by mu
+    std::vector<std::thread> workers;
+    bool stop = false;
+
+    explicit Pool(int n)
+    {
+        workers.reserve((size_t)std::max(0, n));
+        for (int i = 0; i < n; ++i) {
+            try { workers.emplace_back([this] { loop(); }); } catch (const std::system_error &) { break; }   // fewer workers, same result
+        }
+    }
+    ~Pool()
+    {
+        { std::lock_guard<std::mutex> g(mu); stop = true; }
+        work_cv.notify_all();
+        for (auto &t : workers) if (t.joinable()) t.join();
+    }
+    Pool(const Pool &) = delete;
+    Pool &operator=(const Pool &) = delete;
+
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            if (stop) return;
+            Job *j = nullptr;
+            for (Job *c : jobs) if (c->next.load(std::memory_order_relaxed) < c->chunks) { j = c; break; }
+            if (!j) { work_cv.wait(lk); continue; }
+            j->active += 1;                           // under the lock: the caller cannot miss it
+            lk.unlock();
+            for (;;) {
+                const size_t c = j->next.fetch_add(1);
+                if (c >= j->chunks) break;
+                j->run(j->ctx, c);
+            }
+            lk.lock();
+            if (--j->active == 0) done_cv.notify_all();
+        }
+    }
+
+    // runs the job to completion with the caller taking part; returns when no thread is inside it any more
+    void run(Job &job)
+    {
+        if (!workers.empty() && job.chunks > 1) {
+            { std::lock_guard<std::mutex> g(mu); jobs.push_back(&job); }
+            const size_t wake = std::min(job.chunks - 1, workers.size());
+            if (wake >= workers.size()) work_cv.notify_all(); else for (size_t i = 0; i < wake; ++i) work_cv.notify_one();
+        }
+        for (;;) {
+            const size_t c = job.next.fetch_add(1);
+            if (c >= job.chunks) break;
+            job.run(job.ctx, c);
+        }
+        if (!workers.empty() && job.chunks > 1) {
+            std::unique_lock<std::mutex> lk(mu);
+            jobs.erase(std::find(jobs.begin(), jobs.end(), &job));      // no worker enters from here on
+            done_cv.wait(lk, [&] { return job.active == 0; });
+        }
+    }
+};
+
+inline std::atomic<Pool *> &pool_ptr() { static std::atomic<Pool *> p{nullptr}; return p; }
+
+// The process's pool, made on first use and never destroyed (its threads sleep on a condition variable that must
+// outlive every static destructor).  A forked child starts without one: the parent's threads do not exist there.
+inline Pool *pool()
+{
+    Pool *p = pool_ptr().load(std::memory_order_acquire);
+    if (p) return p;
+    static const int reg = pthread_atfork(nullptr, nullptr, [] { pool_ptr().store(nullptr, std::memory_order_release); });
+    (void)reg;
+    Pool *made = new Pool(worker_threads() - 1);
+    if (pool_ptr().compare_exchange_strong(p, made, std::memory_order_acq_rel)) return made;
+    delete made;                                      // another thread was first
+    return p;
+}
+} // namespace detail
 
 // fn(i) for i in [0, n), chunks of `grain` consecutive i per hand-out.  An exception thrown by fn (bad_alloc from a
 // vector that grows, say) never ends a worker thread -- that would be std::terminate --: the first one is kept, the
-// remaining chunks are skipped, every thread is joined, and it is rethrown on the calling thread, where the C ABI
-// wrappers turn it into a status.
+// remaining chunks are skipped, every thread has left the loop, and it is rethrown on the calling thread, where the
+// C ABI wrappers turn it into a status.
 template <class F>
 void parallel_for(size_t n, size_t grain, F fn)
 {
     if (grain == 0) grain = 1;
     const size_t chunks = (n + grain - 1) / grain;
-    const int nt = (int)std::min<size_t>((size_t)worker_threads(), chunks);
-    if (nt <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
-    std::atomic<size_t> next{0};
-    std::exception_ptr first;
-    std::mutex first_mu;
-    auto body = [&]() noexcept {
+    if (chunks <= 1 || worker_threads() <= 1) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+    struct Ctx {
+        F &fn; size_t n, grain, chunks;
+        detail::Job job;
+        std::exception_ptr first;
+        std::mutex first_mu;
+    } ctx{fn, n, grain, chunks, {}, nullptr, {}};
+    ctx.job.chunks = chunks;
+    ctx.job.ctx = &ctx;
+    ctx.job.run = [](void *v, size_t c) {
+        Ctx &x = *static_cast<Ctx *>(v);
         try {
-            for (;;) {
-                const size_t c = next.fetch_add(1);
-                if (c >= chunks) break;
-                const size_t e = std::min(n, (c + 1) * grain);
-                for (size_t i = c * grain; i < e; ++i) fn(i);
-            }
+            const size_t e = std::min(x.n, (c + 1) * x.grain);
+            for (size_t i = c * x.grain; i < e; ++i) x.fn(i);
         } catch (...) {
-            next.store(chunks);                                   // nobody starts another chunk
-            std::lock_guard<std::mutex> g(first_mu);
-            if (!first) first = std::current_exception();
+            x.job.next.store(x.chunks);                           // nobody starts another chunk
+            std::lock_guard<std::mutex> g(x.first_mu);
+            if (!x.first) x.first = std::current_exception();
         }
     };
-    {
-        std::vector<std::thread> th;
-        JoinAll join{th};
-        th.reserve((size_t)nt);
-        for (int t = 1; t < nt; ++t) {
-            try { th.emplace_back(body); } catch (const std::system_error &) { break; }   // no more threads: the ones we have do the work
-        }
-        body();
-    }
-    if (first) std::rethrow_exception(first);
+    detail::pool()->run(ctx.job);
+    if (ctx.first) std::rethrow_exception(ctx.first);
 }
 
 // A thread that is joined when it goes out of scope (an exception unwinding past a joinable std::thread is

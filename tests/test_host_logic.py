@@ -111,6 +111,64 @@ def test_bed_writer_duplicate_line_multi_contig_random(tmp_path):
         assert lines[own[-1]] == lines[own[-2]]
 
 
+def _writer_rules(feeds):
+    """callable_profiler.rs:39-66, 122-155 run position by position over the intervals' positions, restated on
+    intervals for this test only: the text `dut_profiler_feed_contig` must produce."""
+    names = ["REF_N", "CALLABLE", "NO_COVERAGE", "LOW_COVERAGE", "EXCESSIVE_COVERAGE", "POOR_MAPPING_QUALITY"]
+    out, cur = [], None
+
+    def write():
+        if cur is not None:
+            out.append(f"{cur[0]}\t{cur[1]}\t{cur[2]}\t{names[cur[3]]}\n")
+    for contig, iv in feeds:
+        for s, e, st in iv.tolist():
+            if cur is None:
+                if st == 0:
+                    cur = [contig, 0, e, st]
+                else:
+                    if s > 0:
+                        cur = [contig, 0, s, 0]; write()
+                    cur = [contig, s, e, st]
+            elif cur[0] == contig and cur[3] == st:
+                cur[2] = e
+            else:
+                write(); cur = [contig, s, e, st]
+        write()
+    return "".join(out)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_bed_text_of_long_interval_lists_is_the_same_in_chunks(seed, tmp_path):
+    """Contigs with tens of thousands of intervals have their lines formatted in chunks on all host threads; the
+    bytes are those of the one-line-at-a-time rules (also taken when neighbours share a state, and when the plot
+    ranges are wanted)."""
+    rng = np.random.default_rng(seed)
+    feeds = []
+    for c in range(3):
+        n = int(rng.integers(5000, 60000)) if c != 1 or seed % 2 else 100
+        lens = rng.integers(1, 400, size=n)
+        ends = np.cumsum(lens) + (int(rng.integers(0, 50)) if seed % 3 else 0)
+        starts = ends - lens
+        st = rng.integers(0, 6, size=n)
+        if seed != 4 or c != 2:                            # maximal runs, as the engine gives them ...
+            for i in range(1, n):
+                if st[i] == st[i - 1]:
+                    st[i] = (st[i] + 1 + int(rng.integers(0, 5))) % 6
+                    if st[i] == st[i - 1]: st[i] = (st[i] + 1) % 6
+        if seed == 1 and c == 0: st[0] = 0                 # ... the first one REF_N or not, at 0 or not
+        feeds.append((f"chr{c + 1}", np.stack([starts, ends, st], axis=1).astype(np.uint32)))
+    want = _writer_rules(feeds)
+    for plots in (False, True):
+        path = str(tmp_path / f"w{int(plots)}.bed")
+        prof = CallableProfiler(path)
+        if plots:
+            prof.enable_plots(int(max(iv[-1, 1] for _, iv in feeds)))
+        for name, iv in feeds:
+            prof.feed_contig(name, ContigResult(summary=_FakeSummary([0] * 6), intervals=iv))
+        prof.close()
+        assert open(path).read() == want, plots
+
+
 @pytest.mark.parametrize("seed", range(12))
 @pytest.mark.parametrize("max_depth", [0, 1, 3, 8, 500])
 def test_admission_rule_matches_the_oracle_engine(seed, max_depth):

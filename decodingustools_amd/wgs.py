@@ -123,7 +123,7 @@ class ResidentShard:
 def build_shard(rank: int, world: int, device_id: int, options: CallableOptions, depth: float = 30.0,
                 scale: float = 1.0, stream: int = 0, gen_threads: int = 4, log=None,
                 keep_records: Optional[dict] = None) -> ResidentShard:
-    """Generate this rank's contigs (a few ahead on host threads: numpy releases the GIL), push each
+    """Generate this rank's contigs (`gen_threads` at a time on host threads: numpy releases the GIL), push each
     through the module API once (admission + H2D + kernels + D2H of the runs) and keep it resident.
     `keep_records`: a dict that receives {tid: (records, ref)} (tests compare against the oracle)."""
     contigs = genome(scale)
@@ -136,30 +136,27 @@ def build_shard(rank: int, world: int, device_id: int, options: CallableOptions,
         rec, ref = make_contig(item[0], item[2], depth)
         return rec, ref, time.perf_counter() - t0
 
-    with ThreadPoolExecutor(max(1, gen_threads)) as pool:
-        futs = {}
-        nxt = 0
-
-        def top_up():
-            nonlocal nxt
-            while nxt < len(mine) and len(futs) < max(1, gen_threads):
-                futs[nxt] = pool.submit(gen, mine[nxt])
-                nxt += 1
-        top_up()
-        for i, (tid, name, L) in enumerate(mine):
-            rec, ref, gen_s = futs.pop(i).result()
-            top_up()
-            eng = Engine(options, device_id, stream)
-            t0 = time.perf_counter()
-            out = engine_process_contig_runs(eng, options, tid, name, L, rec, ref)
-            first = time.perf_counter() - t0
-            rc = ResidentContig(tid, name, L, eng, out, rec.n, int(rec.qual.shape[0]),
-                                dev_summary=device_summary_tensor(eng), first_pass_s=first, gen_s=gen_s)
-            shard.mine.append(rc)
-            if keep_records is not None:
-                keep_records[tid] = (rec, ref)
-            if log:
-                log(f"[wgs r{rank}] {name}: {L} bp, {rec.n} reads, generated in {gen_s:.1f}s, first pass {first:.2f}s, "
-                    f"{out.intervals.shape[0]} runs")
-            del rec, ref
+    # Batches of `gen_threads` contigs: generated side by side, then -- with no generator running, so that the first
+    # passes are timed on a quiet host like a real run's -- pushed through the module API one after the other.
+    B = max(1, gen_threads)
+    with ThreadPoolExecutor(B) as pool:
+        for b0 in range(0, len(mine), B):
+            batch = mine[b0:b0 + B]
+            made = [f.result() for f in [pool.submit(gen, item) for item in batch]]
+            for i, (tid, name, L) in enumerate(batch):
+                (rec, ref, gen_s), made[i] = made[i], None           # the records are freed contig by contig
+                eng = Engine(options, device_id, stream)
+                t0 = time.perf_counter()
+                out = engine_process_contig_runs(eng, options, tid, name, L, rec, ref)
+                first = time.perf_counter() - t0
+                rc = ResidentContig(tid, name, L, eng, out, rec.n, int(rec.qual.shape[0]),
+                                    dev_summary=device_summary_tensor(eng), first_pass_s=first, gen_s=gen_s)
+                shard.mine.append(rc)
+                if keep_records is not None:
+                    keep_records[tid] = (rec, ref)
+                if log:
+                    log(f"[wgs r{rank}] {name}: {L} bp, {rec.n} reads, generated in {gen_s:.1f}s, first pass {first:.2f}s, "
+                        f"{out.intervals.shape[0]} runs")
+                del rec, ref
+            del made
     return shard

@@ -887,7 +887,10 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     //      the (reference, query) position before every operation whose index in the contig's CIGAR array is a multiple
     //      of 64, where k_pileup starts its walk of such a read instead of at its first operation.  In chunks, on all
     //      host threads. ----
-    const size_t grain = 65536, nchunk = (n + grain - 1) / grain;
+    // (chunks of at most 65 536 reads; long reads -- few records, thousands of operations each -- get smaller ones so
+    // that every thread has some)
+    const size_t grain = dut::grain_for(n, 65536);
+    const size_t nchunk = (n + grain - 1) / grain;
     struct Chunk { int bad = 0; uint32_t n_long = 0, err = 0; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide; };
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();

@@ -514,7 +514,7 @@ static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t con
     // (not value-initialised: the pages are first touched by the threads that fill them)
     std::unique_ptr<uint64_t[]> rlen_buf(new uint64_t[rec->n ? rec->n : 1]);
     uint64_t *rlen = rlen_buf.get();
-    dut::parallel_for(rec->n, 65536, [&](size_t i) { rlen[i] = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]); });
+    dut::parallel_for(rec->n, dut::grain_for(rec->n, 65536), [&](size_t i) { rlen[i] = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]); });
     dut_stage_time("  admit: spans", tm);
     bool any_pushed = false;
     int64_t cur_start = -1;
@@ -706,7 +706,7 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
                 patched.cap = need + need / 8 + 16;
             }
             uint32_t *pp = patched.p;
-            dut::parallel_for(n_keep, 1u << 16, [&](size_t i) {           // reads in front of a0 keep their words: they are not in the tile
+            dut::parallel_for(n_keep, dut::grain_for(n_keep, 1u << 16), [&](size_t i) {           // reads in front of a0 keep their words: they are not in the tile
                 const bool keep = i < a0 || acc[i];
                 for (uint32_t k = rec->cigar_off[i]; k < rec->cigar_off[i + 1]; ++k) pp[k] = keep ? rec->cigar[k] : ((rec->cigar[k] & ~15u) | 5u);
             });

@@ -27,6 +27,14 @@ inline int worker_threads()
     return n;
 }
 
+// hand-out size for a loop over n records whose cost per record varies by orders of magnitude (short reads: millions
+// of records of a few CIGAR operations; long reads: a few hundred thousand of thousands each): at most `most`, small
+// enough that every thread gets several hand-outs
+inline size_t grain_for(size_t n, size_t most)
+{
+    return std::min(most, std::max<size_t>(64, n / (16 * (size_t)worker_threads())));
+}
+
 // The workers: worker_threads() - 1 threads that live as long as the process and sleep between jobs (a contig passes
 // through some twenty parallel loops; starting and joining fifteen threads for each was a tenth of its host time, and
 // much more whenever another thread of the process was faulting pages in at the time -- thread stacks are mapped under

@@ -388,6 +388,35 @@ def test_a_refused_tile_leaves_the_contig_as_it_was():
     assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
 
 
+def test_contexts_that_interleave_their_contigs_do_not_share_staging():
+    """The host staging arrays are pooled across contexts (taken at cl_contig_begin, given back at upload): two
+    engines whose begin / push / finish calls interleave, and one that abandons a contig half way, give what each
+    contig gives alone."""
+    opt = CallableOptions()
+    L1, L2 = 350_000, 200_000
+    r1, r2 = synth.short_read_contig(L1, 30, 11), synth.long_read_contig(L2, 30, 12)
+    f1, f2 = synth.make_reference(L1, 11), synth.make_reference(L2, 12)
+
+    def push(eng, r):
+        eng.push_reads(r.pos, r.mapq, r.cigar_off, r.cigar, r.qual_off, r.qual)
+    with Engine(opt, 0) as a:
+        a.contig_begin(0, L1, f1); push(a, r1); want1 = a.contig_finish()
+        a.contig_begin(1, L2, f2); push(a, r2); want2 = a.contig_finish()
+    with Engine(opt, 0) as a, Engine(opt, 0) as b, Engine(opt, 0) as c:
+        for _ in range(2):
+            a.contig_begin(0, L1, f1)
+            b.contig_begin(1, L2, f2)
+            c.contig_begin(0, L1, f1); push(c, r1.slice(0, r1.n // 3))        # never finished
+            push(a, r1.slice(0, r1.n // 2))
+            push(b, r2)
+            got2 = b.contig_finish()
+            push(a, r1.slice(r1.n // 2, r1.n))
+            got1 = a.contig_finish()
+            assert got1.as_dict() == want1.as_dict() and np.array_equal(got1.intervals, want1.intervals)
+            assert got2.as_dict() == want2.as_dict() and np.array_equal(got2.intervals, want2.intervals)
+            a, b = b, a                                                       # the contigs swap engines
+
+
 @pytest.mark.parametrize("case", KATS["site_cases"], ids=[c["name"] for c in KATS["site_cases"]])
 def test_site_kats_on_gpu(case):
     rec = ContigRecords.from_reads([tuple(r) for r in case["reads"]])

@@ -527,8 +527,8 @@ Reads device_reads(const cl_ctx *c)
 }
 
 // The windows' candidate ranges: an index of the resident reads (binary searches over the sorted positions), built on
-// the host at upload -- where the positions still are -- instead of in every run.  Same rules as the device's
-// window_bounds() (kernels.hip.h), which the tests hold against this one through the results.
+// the host at upload -- where the positions still are -- instead of in every run (round 1 ran the same rules as a
+// device function in front of every pileup launch; the parity tests hold the results of this one against the oracle).
 void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &flags)
 {
     const uint32_t n = (uint32_t)c->h_pos.size(), n_wide = (uint32_t)c->h_wide_pos.size();

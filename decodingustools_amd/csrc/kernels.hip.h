@@ -256,7 +256,7 @@ struct PileupArgs {
 // blocks' checkpoints.
 //
 // DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window has <= 32767 candidates
-// (otherwise window_bounds raises kNeedDeep and the host re-runs the contig with DEEP = true: one
+// (otherwise host_window_bounds raises kNeedDeep and the contig runs with DEEP = true: one
 // 32-bit counter per position).
 // ---------------------------------------------------------------------------------------------
 template <bool ORF>
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
     // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
     // subtraction of 1 from the whole word) never borrows from the high half; exact while the window
-    // is touched by < 32768 reads (window_bounds raises kNeedDeep beyond that).
+    // is touched by < 32768 reads (host_window_bounds raises kNeedDeep beyond that).
     constexpr int kDiffWords = DEEP ? T : T / 2;
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_low[kDiffWords];
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     const uint32_t wlo = wm.wlo, wn = wm.wn;
     const uint32_t n_cand = wn + (hi - lo);
     // all quality bytes of the candidates lie within 2^32 of the first one's (checked by
-    // window_bounds), so they are addressed by 32-bit offsets from a uniform base.  The base
+    // host_window_bounds), so they are addressed by 32-bit offsets from a uniform base.  The base
     // sits kQualPad bytes low so that the offset of a unit start never goes negative.
     const unsigned long long qwin = wm.q0;
     const uint8_t *qbase = a.R.qual + qwin - kQualPad;

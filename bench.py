@@ -160,8 +160,8 @@ def kernel_profile(engines, steps):
 
 
 def traffic_from_profiles():
-    """The PMC-measured HBM traffic of one k_pileup launch is a builder-side figure (rocprofv3 --pmc needs its
-    own run): it is quoted from the committed profile, under its own key, never as a measurement of this run."""
+    """The committed profile's figure for the HBM traffic of one k_pileup launch, under its own key with the build it
+    was measured on -- beside `traffic`, which measure_traffic() fills from this run's own PMC passes."""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         d = json.load(open(tf))
@@ -169,6 +169,49 @@ def traffic_from_profiles():
                 "file": "profiles/traffic.json", "build": d.get("build"), "workload": d.get("workload", "chr21 30x")}
     except Exception:
         return None
+
+
+def measure_traffic(args):
+    """roofline.traffic of THIS run: the HBM bytes of one k_pileup launch from the PMC counters, collected the way
+    MI355X_MICROARCH.md's HBM section prescribes -- FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes, no
+    tracing domain beside them -- over two child runs of this script on the same workload (5 + 2 steps, no oracle, no
+    secondary lines), after the timed region.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KB
+    and gfx950's FETCH_SIZE counts 64 B per 128-byte request of a wide streaming read.  Returns (bytes, detail) or
+    (None, reason): a profiler that is missing or refuses never costs the bench line."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rp):
+        return None, "rocprofv3 not found"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["TMPDIR"] = "/tmp"
+    got = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+               "--steps", "5", "--warmup", "2", "--cpu-sample", "0", "--no-secondary", "--no-traffic", "--min-time", "0",
+               "--max-blocks", "1", "--length", str(args.length), "--depth", str(args.depth)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_pileup" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
+                        vals.append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"no {ctr} rows for k_pileup (rocprofv3 rc {r.returncode}: {(r.stderr or '')[-200:]})"
+            got[ctr] = (sum(vals) / len(vals), len(vals))
+        except Exception as e:
+            return None, f"{ctr} pass failed: {e}"
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nbytes = int((2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024)
+    return nbytes, {"FETCH_SIZE_KB": got["FETCH_SIZE"][0], "WRITE_SIZE_KB": got["WRITE_SIZE"][0],
+                    "launches_averaged": got["FETCH_SIZE"][1],
+                    "how": "two child runs of bench.py under rocprofv3 --pmc (FETCH_SIZE, then WRITE_SIZE), "
+                           "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"}
 
 
 def roofline(alg_bytes, pile_ms, step_ms, kms, n_gpus=1):
@@ -361,6 +404,18 @@ def run_chr21(args, rank, world, dev_id, torch, dist, coll_dev):
     del rec, ref
     if world == 1 and not args.no_secondary:
         out["configs"] = secondary_configs(dev_id, opt, args)
+    profiled = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES"))
+    if world == 1 and rank == 0 and not args.no_traffic and not profiled:
+        t0 = time.perf_counter()
+        nbytes, detail = measure_traffic(args)
+        if nbytes is not None:
+            out["roofline"]["traffic"] = nbytes
+            out["roofline"]["traffic_detail"] = detail
+            log(f"[bench] k_pileup HBM traffic by PMC: {nbytes / 1e6:.1f} MB per launch against "
+                f"{out['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic ({time.perf_counter() - t0:.0f}s)")
+        else:
+            out["roofline"]["traffic_error"] = detail
+            log(f"[bench] traffic not measured: {detail}")
     return out
 
 
@@ -457,6 +512,8 @@ def main():
     ap.add_argument("--long-length", type=int, default=57_227_415, help="secondary config 3: contig length (chrY)")
     ap.add_argument("--site-length", type=int, default=57_227_415, help="secondary config 5: contig length (chrY)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs[2] / configs[4] lines")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank logic on one GPU)")
     args = ap.parse_args()
 

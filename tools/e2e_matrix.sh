@@ -6,7 +6,7 @@ for S in 0 1; do
 for T in 12 16; do
   for C in 4 8; do
     echo "== DUT_PIN_SPIN=$S DUT_THREADS=$T DUT_COPY_THREADS=$C"
-    DUT_PIN_SPIN=$S DUT_THREADS=$T DUT_COPY_THREADS=$C python3 bench.py --no-secondary --cpu-sample 0 --min-time 0 --max-blocks 1 2>&1 >/dev/null | grep "end-to-end"
+    DUT_PIN_SPIN=$S DUT_THREADS=$T DUT_COPY_THREADS=$C python3 bench.py --no-secondary --no-traffic --cpu-sample 0 --min-time 0 --max-blocks 1 2>&1 >/dev/null | grep "end-to-end"
   done
 done
 done

@@ -33,7 +33,7 @@ if pile and "FETCH_SIZE" in pile[0] and "WRITE_SIZE" in pile[0]:
     except Exception:
         build = None
     json.dump({"k_pileup_hbm_bytes_per_launch": int((2 * f_kb + w_kb) * 1024), "build": build, "round": tag,
-               "workload": "chr21 30x (bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-secondary --min-time 0)",
+               "workload": "chr21 30x (bench.py --steps 5 --warmup 2 --cpu-sample 0 --no-secondary --no-traffic --min-time 0)",
                "how": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over bench.py; "
                       "bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950 FETCH_SIZE counts half of a wide streaming read)",
                "FETCH_SIZE_KB": f_kb, "WRITE_SIZE_KB": w_kb}, open(os.path.join(P, "traffic.json"), "w"), indent=1)

@@ -267,6 +267,36 @@ def test_long_read_chrY_full_size_properties_and_oracle_windows(tmp_path):
             assert np.array_equal(arr_o[a:b], arr_g[a:b]), (nm, a)
 
 
+def test_site_pileup_chrY_full_size_rows_and_oracle_windows():
+    """BASELINE.json configs[4] at full size (chrY-shaped 57.2 Mb, 40x, 14.8 M reads with bases, 200 000 sites, base
+    quality >= 20): a site's row does not depend on which other sites are asked for, every row is bounded by the
+    coverage, and the rows of the sites inside windows equal the oracle's over the reads that can reach them."""
+    L = 57_227_415
+    seed = synth.seed_for(5, 23)
+    ref = synth.make_reference(L, seed)
+    rec = synth.short_read_contig(L, 40, seed, with_seq=True, ref=ref, max_live_assert=0)
+    rng = np.random.default_rng(5)
+    sites = rng.choice(np.arange(1, L + 1), size=200_000, replace=False).astype(np.uint32)
+    with Engine(CallableOptions(), 0) as eng:
+        hist = eng.site_pileup(20, L, L, rec, sites)
+        ms, nbytes = eng.site_pileup_stats()
+        half = eng.site_pileup(20, L, L, rec, sites[::2])
+        srt = np.sort(sites)
+        hist_sorted = eng.site_pileup(20, L, L, rec, srt)
+    assert ms > 0 and nbytes > rec.n * 16
+    assert np.array_equal(half, hist[::2])                                   # rows are independent of the list
+    assert np.array_equal(hist_sorted, hist[np.argsort(sites, kind="stable")])   # ... and of its order
+    assert int((hist.sum(1) > 0).sum()) > 150_000 and int(hist.sum(1).max()) < 400
+    for a in [0, 1_234_567, 28_000_000, L - 300_000]:
+        b = min(a + 300_000, L)
+        i0 = int(np.searchsorted(rec.pos, a - 2_000)); i1 = int(np.searchsorted(rec.pos, b))
+        sub = rec.slice(i0, i1)
+        sel = np.flatnonzero((sites > a) & (sites <= b))                     # 1-based sites over positions [a, b)
+        assert sel.shape[0] > 500
+        exp = oracle.site_pileup(10, 20, L, ref, sub, sites[sel])
+        assert np.array_equal(exp["hist"], hist[sel]), a
+
+
 def test_bench_whole_genome_line_over_two_ranks(tmp_path):
     """The harness the driver runs for N > 1 (`bench.py --gpus N` under torch.distributed.run), rehearsed with two ranks
     on the box's one GPU (gloo for the collectives; nccl needs one device per rank) at 1/64 scale: one JSON line from

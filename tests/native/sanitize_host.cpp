@@ -97,6 +97,33 @@ int main(int argc, char **argv)
         printf("parallel_for: exception %s, helper ran %d, not every index ran %d\n", caught ? "caught" : "LOST", ran, done.load() < 20000 ? 1 : 0);
         if (!caught) return 3;
     }
+    // the persistent workers: loops started from several threads at once, and from inside a chunk of another loop,
+    // share them and each comes back complete (the caller always works on its own loop)
+    {
+        std::atomic<uint64_t> total{0};
+        auto burst = [&](uint64_t salt) {
+            for (int rep = 0; rep < 40; ++rep) {
+                std::atomic<uint64_t> sum{0};
+                const size_t n = 300 + 97 * (size_t)rep;
+                dut::parallel_for(n, 3, [&](size_t i) {
+                    if (i % 64 == 0) {                         // a loop inside a chunk
+                        std::atomic<uint64_t> inner{0};
+                        dut::parallel_for(50, 4, [&](size_t j) { inner.fetch_add(j + 1); });
+                        if (inner.load() != 50 * 51 / 2) abort();
+                    }
+                    sum.fetch_add(i + salt);
+                });
+                if (sum.load() != n * (n - 1) / 2 + salt * n) abort();
+                total.fetch_add(sum.load());
+            }
+        };
+        {
+            dut::Thread a = dut::spawn_or_run([&]() { burst(1); });
+            dut::Thread b = dut::spawn_or_run([&]() { burst(2); });
+            burst(3);
+        }
+        printf("worker pool: three callers, nested loops, total %llu\n", (unsigned long long)total.load());
+    }
     // summary JSON with awkward names
     dut_contig_stats st[2]; memset(st, 0, sizeof(st));
     st[0].length = 20; st[0].n_covered_bases = 12; st[0].summed_coverage = 22; st[0].summed_baseq = 420; st[0].summed_mapq = 960; st[0].quality_bases = 14; st[0].n_reads = 3;

@@ -495,8 +495,11 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                     ve = (sv.on && u + 4u * j <= sv.u1) ? ve : 0u;
                     const uint4 ms = s_mstart[vs], me = s_mend[ve];
                     const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                    // a slot past the segment's end adds zeros: to the word of its own unit number, not (with the lanes
+                    // beside it) to the word of the segment's last unit
+                    const uint32_t un = u + 4u * j, ua = un < (uint32_t)(T / 16) ? un : (uint32_t)(T / 16) - 1u;
                     if (MODE == 2) sq32 += apply_unit32<ORF>(v[j], vm, uu[j], s_qcw, a.o);
-                    else if (MODE == 0) sq32 += apply_unit8<ORF>(v[j], vm, uu[j], sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                    else if (MODE == 0) sq32 += apply_unit8<ORF>(v[j], vm, ua, sv.set * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
                     else sq32 += apply_unit16<ORF>(v[j], vm, uu[j], reinterpret_cast<unsigned long long *>(s_qcw), a.o);
                 }
             }

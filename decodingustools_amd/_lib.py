@@ -103,6 +103,7 @@ SYMBOLS = [
     ("cl_push_reads", C.c_int, [C.c_void_p, C.POINTER(cl_read_tile)]),
     ("cl_contig_finish", C.c_int, [C.c_void_p, C.POINTER(cl_contig_summary),
                                    C.POINTER(C.POINTER(cl_interval)), C.POINTER(C.c_size_t)]),
+    ("cl_contig_abort", C.c_int, [C.c_void_p]),
     ("cl_contig_upload", C.c_int, [C.c_void_p]),
     ("cl_contig_run", C.c_int, [C.c_void_p]),
     ("cl_contig_collect", C.c_int, [C.c_void_p, C.POINTER(cl_contig_summary),

@@ -32,6 +32,27 @@ def _stale():
     return any(os.path.getmtime(p) > t for p in SOURCES + HEADERS)
 
 
+TUNING_LIB = os.path.join(LIBDIR, "libcallable_hip_tuning.so")
+
+
+def build_tuning(verbose=False):
+    """The same library with -DCL_TUNING: the timing-experiment hooks of tools/ (CL_ABLATE skips kernel phases,
+    CL_FORCE_LONG picks the form of k_pileup by hand).  Never loaded by the product: tools select it through
+    DUT_CALLABLE_LIB."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    os.makedirs(LIBDIR, exist_ok=True)
+    tmp = f".tmp{os.getpid()}"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DCL_TUNING",
+           "-Wall", "-Wno-unused-function"] + SOURCES + ["-lz", "-ldl", "-o", TUNING_LIB + tmp]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stdout + r.stderr)
+    os.replace(TUNING_LIB + tmp, TUNING_LIB)
+    return TUNING_LIB
+
+
 def build(force=False, verbose=False):
     """Compile for gfx950 (cross-compiles without a GPU). Returns the library path."""
     if not force and not _stale():
@@ -60,3 +81,5 @@ def build(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--tuning" in sys.argv:
+        print(build_tuning(verbose=True))

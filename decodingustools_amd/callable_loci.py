@@ -128,6 +128,9 @@ class Engine:
         t.pos, t.mapq, t.cigar_off, t.cigar, t.qual_off, t.qual = [_ptr(a) for a in arrs]
         self._check(self._lib.cl_push_reads(self._h, C.byref(t)))
 
+    def contig_abort(self):
+        self._check(self._lib.cl_contig_abort(self._h))
+
     def contig_upload(self):
         self._check(self._lib.cl_contig_upload(self._h))
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -72,6 +73,7 @@ template <typename T> struct RawVec {
     RawVec() = default;
     RawVec(const RawVec &) = delete;
     RawVec &operator=(const RawVec &) = delete;
+    RawVec(RawVec &&o) noexcept : p(o.p), n(o.n), cap(o.cap) { o.p = nullptr; o.n = o.cap = 0; }
     ~RawVec() { free(p); }
     size_t size() const { return n; }
     bool empty() const { return n == 0; }
@@ -175,24 +177,51 @@ struct PinRing {
     hipStream_t copy_stream[kCopyThreads] = {};
     uint8_t *pin[kCopyThreads][2] = {};
     hipEvent_t pin_ev[kCopyThreads][2] = {};
-    std::mutex busy;
-    bool ok = false;
-    explicit PinRing(int dev) : device(dev)
+    // who is using the ring: a transfer holds it from ring_start to ring_finish -- across C-ABI calls for a quality
+    // prefetch, and possibly released on another thread than the one that took it, so an ownership flag under a
+    // condition variable rather than a mutex (unlocking a std::mutex from another thread is undefined)
+    std::mutex own_mu;
+    std::condition_variable own_cv;
+    const void *owner = nullptr;
+    void acquire(const void *who)
     {
-        if (hipSetDevice(dev) != hipSuccess) return;
-        for (int t = 0; t < threads(); ++t) {
-            if (hipStreamCreateWithFlags(&copy_stream[t], hipStreamNonBlocking) != hipSuccess) return;
+        std::unique_lock<std::mutex> lk(own_mu);
+        // a context of this device with an unclaimed prefetch pins the ring until its next push / upload / begin /
+        // abort / destroy; a thread that drives two contexts must not interleave them there
+        int waited = 0;
+        while (owner && !own_cv.wait_for(lk, std::chrono::seconds(10), [this] { return owner == nullptr; }))
+            if (++waited == 1)
+                fprintf(stderr, "[callable_loci] waiting for the device's pinned staging ring: another context holds it "
+                                "(an unclaimed cl_contig_prefetch_qual keeps it until that context's next push, upload, begin, abort or destroy)\n");
+        owner = who;
+    }
+    void release(const void *who)
+    {
+        { std::lock_guard<std::mutex> g(own_mu); if (owner == who) owner = nullptr; }
+        own_cv.notify_one();
+    }
+    bool ok = false;
+    int slots = 0;                                          // thread slots that have their stream, buffers and events
+    // slots [slots, n) are made (by the ring's owner, or at construction); false when the runtime refuses
+    bool ensure_slots(int n)
+    {
+        if (n > kCopyThreads) n = kCopyThreads;
+        if (hipSetDevice(device) != hipSuccess) return false;
+        for (int t = slots; t < n; ++t) {
+            if (hipStreamCreateWithFlags(&copy_stream[t], hipStreamNonBlocking) != hipSuccess) return false;
             for (int b = 0; b < 2; ++b) {
-                if (hipHostMalloc(reinterpret_cast<void **>(&pin[t][b]), kPinBytes, hipHostMallocDefault) != hipSuccess) return;
+                if (hipHostMalloc(reinterpret_cast<void **>(&pin[t][b]), kPinBytes, hipHostMallocDefault) != hipSuccess) return false;
                 // blocking waits: a copier that spins on its buffer's event burns a core the host stages beside it
                 // need (DUT_PIN_SPIN=1: the runtime's default busy wait, for comparison)
                 const char *spin = getenv("DUT_PIN_SPIN");
                 const unsigned flags = hipEventDisableTiming | ((spin && *spin == '1') ? 0u : (unsigned)hipEventBlockingSync);
-                if (hipEventCreateWithFlags(&pin_ev[t][b], flags) != hipSuccess) return;
+                if (hipEventCreateWithFlags(&pin_ev[t][b], flags) != hipSuccess) return false;
             }
+            slots = t + 1;
         }
-        ok = true;
+        return true;
     }
+    explicit PinRing(int dev) : device(dev) { ok = ensure_slots(threads()); }
     ~PinRing()
     {
         (void)hipSetDevice(device);
@@ -257,6 +286,8 @@ struct cl_ctx {
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
     bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
+    int form = 0;                    // the form of k_pileup the resident contig gets (pick_form, at upload)
+    uint32_t tune_ablate = 0;        // CL_TUNING builds: CL_ABLATE, read once at cl_create
     bool has_long = false;           // some read has more than kLongOps CIGAR ops (its checkpoints are in h_ck_x / h_ck_y)
     int32_t tid = 0;
     uint32_t contig_len = 0;
@@ -302,6 +333,8 @@ struct cl_ctx {
     DevBuf<FinPartial> d_fin;
     DevBuf<uint32_t> d_errflag;        // [0] error bits raised by the kernels of a run, [1] unused
     DevBuf<uint32_t> d_ck_x, d_ck_y;
+    DevBuf<uint2> d_runtab;            // run-table form: the windows' match pieces (host_build_runs)
+    uint64_t n_runtab = 0;
     DevBuf<uint32_t> d_lut;
     DevBuf<DevSummary> d_summary;
     DevBuf<Interval> d_iv;
@@ -419,7 +452,7 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
     PinRing *R = c->ring.get();
-    R->busy.lock();                                       // another context of this device may be using the ring
+    R->acquire(c);                                        // another context of this device may be using the ring
     c->ring_held = true;
     const uint64_t CH = PinRing::kPinBytes, nch = (n + CH - 1) / CH;
     const int T = PinRing::threads();
@@ -450,7 +483,7 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
 cl_status ring_finish(cl_ctx *c)
 {
     c->copiers.clear();                                   // dut::Thread joins in its destructor
-    if (c->ring_held) { c->ring_held = false; c->ring->busy.unlock(); }
+    if (c->ring_held) { c->ring_held = false; c->ring->release(c); }
     for (int t = 0; t < PinRing::kCopyThreads; ++t) HIP_TRY(c, c->copy_err[t]);
     return CL_OK;
 }
@@ -501,21 +534,22 @@ cl_status harvest_events(cl_ctx *c)
     return CL_OK;
 }
 
-// which form of k_pileup a resident contig gets: by its shape (CL_FORCE_LONG: timing experiments)
-struct Variant { bool lng, lng4; };
-Variant pick_variant(const cl_ctx *c)
+// which form of k_pileup a resident contig gets: by its shape, decided once at upload and kept in the context
+// (kernels.hip.h: LONG = 0 short reads, 1 long match runs, 2 the run table; 4 = the block-parallel CIGAR scan that
+// the run table replaced, reachable in tuning builds only)
+int pick_form(const cl_ctx *c)
 {
-    Variant v;
-    // long-read shape (8 or more CIGAR operations per read on average): the operation-parallel forms ...
-    v.lng = c->n_reads && c->n_cigar >= 8ull * c->n_reads;
-    // ... with short runs (operations average < 56 bases -- the measured crossover of the two
-    // variants lies between 50 and 70): four operations per lane, block-parallel
-    v.lng4 = v.lng && c->n_qual < 56ull * c->n_cigar;
-    if (const char *fl = getenv("CL_FORCE_LONG")) {
-        const int f = atoi(fl);
-        v.lng = f != 0; v.lng4 = f == 4;
+    int form = 0;
+    // long-read shape (8 or more CIGAR operations per read on average): no lane-serial CIGAR walk ...
+    if (c->n_reads && c->n_cigar >= 8ull * c->n_reads) {
+        // ... with short runs (operations average < 56 bases -- the measured crossover lies between 50 and 70): the
+        // host's walk leaves a table of match pieces per window; else a wave takes 64 operations of a read at a time
+        form = c->n_qual < 56ull * c->n_cigar ? 2 : 1;
     }
-    return v;
+#ifdef CL_TUNING
+    if (const char *fl = getenv("CL_FORCE_LONG")) form = atoi(fl);
+#endif
+    return form;
 }
 
 Reads device_reads(const cl_ctx *c)
@@ -549,7 +583,7 @@ void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &fl
             m.wn = lb(wpos, n_wide, W - (long long)c->span_n + 1) - m.wlo;
         }
         const uint32_t first = m.wn ? c->h_wide_idx[m.wlo] : m.lo;      // lo <= n: the offsets array has n + 1 entries
-        m.q0 = c->h_qual_off[first]; m.pad[0] = 0; m.pad[1] = 0;
+        m.q0 = c->h_qual_off[first]; m.rlo = 0; m.rn = 0;
         // k_pileup addresses the quality bytes of a window with 32-bit offsets
         if (m.hi > first && c->h_qual_off[m.hi] - c->h_qual_off[first] > 0xFFFF0000ull) fl.fetch_or(kErrRange);
         // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
@@ -557,6 +591,211 @@ void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &fl
         win[w] = m;
     });
     flags = fl.load();
+}
+
+
+// The run table of the run-table form (kernels.hip.h, LONG = 2): per window of kT positions the M/=/X pieces of the reads
+// that cover it -- what the reference's column walk visits as (alignment, qpos) with !is_del (mod.rs:30-37), grouped by
+// window instead of by column.  One more walk over the staged CIGARs, at upload: a thread takes a range of windows
+// and sweeps it with a list of read cursors (operation index, reference and query position), so every operation is
+// visited once per range it touches; reads that start before the range enter at their last checkpoint in front of it
+// (the 64-operation checkpoints of cl_push_reads' walk).  Reads below min_mapping_quality never enter (mod.rs:25).
+// A piece = {x, y}: x + 16 u = the byte offset of unit u's qualities from the window's quality base;
+// y = start | end - 1 << 11 | (read & 1) << 29 | valid << 31; it covers the unit of its start and at most the next one.
+// The pieces are written straight into the pinned buffers of the staging ring and leave for HBM as a buffer fills: the
+// table exists nowhere in host memory.  Buffers are placed in the device array in the order they fill (a window only
+// needs its own pieces contiguous: its record holds their absolute index).
+struct RunCur { uint32_t k, k1, x, y, qlen, flags; unsigned long long q0; };
+
+// One window: the cursors of `act` emit their pieces inside [W, W + kT) to out[0, cap) and move on; finished reads
+// leave the list.  Returns the number of pieces, or SIZE_MAX when `cap` did not suffice (the list is then spoilt: the
+// caller restores its copy).
+size_t sweep_window(std::vector<RunCur> &act, const uint32_t *cig, uint32_t W, unsigned long long qwin, uint2 *out, size_t cap)
+{
+    const uint32_t Wend = W + kT;
+    size_t n = 0, keep = 0;
+    const size_t na = act.size();
+    for (size_t i = 0; i < na; ++i) {
+        RunCur cu = act[i];
+        // every piece of an operation that starts at (x, y) has the same first word: q + kQualPad - sr with q = qrel + y +
+        // (sp - x) and sr = sp - W
+        const uint32_t qb = (uint32_t)(cu.q0 - qwin) + (uint32_t)kQualPad + W;
+        while (cu.k < cu.k1 && cu.x < Wend) {
+            const uint32_t cw = cig[cu.k], op = cw & 15u, l = cw >> 4;
+            const uint32_t radv = (0x18Du >> op) & 1u, qadv = (0x193u >> op) & 1u, ism = (0x181u >> op) & 1u;
+            const uint32_t xe = cu.x + (radv ? l : 0u);
+            if (ism) {
+                if (n + (kT / 32u + 2u) > cap) return SIZE_MAX;                 // what one clipped run can emit at most
+                const uint32_t sp = cu.x > W ? cu.x : W;
+                const uint32_t lq = cu.y < cu.qlen ? std::min(cu.qlen - cu.y, l) : 0u;   // bases that have a quality byte
+                uint32_t tp = xe < Wend ? xe : Wend;
+                tp = (cu.x + lq) < tp ? (cu.x + lq) : tp;
+                if (sp < tp) {
+                    uint32_t sr = sp - W;
+                    const uint32_t tr = tp - W, ex = qb + cu.y - cu.x;
+                    do {
+                        const uint32_t pe = std::min(tr, ((sr >> 4) + 2u) << 4);
+                        out[n++] = make_uint2(ex, sr | ((pe - 1u) << 11) | cu.flags);
+                        sr = pe;
+                    } while (sr < tr);
+                }
+            }
+            if (xe > Wend) break;                                // the operation goes on in the next window
+            if (xe < cu.x) { cu.k = cu.k1; break; }              // wraps the 32-bit coordinate: flagged kErrRange by cl_push_reads
+            cu.x = xe; cu.y += qadv ? l : 0u; cu.k += 1u;
+        }
+        if (cu.k < cu.k1) act[keep++] = cu;
+    }
+    act.resize(keep);
+    return n;
+}
+
+// pieces per pinned buffer (DUT_RUN_CHUNK: a test hook that makes the buffer-full and oversized-window paths reachable
+// with small inputs; read once)
+size_t run_chunk_entries()
+{
+    static const size_t n = [] {
+        const char *e = getenv("DUT_RUN_CHUNK");
+        const size_t full = PinRing::kPinBytes / sizeof(uint2);
+        const size_t v = e ? (size_t)strtoull(e, nullptr, 0) : full;
+        return v < kT / 32u + 2u ? kT / 32u + 2u : (v > full ? full : v);
+    }();
+    return n;
+}
+
+cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
+{
+    const uint32_t n_win = c->n_win;
+    const int32_t *pos = c->h_pos.data();
+    const uint8_t *mapq = c->h_mapq.data();
+    const uint32_t *end = c->h_end.data(), *coff = c->h_cigar_off.data(), *cig = c->h_cigar.data();
+    const uint32_t *ckx = c->h_ck_x.data(), *cky = c->h_ck_y.data(), *wide_idx = c->h_wide_idx.data();
+    const unsigned long long *qoff = c->h_qual_off.data();
+    const uint32_t min_mapq = c->opt.min_mapping_quality;
+    c->n_runtab = 0;
+    if (n_win == 0) return CL_OK;
+    cl_status s = ensure_pins(c);
+    if (s != CL_OK) return s;
+    const int nt = std::max(1, std::min<int>(PinRing::kCopyThreads, dut::worker_threads()));
+    // tasks: several per thread so that uneven depth evens out, not so short that the range-start walks show
+    const size_t per = std::max<size_t>(16, (size_t)n_win / (8 * (size_t)nt) + 1);
+    const size_t ntasks = ((size_t)n_win + per - 1) / per;
+    const size_t capE = run_chunk_entries();
+    // the device array: an estimate first (a piece per ~12 aligned bases); a contig that needs more tells how much
+    uint64_t want = c->n_qual / 12 + (uint64_t)n_win * 8 + 65536;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, c->d_runtab.reserve(want));
+        uint2 *const d_tab = c->d_runtab.p;
+        const uint64_t dev_cap = c->d_runtab.cap;
+        std::atomic<uint64_t> dev_next{0};
+        std::atomic<size_t> next_task{0};
+        PinRing *R = c->ring.get();
+        R->acquire(c);
+        c->ring_held = true;
+        if (!R->ensure_slots(nt)) { (void)ring_finish(c); return fail(c, CL_ERR_DEVICE, "cannot extend the pinned staging ring (hipHostMalloc)"); }
+        for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
+        for (int t = 0; t < nt; ++t) {
+            c->copiers.push_back(dut::spawn_or_run([&, t]() {
+                hipError_t err = hipSetDevice(c->device);
+                int kb = 0;                                                  // buffers this thread has sent
+                auto cur_buf = [&]() { return reinterpret_cast<uint2 *>(R->pin[t][kb & 1]); };
+                auto send = [&](uint2 *dst, size_t cnt) {                    // the current buffer leaves; on to the other one
+                    if (err != hipSuccess) return;
+                    err = hipMemcpyAsync(dst, cur_buf(), cnt * sizeof(uint2), hipMemcpyHostToDevice, R->copy_stream[t]);
+                    if (err == hipSuccess) err = hipEventRecord(R->pin_ev[t][kb & 1], R->copy_stream[t]);
+                    ++kb;
+                    if (kb >= 2 && err == hipSuccess) err = hipEventSynchronize(R->pin_ev[t][kb & 1]);   // its previous transfer is done
+                };
+                std::vector<RunCur> act, save;
+                std::vector<uint32_t> in_buf;                                // windows whose pieces lie in the current buffer
+                RawVec<uint2> big;
+                size_t used = 0;
+                auto flush = [&]() {
+                    if (!used) return;
+                    const uint64_t off = dev_next.fetch_add(used);
+                    if (off + used <= dev_cap) send(d_tab + off, used);      // else: the array is too small, only the total counts now
+                    for (uint32_t w : in_buf) win[w].rlo += (uint32_t)off;
+                    in_buf.clear(); used = 0;
+                };
+                auto enter = [&](uint32_t r, uint32_t W) {                   // a read that covers positions at or after W
+                    if (mapq[r] < min_mapq) return;
+                    RunCur cu;
+                    cu.k = coff[r]; cu.k1 = coff[r + 1]; cu.x = (uint32_t)pos[r]; cu.y = 0;
+                    if (cu.k >= cu.k1 || end[r] <= W) return;
+                    const unsigned long long ql = qoff[r + 1] - qoff[r];
+                    cu.qlen = ql > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ql;
+                    cu.q0 = qoff[r]; cu.flags = ((r & 1u) << 29) | 0x80000000u;
+                    if (cu.k1 - cu.k > kLongOps && cu.x < W) {               // the last checkpoint at or before W
+                        const uint32_t jlo = (cu.k + 63u) >> 6, jhi = (cu.k1 - 1u) >> 6;
+                        if (jlo <= jhi && ckx[jlo] <= W) {
+                            uint32_t lo_j = jlo, hi_j = jhi;
+                            while (lo_j < hi_j) {
+                                const uint32_t mid = lo_j + ((hi_j - lo_j + 1u) >> 1);
+                                if (ckx[mid] <= W) lo_j = mid; else hi_j = mid - 1u;
+                            }
+                            cu.k = lo_j << 6; cu.x = ckx[lo_j]; cu.y = cky[lo_j];
+                        }
+                    }
+                    act.push_back(cu);
+                };
+                try {
+                    size_t task;
+                    while ((task = next_task.fetch_add(1)) < ntasks) {
+                        const size_t w0 = task * per, w1 = std::min<size_t>(n_win, w0 + per);
+                        act.clear();
+                        for (size_t w = w0; w < w1; ++w) {
+                            const uint32_t W = (uint32_t)(w * kT);
+                            WinMeta &m = win[w];
+                            if (w == w0) {
+                                // what covers the range's first window: the wide reads in front of read lo, then [lo, hi)
+                                for (uint32_t i = 0; i < m.wn; ++i) enter(wide_idx[m.wlo + i], W);
+                                for (uint32_t r = m.lo; r < m.hi; ++r) enter(r, W);
+                            } else {
+                                for (uint32_t r = win[w - 1].hi; r < m.hi; ++r) enter(r, W);   // the reads that start in this window
+                            }
+                            save = act;
+                            size_t cnt = sweep_window(act, cig, W, m.q0, cur_buf() + used, capE - used);
+                            if (cnt == SIZE_MAX) {                           // the buffer is full: it leaves, the window starts over
+                                flush();
+                                act = save;
+                                cnt = sweep_window(act, cig, W, m.q0, cur_buf(), capE);
+                            }
+                            if (cnt == SIZE_MAX) {
+                                // a window that no buffer holds (thousandfold depth): through a block of its own
+                                size_t bc = capE * 4;
+                                for (;;) {
+                                    big.clear(); big.resize(bc);
+                                    act = save;
+                                    cnt = sweep_window(act, cig, W, m.q0, big.data(), bc);
+                                    if (cnt != SIZE_MAX) break;
+                                    bc *= 4;
+                                }
+                                const uint64_t off = dev_next.fetch_add(cnt);
+                                if (off + cnt <= dev_cap && err == hipSuccess)
+                                    err = hipMemcpy(d_tab + off, big.data(), cnt * sizeof(uint2), hipMemcpyHostToDevice);
+                                m.rlo = (uint32_t)off; m.rn = (uint32_t)std::min<size_t>(cnt, 0xFFFFFFFFu);
+                                continue;
+                            }
+                            m.rlo = (uint32_t)used; m.rn = (uint32_t)cnt;
+                            if (cnt) in_buf.push_back((uint32_t)w);
+                            used += cnt;
+                        }
+                    }
+                    flush();
+                } catch (...) { if (err == hipSuccess) err = hipErrorOutOfMemory; }
+                for (int b = 0; b < 2 && b < kb; ++b) { const hipError_t e = hipEventSynchronize(R->pin_ev[t][b]); if (err == hipSuccess) err = e; }
+                c->copy_err[t] = err;
+            }));
+        }
+        s = ring_finish(c);
+        if (s != CL_OK) return s;
+        const uint64_t total = dev_next.load();
+        if (total >= 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 match pieces in one contig");
+        if (total <= dev_cap) { c->n_runtab = total; return CL_OK; }
+        want = total;                                            // exact now: once more
+    }
+    return fail(c, CL_ERR_DEVICE, "run table: the second sizing pass did not fit");
 }
 
 // allocate and lay out everything that depends on the extent (called by cl_contig_upload, the staged arrays still there)
@@ -590,6 +829,14 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
         host_window_bounds(c, win, flags);
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
+        c->n_runtab = 0;
+        if (c->form == 2 && !(flags & kErrRange)) {
+            // the windows' match pieces: one more walk over the staged CIGARs, streamed to HBM through the ring
+            StageTimer tr;
+            rs = stream_run_table(c, win);
+            if (rs != CL_OK) return rs;
+            tr.lap("upload: run table (walk + H2D)");
+        }
         if (c->n_win) HIP_TRY(c, hipMemcpyAsync(c->d_win.p, win.data(), (size_t)c->n_win * sizeof(WinMeta), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // a window with more candidates than the 16-bit counters / differences hold: the 32-bit form from the start
@@ -615,10 +862,12 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     if (grid == 0) return;
     // (the ORF template parameter once selected a shorter threshold test for min_base_quality <= 128; one form
     // serves every threshold now and only ORF = true is instantiated)
-    const Variant vr = pick_variant(c);
-    const bool lng = vr.lng, lng4 = vr.lng4;
 #define CL_LAUNCH(DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
-#define CL_LAUNCH_L(DEEP_) do { if (lng4) CL_LAUNCH(DEEP_, 4); else if (lng) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
+#ifdef CL_TUNING
+#define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else if (c->form == 4) CL_LAUNCH(DEEP_, 4); else if (c->form == 1) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
+#else
+#define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else if (c->form == 1) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
+#endif
     // the 32-bit counter variant is used only when the window bounds asked for it (kNeedDeep)
     if (!c->deep) CL_LAUNCH_L(false); else CL_LAUNCH_L(true);
 #undef CL_LAUNCH_L
@@ -651,10 +900,8 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     a.dbg_raw = dbg_raw; a.dbg_qc = dbg_qc; a.dbg_low = dbg_low;
     a.win_wide = c->d_win_wide.p; a.err_flag = c->d_errflag.p;
     a.upl = (c->n_reads && c->n_qual <= 128ull * c->n_reads) ? 2u : 3u;   // by the mean read length
-    {   // timing experiments: CL_ABLATE=<bits> skips phases of k_pileup (results are then wrong)
-        const char *ab = getenv("CL_ABLATE");
-        a.ablate = ab ? (uint32_t)strtoul(ab, nullptr, 0) : 0u;
-    }
+    a.ablate = c->tune_ablate;        // 0 outside tuning builds
+    a.runtab = c->d_runtab.p;
     if (debug) launch_pileup<true>(c, a); else launch_pileup<false>(c, a);
     if (prof) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
@@ -711,6 +958,12 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     make_ge_consts((uint8_t)(opt->min_depth > 255 ? 255 : opt->min_depth), o.md_add, o.md_or, o.md_and);
     o.xd_on = (opt->max_depth >= 1 && opt->max_depth <= 254) ? 1u : 0u;
     make_ge_consts((uint8_t)(o.xd_on ? opt->max_depth + 1 : 255), o.xd_add, o.xd_or, o.xd_and);
+#ifdef CL_TUNING
+    if (const char *ab = getenv("CL_ABLATE")) {   // timing experiments: skips phases of k_pileup (results are then wrong)
+        c->tune_ablate = (uint32_t)strtoul(ab, nullptr, 0);
+        if (c->tune_ablate) fprintf(stderr, "[callable_loci] CL_ABLATE=%u: kernel phases are skipped, RESULTS ARE WRONG (tuning build)\n", c->tune_ablate);
+    }
+#endif
     std::vector<uint32_t> lut;
     build_lut(opt->max_low_mapq_fraction, lut);
     bool ok = c->d_lut.reserve(kLutSize) == hipSuccess &&
@@ -725,6 +978,7 @@ void cl_destroy(cl_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    drop_prefetch(c);                                     // its copiers write into d_qual: joined before anything is released
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
     c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
@@ -732,12 +986,11 @@ void cl_destroy(cl_ctx *c)
     c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_ck_x.release(); c->d_ck_y.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_ck_x.release(); c->d_ck_y.release(); c->d_runtab.release();
     for (int i = 0; i < 2; ++i) if (c->site_ev[i]) (void)hipEventDestroy(c->site_ev[i]);
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
-    drop_prefetch(c);
     c->ring.reset();
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1033,16 +1286,21 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     c->n_qual = c->q_dev;
     c->n_wide = (uint32_t)c->h_wide_idx.size();
     const size_t n = c->n_reads;
-    const Variant vr = pick_variant(c);
+    c->form = pick_form(c);
+    const int form = c->form;
     StageTimer tmr0;
     // What the device needs of the per-read fields depends on the form of k_pileup the contig gets: the short-read form
     // reads one packed record per read (and the ends of its reads with more than kLongOps operations); the long-read
     // forms read the arrays as pushed, and every read's end.
-    const bool need_soa = vr.lng;
+    // The run-table form reads neither CIGARs nor offsets: pos, mapq and end of the windows' candidates, and the table
+    // that the walk in size_for_extent() builds from the staged CIGARs.
+    const bool need_soa = form == 1 || form == 4, need_cigar = form != 2;
     HIP_TRY(c, c->d_end.reserve(n + 1));
-    HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));          // four words are loaded at a read's first op
-    HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
-    HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
+    if (need_cigar) {
+        HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));      // four words are loaded at a read's first op
+        HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
+        HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
+    }
     HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
@@ -1052,24 +1310,26 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // everything goes through the pinned staging ring (pageable vectors -> pinned buffers -> HBM, the fills overlapping
     // the transfers)
     cl_status rs = CL_OK;
-    if (need_soa) {
+    if (form != 0) {
         HIP_TRY(c, c->d_pos.reserve(n + 1));
         HIP_TRY(c, c->d_mapq.reserve(n + 1));
-        HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
-        HIP_TRY(c, c->d_qual_off.reserve(n + 1));
         if ((rs = ring_copy(c, c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_mapq.p, c->h_mapq.data(), n)) != CL_OK) return rs;
+    }
+    if (need_soa) {
+        HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
+        HIP_TRY(c, c->d_qual_off.reserve(n + 1));
         if ((rs = ring_copy(c, c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long))) != CL_OK) return rs;
     }
-    if (vr.lng || c->n_long)
+    if (form != 0 || c->n_long)
         if ((rs = ring_copy(c, c->d_end.p, c->h_end.data(), n * sizeof(uint32_t))) != CL_OK) return rs;
-    if (c->n_long) {                                         // entries of operations inside other reads are never read
+    if (c->n_long && need_cigar) {                           // entries of operations inside other reads are never read
         const size_t nck = (c->n_cigar >> 6) + 1;
         if ((rs = ring_copy(c, c->d_ck_x.p, c->h_ck_x.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_ck_y.p, c->h_ck_y.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
     }
-    if (!vr.lng) {
+    if (form == 0) {
         // the packed records of the short-read form: pos, CIGAR offset, low half of the quality offset, mapq and the two
         // lengths when they fit their fields (else the marker: the kernel takes them from the next record); rec[n] is the
         // sentinel with the totals.  Built straight into the pinned buffers.
@@ -1095,7 +1355,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if (rs != CL_OK) return rs;
     }
     tmr.lap("upload: records");
-    if ((rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
+    if (need_cigar && (rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
     tmr.lap("upload: cigar");
     if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
@@ -1241,6 +1501,19 @@ cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *out, const cl_interval 
     return s;
 }
 
+cl_status cl_contig_abort(cl_ctx *c)
+{
+    if (!c) return CL_ERR_INVALID;
+    (void)hipSetDevice(c->device);
+    drop_prefetch(c);                                     // joins the copiers: nothing reads the caller's buffer any more
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
+    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qual.clear();
+    c->q_dev = 0;
+    c->in_contig = false; c->uploaded = false; c->ran = false;
+    return CL_OK;
+}
+
 cl_status cl_device_summary(cl_ctx *c, void **dev_ptr, size_t *bytes)
 {
     if (!c || !dev_ptr || !bytes) return CL_ERR_INVALID;
@@ -1285,7 +1558,7 @@ cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_byt
     // per read: one packed 16-byte record in the short-read form; pos 4 + mapq 1 + CIGAR offset 4 + quality offset 8 in
     // the long-read forms
     const uint64_t n = c->n_reads;
-    const uint64_t per_read = pick_variant(c).lng ? (4 + 1 + 4 + 8) : sizeof(ReadRec);
+    const uint64_t per_read = c->form ? (4 + 1 + 4 + 8) : sizeof(ReadRec);
     if (input_bytes)
         *input_bytes = c->n_qual + n * per_read + c->n_cigar * 4 + (uint64_t)c->extent;
     if (output_bytes) *output_bytes = 12ull * c->h_sum.n_intervals;

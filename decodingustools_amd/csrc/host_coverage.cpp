@@ -643,6 +643,10 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     double tm = dut_now();
     int rc = cl_contig_begin(ctx, tid, contig_len, ref, ref_len);
     if (rc != CL_OK) return rc;
+    // Every early return below abandons the contig: a quality prefetch in flight still reads `rec->qual` and holds the
+    // device's staging ring, and the caller frees the records (and may destroy the context) right after an error.
+    // Declared before the helper threads so that it runs after they are joined.
+    struct AbortGuard { cl_ctx *c; bool armed = true; ~AbortGuard() { if (armed) (void)cl_contig_abort(c); } } abandon{ctx};
     // Reads at or past contig_len (never yielded by the region fetch) are the sorted tail and are cut off.  The quality
     // bytes of the rest start towards the device now, beside the admission below (the tile is pushed as the records lie;
     // should it turn out that it cannot be -- unsorted input, leading reads to drop -- the engine discards the prefetch).
@@ -760,6 +764,7 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     stats->quality_bases = sum.quality_bases;
     stats->n_reads = n_names;
     stats->reserved = 0;
+    abandon.armed = false;
     return CL_OK;
 }
 

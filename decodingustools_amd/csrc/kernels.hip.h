@@ -181,7 +181,7 @@ struct __attribute__((aligned(32))) WinMeta {
     uint32_t lo, hi;                   // ordinary candidates: reads [lo, hi)
     uint32_t wlo, wn;                  // wide candidates: wide_idx[wlo .. wlo+wn)
     unsigned long long q0;             // qual_off of the window's first candidate read
-    uint32_t pad[2];
+    uint32_t rlo, rn;                  // run-table form: the window's entries are runtab[rlo .. rlo + rn)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -210,6 +210,7 @@ struct PileupArgs {
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (host)
+    const uint2    *runtab;       // run-table form (LONG = 2): per window, the M/=/X pieces of its reads (host, at upload)
     uint8_t        *state;        // n_win*T bytes; written by the DEBUG instantiation only (test dumps)
     uint16_t       *runs;         // per window T entries: the run starts strictly inside the window, rel. position | state << 12
     uint8_t        *first_state, *last_state;   // per window: state of its first / last position (run seams)
@@ -219,7 +220,7 @@ struct PileupArgs {
     uint32_t        n_win8;       // ceil(n_win/8): XCD-contiguous window ranges
     // debug dumps (nullptr in production)
     uint32_t *dbg_raw, *dbg_qc, *dbg_low;
-    uint32_t ablate;              // timing experiments only (env CL_ABLATE); 0 in production
+    uint32_t ablate;              // timing experiments only (CL_TUNING builds: env CL_ABLATE); ignored otherwise
     uint32_t upl;                 // quality units per lane and trip in the consume loop: 2 for reads of up to ~128 bases, else 3
     uint8_t  *win_wide;           // per window: 1 = a position deeper than 255 was seen here, use 16-bit fields (sticky
                                   // for the resident contig; set by k_pileup itself, see mode8 below)
@@ -254,6 +255,13 @@ struct PileupArgs {
 // average < 56 bases): the (read, 64-operation block) pairs that can touch the window form one flat list,
 // a wave trip takes four of them, one per row of 16 lanes, four operations per lane, starting from the
 // blocks' checkpoints.
+//
+// LONG = 2 (the run-table form; what a contig with short match runs gets): no CIGAR is decoded on the device at
+// all.  The host's walk over the CIGARs at upload leaves, per window, a flat table of the M/=/X pieces of its reads --
+// 8 bytes each: {quality offset, window-relative start | end - 1 | counter set}, a piece never longer than two
+// 16-position units, reads below min_mapq already dropped -- and the kernel streams its window's entries coalesced,
+// one entry per lane, two entries and four quality loads in flight per lane.  The +-1 span scatter and the owner sums
+// take pos / end / mapq of the window's candidates as in the other long-read forms.
 //
 // DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window has <= 32767 candidates
 // (otherwise host_window_bounds raises kNeedDeep and the contig runs with DEEP = true: one
@@ -348,15 +356,22 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 #ifndef CL_MINWAVES
 #define CL_MINWAVES 8
 #endif
+// timing experiments (tools/): phases of k_pileup are skipped by bits of PileupArgs::ablate -- compiled in only with
+// -DCL_TUNING, never into the library the product loads (results are wrong with any bit set)
+#ifdef CL_TUNING
+#define CL_ABL(bit) ((a.ablate & (bit)) != 0u)
+#else
+#define CL_ABL(bit) false
+#endif
 
 template <int T, bool DEBUG, bool ORF, bool DEEP, int LONG>
-__global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4 : CL_MINWAVES)) void k_pileup(PileupArgs a)
+__global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1 || LONG == 4) ? 4 : CL_MINWAVES)) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
     constexpr int kWaves = kBlock / 64;
     constexpr int kSegRound = 2;                    // segments a lane may emit per round
-    constexpr int kListCap = 64 * kSegRound + 16;   // entries of one wave's list (+ carried-over entries)
+    constexpr int kListCap = LONG == 2 ? 1 : 64 * kSegRound + 16;   // entries of one wave's list (+ carried-over entries)
     constexpr uint32_t kLutLds = 256;
     // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
     // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
@@ -377,7 +392,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     // hipcc turns them into a scalar loop over the active lanes.)
     __shared__ unsigned long long s_wtot[kWaves][12];          // [10], [11]: sums of the reads the window owns (LONG = 0)
     // LONG: the live reads of a pass, two entries each: {candidate number, op index, x, y}, {op end, quality offset, quality length, -}
-    __shared__ __attribute__((aligned(16))) uint4 s_live[LONG ? 2 * kBlock : 1];
+    __shared__ __attribute__((aligned(16))) uint4 s_live[(LONG == 1 || LONG == 4) ? 2 * kBlock : 1];
     __shared__ uint32_t s_nlive;
     // LONG = 4: first block number of every live read of the pass (+ the total at [n])
     __shared__ uint32_t s_blk[LONG == 4 ? kBlock + 1 : 1];
@@ -447,7 +462,10 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     // optimistically and the window's maximum raw depth, known in the final phase, is the check: beyond
     // 255 the kernel marks the window in win_wide, raises kNeedWide8, and the host runs the contig again:
     // marked windows then use the 16-bit fields.
-    const bool mode8 = !DEEP && (n_cand <= 510u || a.win_wide[w] == 0);
+    // (LONG = 2: the counter set of a piece is its read's parity in the contig, not in the window's candidate list, so the
+    // candidate count bounds nothing and the maximum raw depth is the check for every window.)
+    constexpr bool kByDepth = LONG == 2;
+    const bool mode8 = !DEEP && ((!kByDepth && n_cand <= 510u) || a.win_wide[w] == 0);
 
     // ---- the pass over the reads ----
     uint32_t sq32 = 0;                              // sum of passing qualities handled by this lane
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
         }
     };
     auto consume_list = [&](uint32_t n_use) {
-        if (a.ablate & 1u) return;
+        if (CL_ABL(1u)) return;
         using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
         if (DEEP) consume(std::integral_constant<int, 2>{}, I3{}, n_use);
         else if (mode8) { if (a.upl == 2u) consume(std::integral_constant<int, 0>{}, I2{}, n_use); else consume(std::integral_constant<int, 0>{}, I3{}, n_use); }
@@ -517,7 +535,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
     uint32_t n_ul = 0;
     auto consume_units = [&](uint32_t n) {
         constexpr int UL = 4;
-        if (a.ablate & 4u) return;                 // timing experiments: units located and listed, nothing applied
+        if (CL_ABL(4u)) return;                 // timing experiments: units located and listed, nothing applied
         for (uint32_t b0 = 0; b0 < n; b0 += 64u * UL) {
             uint2 d[UL];
             Q16 v[UL];
@@ -544,7 +562,92 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
             }
         }
     };
-    for (uint32_t base = 0; base < ((a.ablate & 2u) ? 0u : n_cand); base += kBlock) {
+    if constexpr (LONG == 2) {
+        // ---- run-table form.  (1) the window's candidates: +-1 at the clipped span ends, and the separable sums of the
+        //      reads that start here (contig_profiler.rs:74) ----
+        for (uint32_t base = 0; base < n_cand; base += kBlock) {
+            const uint32_t v = base + tid;
+            unsigned long long own_len = 0, own_mq = 0;
+            if (v < n_cand) {
+                const uint32_t r = v < wn ? a.wide_idx[wlo + v] : lo + (v - wn);
+                const uint32_t x = (uint32_t)a.R.pos[r], e = a.end[r], mq = a.R.mapq[r];
+                if (x >= W) {                                    // the window that holds the read's start owns its sums
+                    own_len = e - x;
+                    own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
+                }
+                if (e > W) {
+                    const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
+                    uint32_t ib, vb, ie, ve2;
+                    if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
+                    else {
+                        ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
+                        ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                    }
+                    atomicAdd(&s_raw[ib], vb);
+                    if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
+                    if (mq <= a.o.max_low_mapq) {
+                        atomicAdd(&s_low[ib], vb);
+                        if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
+                    }
+                }
+            }
+            win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq);
+        }
+        // ---- (2) the window's pieces, streamed: entry {x, y}: x + 16 u = byte offset of unit u's qualities from qbase;
+        //      y = start (11 bits) | end - 1 (11) | - | counter set (bit 29) | - | valid (bit 31).  A piece covers the
+        //      unit of its start and at most the next one. ----
+        {
+            constexpr int E = 2;                                 // entries per lane and trip: four quality loads in flight
+            const uint2 *ent = a.runtab + wm.rlo;
+            const uint32_t nent = CL_ABL(2u) ? 0u : wm.rn;
+            auto fetch = [&](uint32_t b, uint2 (&d)[E]) {
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    const uint32_t idx = b + (uint32_t)j * kBlock + tid;
+                    d[j] = make_uint2((uint32_t)kQualPad, 0u);   // a lane without an entry loads the window's first bytes
+                    if (idx < nent) d[j] = ent[idx];
+                }
+            };
+            uint2 d[E], dn[E];
+            fetch(0u, d);
+            for (uint32_t b = 0; b < nent; b += kBlock * E) {     // block-uniform
+                fetch(b + kBlock * E, dn);                        // the next trip's entries are requested first
+                Q16 v[E][2];
+                uint32_t u0[E], two[E];
+#pragma unroll
+                for (int j = 0; j < E; ++j) {
+                    u0[j] = (d[j].y & 2047u) >> 4;
+                    two[j] = (((d[j].y >> 11) & 2047u) >> 4) - u0[j];          // 0 or 1
+                    __builtin_memcpy(&v[j][0], qbase + (d[j].x + (u0[j] << 4)), 16);
+                    __builtin_memcpy(&v[j][1], qbase + (d[j].x + ((u0[j] + two[j]) << 4)), 16);
+                }
+                if (!CL_ABL(4u)) {
+#pragma unroll
+                    for (int j = 0; j < E; ++j) {
+                        const uint32_t srel = d[j].y & 2047u, trel = ((d[j].y >> 11) & 2047u) + 1u;
+                        const uint32_t set_off = ((d[j].y >> 29) & 1u) * (uint32_t)(T / 8);
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            if ((d[j].y >> 31) && (h == 0 || two[j])) {
+                                const uint32_t u = u0[j] + (uint32_t)h, ps = u << 4;
+                                const uint32_t vs = srel > ps ? srel - ps : 0u;
+                                const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
+                                const uint4 ms = s_mstart[vs], me = s_mend[ve];
+                                const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
+                                if (DEEP) sq32 += apply_unit32<ORF>(v[j][h], vm, u, s_qcw, a.o);
+                                else if (mode8) sq32 += apply_unit8<ORF>(v[j][h], vm, u, set_off, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                                else sq32 += apply_unit16<ORF>(v[j][h], vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < E; ++j) d[j] = dn[j];
+                sumq += sq32; sq32 = 0;
+            }
+        }
+    } else
+    for (uint32_t base = 0; base < (CL_ABL(2u) ? 0u : n_cand); base += kBlock) {
         const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets
         uint32_t r = lo + (v - wn);
         if (v < wn) r = a.wide_idx[wlo + v];
@@ -743,7 +846,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                 bool on = tb + g < nb;
                 if (on) locate(tb + g, cur);
                 request(cur, on, cw_c, cx_c, cy_c);
-                while (tb < nb && !(a.ablate & 8u)) {               // wave-uniform (bit 8: timing experiment, no trips)
+                while (tb < nb && !(CL_ABL(8u))) {               // wave-uniform (bit 8: timing experiment, no trips)
                     const uint32_t tbn = tb + 4u * (uint32_t)kWaves;
                     const bool on_n = tbn + g < nb;
                     if (on_n) locate(tbn + g, nxt);
@@ -778,7 +881,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                         const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
                         uint32_t tp = xe < Wend ? xe : Wend;
                         tp = (xs + lq) < tp ? (xs + lq) : tp;
-                        const bool valid = ism && sp < tp && !(a.ablate & 1u);
+                        const bool valid = ism && sp < tp && !(CL_ABL(1u));
                         const uint32_t sr = sp - W, tr = tp - W;
                         const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
                         const bool big = valid && (tr - sr) > 64u;
@@ -908,7 +1011,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
                         const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
                         uint32_t tp = xe < Wend ? xe : Wend;
                         tp = (xs + lq) < tp ? (xs + lq) : tp;
-                        const bool valid = ism && sp < tp && !(a.ablate & 1u);
+                        const bool valid = ism && sp < tp && !(CL_ABL(1u));
                         const uint32_t sr = sp - W, tr = tp - W;
                         const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
                         const bool big = valid && (tr - sr) > 64u;
@@ -1285,7 +1388,7 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG) ? 4
         for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
         wp.max_raw = m;
         a.winpart[w] = wp;
-        if (!DEEP && mode8 && n_cand > 510u && m > 255u) { a.win_wide[w] = 1; atomicOr(a.err_flag, kNeedWide8); }
+        if (!DEEP && mode8 && (kByDepth || n_cand > 510u) && m > 255u) { a.win_wide[w] = 1; atomicOr(a.err_flag, kNeedWide8); }
     }
 }
 

@@ -139,6 +139,11 @@ cl_status cl_push_reads(cl_ctx *ctx, const cl_read_tile *tile);
  * the next cl_contig_begin / cl_destroy. */
 cl_status cl_contig_finish(cl_ctx *ctx, cl_contig_summary *out,
                            const cl_interval **intervals, size_t *n_intervals);
+/* Abandons the contig that was begun (the error path of a caller: mod.rs:79 `?` leaves process_single_contig the same
+ * way).  A quality prefetch that no tile has claimed is waited for and discarded -- no copy reads the caller's buffer
+ * once this returns, and the device's staging ring is free for other contexts --, staged reads are dropped.  The
+ * message of cl_last_error() survives.  cl_contig_begin and cl_destroy imply it. */
+cl_status cl_contig_abort(cl_ctx *ctx);
 
 /* ---- the same, split so that a caller can keep a contig resident in HBM and re-run it ---- */
 cl_status cl_contig_upload(cl_ctx *ctx);      /* H2D of everything pushed; synchronous     */

@@ -36,4 +36,5 @@ extern "C" {
     pub fn cl_push_reads(ctx: *mut ClCtx, tile: *const ClReadTile) -> c_int;
     pub fn cl_contig_finish(ctx: *mut ClCtx, out: *mut ClContigSummary,
                             iv: *mut *const ClInterval, n_iv: *mut usize) -> c_int;
+    pub fn cl_contig_abort(ctx: *mut ClCtx) -> c_int;      // error path: cancels an unclaimed prefetch, drops staged reads
 }

@@ -965,3 +965,84 @@ def test_long_reads_with_eqx_cigars(tmp_path):
     ref = synth.make_reference(L, synth.seed_for(3, 29))
     compare([("chrE", 3, L, ref, rec)], dict(), tmp_path, "eqx")
     compare([("chrE", 3, L, ref, rec)], dict(min_base_quality=25, min_mapping_quality=30, max_depth=30), tmp_path, "eqx2")
+
+
+# ---- the run-table form of k_pileup (contigs with short match runs): the host's walk at upload ----
+_RUN_TABLE_CASE = r"""
+import os, sys, tempfile, pathlib
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import numpy as np
+import test_gpu_parity as T
+from decodingustools_amd import synth
+L = 150_000
+rec = synth.long_read_contig(L, 50, synth.seed_for(3, 31))
+ref = synth.make_reference(L, synth.seed_for(3, 31))
+assert rec.cigar.shape[0] >= 8 * rec.n and rec.qual.shape[0] < 56 * rec.cigar.shape[0]
+T.compare([("chrR", 5, L, ref, rec)], dict(), pathlib.Path(tempfile.mkdtemp()), "runtab_" + os.environ["DUT_RUN_CHUNK"])
+print("RUN_TABLE_OK")
+"""
+
+
+@pytest.mark.parametrize("chunk", ["70", "3000", "40000"])
+def test_run_table_through_small_pinned_buffers(chunk):
+    """The pieces of a window go to HBM through pinned buffers of DUT_RUN_CHUNK pieces: 70 -- every window is larger than
+    a buffer and travels as a block of its own; 3 000 -- a buffer holds less than one ordinary window; 40 000 -- a few
+    windows per buffer, the buffer-full path with the window started over.  (The knob is read once per process.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUT_RUN_CHUNK=chunk)
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _RUN_TABLE_CASE], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "RUN_TABLE_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_run_table_with_one_base_runs_needs_the_second_sizing_pass(tmp_path):
+    """Match runs of one base (a piece per base): more pieces than the first estimate of the device array holds, so the
+    walk runs twice; '=' / 'X' runs, reads that start in the middle of a unit, a deletion right at a window seam."""
+    L = 9_000
+    rng = np.random.default_rng(77)
+    reads = []
+    for i, p in enumerate(np.sort(rng.integers(0, L - 700, 2600))):
+        unit = ["1M1I1M1D", "1=1I1X1D", "2M1D1M1I"][i % 3]
+        cig = unit * 60
+        if i % 4 == 0:
+            cig = f"{int(rng.integers(1, 6))}S" + cig
+        reads.append((int(p), cig, int(rng.choice([0, 9, 10, 60, 60])), int(rng.choice([5, 19, 20, 40])), 0, f"o{i}"))
+    # a read whose deletion spans the seam between the windows at 2048 and another that ends exactly on it
+    reads.append((2040, "8M3D9M", 60, 33, 0, "seam1")); reads.append((2032, "16M", 60, 33, 0, "seam2"))
+    reads.sort(key=lambda r: r[0])
+    rec = ContigRecords.from_reads(reads)
+    assert rec.cigar.shape[0] >= 8 * rec.n and rec.qual.shape[0] < 56 * rec.cigar.shape[0]
+    ref = synth.make_reference(L, 78)
+    compare([("chr1b", 2, L, ref, rec)], dict(max_depth=100_000, min_depth=2), tmp_path, "runtab1b")
+    compare([("chr1b", 2, L, ref, rec)], dict(max_depth=100_000, min_base_quality=0, min_mapping_quality=0), tmp_path, "runtab1b0")
+
+
+def test_run_table_with_truncated_qualities_and_long_runs(tmp_path):
+    """Reads whose quality string is shorter than their CIGAR says (pieces stop where the bytes do), runs longer than two
+    units (several pieces per run), long N gaps and reads that span many windows -- in a contig the run-table form takes."""
+    L = 60_000
+    rng = np.random.default_rng(91)
+    reads = []
+    for i, p in enumerate(np.sort(rng.integers(0, L - 9000, 500))):
+        ops = []
+        for j in range(int(rng.integers(20, 60))):
+            ops.append(f"{int(rng.integers(1, 120))}M")
+            ops.append(rng.choice(["1I", "2D", "1D", "3I", "300N" if j % 17 == 0 else "1D"]))
+        cig = "".join(ops)
+        reads.append([int(p), cig, int(rng.choice([0, 10, 60])), int(rng.choice([10, 20, 30])), 0, f"t{i}"])
+    rec = ContigRecords.from_reads(reads)
+    # cut the quality strings of every third read short (records.validate() only checks the totals)
+    keep = np.ones(rec.qual.shape[0], bool)
+    qoff = rec.qual_off.astype(np.int64)
+    newoff = [0]
+    for i in range(rec.n):
+        a, b = int(qoff[i]), int(qoff[i + 1])
+        cut = (b - a) // 3 if i % 3 == 0 else 0
+        keep[b - cut:b] = False
+        newoff.append(newoff[-1] + (b - a - cut))
+    rec.qual = np.ascontiguousarray(rec.qual[keep]); rec.qual_off = np.asarray(newoff, np.uint64)
+    rec.validate()
+    if not (rec.cigar.shape[0] >= 8 * rec.n and rec.qual.shape[0] < 56 * rec.cigar.shape[0]):
+        pytest.skip("shape does not select the run-table form")
+    ref = synth.make_reference(L, 92)
+    compare([("chrT", 1, L, ref, rec)], dict(min_depth=1), tmp_path, "runtabT")

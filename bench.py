@@ -171,15 +171,72 @@ def traffic_from_profiles():
         return None
 
 
-def measure_traffic(args):
-    """roofline.traffic of THIS run: the HBM bytes of one k_pileup launch from the PMC counters, collected the way
-    MI355X_MICROARCH.md's HBM section prescribes -- FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes, no
-    tracing domain beside them -- over two child runs of this script on the same workload (5 + 2 steps, no oracle, no
-    secondary lines), after the timed region.  bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: the counters are in KB
-    and gfx950's FETCH_SIZE counts 64 B per 128-byte request of a wide streaming read.  Returns (bytes, detail) or
-    (None, reason): a profiler that is missing or refuses never costs the bench line."""
+def save_records(dirpath, tag, rec, ref, extra=None):
+    """The inputs of a workload as .npy files for the PMC child passes (they would otherwise generate them again:
+    a minute per pass).  Returns False when the scratch directory cannot take them."""
+    try:
+        d = os.path.join(dirpath, tag)
+        os.makedirs(d, exist_ok=True)
+        for k in ("pos", "flag", "mapq", "cigar_off", "cigar", "qual_off", "qual", "qname_off", "qname", "seq_off", "seq4"):
+            v = getattr(rec, k, None)
+            if v is not None:
+                np.save(os.path.join(d, k + ".npy"), v)
+        np.save(os.path.join(d, "ref.npy"), ref)
+        for k, v in (extra or {}).items():
+            np.save(os.path.join(d, k + ".npy"), v)
+        return True
+    except Exception as e:
+        log(f"[bench] could not cache the {tag} inputs for the PMC passes: {e}")
+        return False
+
+
+def load_records(dirpath, tag):
+    from decodingustools_amd.records import ContigRecords
+    d = os.path.join(dirpath, tag)
+    f = {k[:-4]: np.load(os.path.join(d, k)) for k in os.listdir(d) if k.endswith(".npy")}
+    rec = ContigRecords(pos=f["pos"], flag=f["flag"], mapq=f["mapq"], cigar_off=f["cigar_off"], cigar=f["cigar"],
+                        qual_off=f["qual_off"], qual=f["qual"], qname_off=f["qname_off"], qname=f["qname"],
+                        seq_off=f.get("seq_off"), seq4=f.get("seq4"))
+    return rec, f["ref"], f
+
+
+def pmc_child(dirpath, dev_id):
+    """What runs under `rocprofv3 --pmc <counter>`: every workload cached in `dirpath` once through the engine and a
+    few resident steps more.  Prints nothing: the parent reads the profiler's CSV by kernel name."""
+    from decodingustools_amd import (CallableOptions, CallableProfiler, ContigProfiler, Engine, process_single_contig)
+    opt = CallableOptions()
+    tmpd = tempfile.mkdtemp()
+    for tag, name, tid in (("chr21", "chr21", 20), ("long", "chrY", 23)):
+        if not os.path.isdir(os.path.join(dirpath, tag)):
+            continue
+        rec, ref, _ = load_records(dirpath, tag)
+        with Engine(opt, dev_id) as eng:
+            counter = CallableProfiler(os.path.join(tmpd, tag + ".bed"))
+            process_single_contig(eng, counter, ContigProfiler(name, ref.shape[0]), opt, tid, rec, ref)
+            counter.close()
+            for _ in range(4):
+                eng.contig_run()
+            eng.sync()
+        del rec, ref
+    if os.path.isdir(os.path.join(dirpath, "site")):
+        rec, ref, f = load_records(dirpath, "site")
+        with Engine(opt, dev_id) as eng:
+            for _ in range(2):
+                eng.site_pileup(20, ref.shape[0], ref.shape[0], rec, f["sites"])
+
+
+def measure_traffic(cache_dir):
+    """roofline.traffic of THIS run: HBM bytes per launch from the PMC counters, collected the way MI355X_MICROARCH.md's
+    HBM section prescribes -- FETCH_SIZE and WRITE_SIZE in separate `rocprofv3 --pmc` passes, no tracing domain beside
+    them -- over two child runs of this script (--pmc-child: the cached inputs of the headline workload and of the
+    secondary ones, a first pass and four resident steps each), after the timed region.  bytes = (2 x FETCH_SIZE +
+    WRITE_SIZE) x 1024: the counters are in KB and gfx950's FETCH_SIZE counts 64 B per 128-byte request of a wide
+    streaming read (calibrated on k_pileup's access pattern with tools/ubench/fetch_calib.hip; the site kernel's
+    scattered byte loads are not such a stream, so its figure is reported raw as well).  Returns ({kernel key: {...}},
+    None) or (None, reason): a profiler that is missing or refuses never costs the bench line."""
     import csv
     import glob
+    import re
     import shutil
     import subprocess
     rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
@@ -191,27 +248,40 @@ def measure_traffic(args):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
         cmd = [rp, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
-               "--steps", "5", "--warmup", "2", "--cpu-sample", "0", "--no-secondary", "--no-traffic", "--min-time", "0",
-               "--max-blocks", "1", "--length", str(args.length), "--depth", str(args.depth)]
+               "--pmc-child", cache_dir]
         try:
-            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=300)
-            vals = []
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=420)
+            vals = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_pileup" in row.get("Kernel_Name", "") and row.get("Counter_Name") == ctr:
-                        vals.append(float(row["Counter_Value"]))
+                    kn = row.get("Kernel_Name", "")
+                    if row.get("Counter_Name") != ctr:
+                        continue
+                    if "k_site_pileup" in kn:
+                        key = "k_site_pileup"
+                    elif "k_pileup" in kn:
+                        m = re.search(r"k_pileup<[^>]*?(\d+)\s*>", kn)
+                        key = "k_pileup_form" + (m.group(1) if m else "?")
+                    else:
+                        continue
+                    vals.setdefault(key, []).append(float(row["Counter_Value"]))
             if not vals:
-                return None, f"no {ctr} rows for k_pileup (rocprofv3 rc {r.returncode}: {(r.stderr or '')[-200:]})"
-            got[ctr] = (sum(vals) / len(vals), len(vals))
+                return None, f"no {ctr} rows (rocprofv3 rc {r.returncode}: {(r.stderr or '')[-300:]})"
+            got[ctr] = {k: (sum(v) / len(v), len(v)) for k, v in vals.items()}
         except Exception as e:
             return None, f"{ctr} pass failed: {e}"
         finally:
             shutil.rmtree(d, ignore_errors=True)
-    nbytes = int((2.0 * got["FETCH_SIZE"][0] + got["WRITE_SIZE"][0]) * 1024)
-    return nbytes, {"FETCH_SIZE_KB": got["FETCH_SIZE"][0], "WRITE_SIZE_KB": got["WRITE_SIZE"][0],
-                    "launches_averaged": got["FETCH_SIZE"][1],
+    out = {}
+    for key in got["FETCH_SIZE"]:
+        if key not in got["WRITE_SIZE"]:
+            continue
+        fk, n = got["FETCH_SIZE"][key]
+        wk = got["WRITE_SIZE"][key][0]
+        out[key] = {"bytes": int((2.0 * fk + wk) * 1024), "FETCH_SIZE_KB": fk, "WRITE_SIZE_KB": wk, "launches_averaged": n,
                     "how": "two child runs of bench.py under rocprofv3 --pmc (FETCH_SIZE, then WRITE_SIZE), "
                            "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024"}
+    return out, None
 
 
 def roofline(alg_bytes, pile_ms, step_ms, kms, n_gpus=1):
@@ -227,72 +297,159 @@ def roofline(alg_bytes, pile_ms, step_ms, kms, n_gpus=1):
 
 
 # ------------------------------------------------------------------------------------------------
-# secondary configurations (N = 1 only): driver-observed lines for configs[2] and configs[4]
+# secondary measurements of the N = 1 line: configs[2] (long reads), configs[4] (site pileup), the same
+# chr21 input from BAM + FASTA files, and configs[3] on this one GPU (the 1-GPU point of the scaling curve)
 # ------------------------------------------------------------------------------------------------
-def secondary_configs(dev_id, opt, args):
+def long_read_config(dev_id, opt, args, cache_dir, tmpd):
+    """configs[2]: chrY-shaped, 50x, long reads (median 10 kb, an indel every ~15 bases); BED and summary compared with
+    the oracle over the WHOLE contig."""
+    import oracle
     from decodingustools_amd import CallableProfiler, ContigProfiler, Engine, process_single_contig, synth
-    out = {}
-    tmpd = tempfile.mkdtemp()
-    # configs[2]: chrY-shaped, 50x, long reads (median 10 kb, an indel every ~15 bases)
-    try:
-        L = args.long_length
+    L = args.long_length
+    t0 = time.perf_counter()
+    seed = synth.seed_for(3, 23)
+    rec = synth.long_read_contig(L, 50, seed)
+    ref = synth.make_reference(L, seed)
+    gen = time.perf_counter() - t0
+    gbed = os.path.join(tmpd, "long.bed")
+    with Engine(opt, dev_id) as eng:
+        counter = CallableProfiler(gbed)
+        st = ContigProfiler("chrY", L)
         t0 = time.perf_counter()
-        seed = synth.seed_for(3, 23)
-        rec = synth.long_read_contig(L, 50, seed)
-        ref = synth.make_reference(L, seed)
-        gen = time.perf_counter() - t0
-        with Engine(opt, dev_id) as eng:
-            counter = CallableProfiler(os.path.join(tmpd, "long.bed"))
-            st = ContigProfiler("chrY", L)
-            t0 = time.perf_counter()
-            process_single_contig(eng, counter, st, opt, 23, rec, ref)
-            counter.close()
-            first = time.perf_counter() - t0
-            for _ in range(2):
-                eng.contig_run()
-            eng.sync()
-            kms, _ = kernel_profile([eng], 5)
-            inb, outb = eng.contig_bytes()
-        step = sum(kms.values())
-        out["long_read_chrY_50x"] = {
-            "workload": "coverage -L chrY synthetic 50x long-read (10 kb ONT-style CIGAR with indels), device-resident",
-            "contig_len": L, "reads": rec.n, "cigar_ops": int(rec.cigar.shape[0]), "aligned_bases": int(rec.qual.shape[0]),
-            "value": L / (step * 1e-3), "unit": "bases/s", "ms_per_step": step, "generated_in_s": round(gen, 1),
-            "end_to_end_first_pass_s": first,
-            "roofline": roofline(inb + outb, kms["pileup"], step, kms)}
-        out["long_read_chrY_50x"]["roofline"].pop("traffic_from_profiles", None)
-        del rec, ref
-    except Exception as e:                                  # a secondary line must not cost the headline
-        out["long_read_chrY_50x"] = {"error": str(e)}
-    # configs[4]: chrY-shaped, 40x, config-2 read model with bases, 200 000 sites, min_quality 20
-    try:
-        L = args.site_length
+        process_single_contig(eng, counter, st, opt, 23, rec, ref)
+        counter.close()
+        first = time.perf_counter() - t0
+        for _ in range(2):
+            eng.contig_run()
+        eng.sync()
+        kms, _ = kernel_profile([eng], 5)
+        inb, outb = eng.contig_bytes()
+    step = sum(kms.values())
+    out = {
+        "workload": "coverage -L chrY synthetic 50x long-read (10 kb ONT-style CIGAR with indels), device-resident",
+        "contig_len": L, "reads": rec.n, "cigar_ops": int(rec.cigar.shape[0]), "aligned_bases": int(rec.qual.shape[0]),
+        "value": L / (step * 1e-3), "unit": "bases/s", "ms_per_step": step, "generated_in_s": round(gen, 1),
+        "end_to_end_first_pass_s": first,
+        "roofline": roofline(inb + outb, kms["pileup"], step, kms)}
+    out["roofline"].pop("traffic_from_profiles", None)
+    if args.cpu_sample != 0:
+        obed = os.path.join(tmpd, "long_o.bed")
+        prof = oracle.Profiler(obed)
         t0 = time.perf_counter()
-        seed = synth.seed_for(5, 23)
-        ref = synth.make_reference(L, seed)
-        rec = synth.short_read_contig(L, 40, seed, with_seq=True, ref=ref, max_live_assert=0)
-        rng = np.random.default_rng(5)
-        sites = rng.choice(np.arange(1, L + 1), size=min(200_000, L), replace=False).astype(np.uint32)
-        gen = time.perf_counter() - t0
-        with Engine(opt, dev_id) as eng:
-            ms_all = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                hist = eng.site_pileup(20, L, L, rec, sites)
-                call = time.perf_counter() - t0
-                kms_, nb = eng.site_pileup_stats()
-                ms_all.append(kms_)
-        kms_ = min(ms_all)
-        ach = nb / (kms_ * 1e-3) / 1e9 if kms_ > 0 else 0.0
-        out["site_pileup_chrY_40x"] = {
-            "workload": "find-y-branch pileup path: chrY 40x synthetic, 200 000-site list, device kernel only",
-            "contig_len": L, "reads": rec.n, "sites": int(sites.shape[0]), "sites_hit": int((hist.sum(1) > 0).sum()),
-            "kernel_ms": kms_, "call_s_incl_h2d": call, "generated_in_s": round(gen, 1),
-            "roofline": {"bound": "hbm", "kernel": "k_site_pileup", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                         "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_launch": nb}}
-    except Exception as e:
-        out["site_pileup_chrY_40x"] = {"error": str(e)}
+        ost, _ = oracle.process_single_contig(prof, opt, "chrY", 23, L, ref, rec)
+        prof.close()
+        cdt = time.perf_counter() - t0
+        exact = open(gbed).read() == open(obed).read() and all(
+            getattr(st, k) == ost[k] for k in ("n_covered_bases", "summed_coverage", "summed_baseq", "summed_mapq", "quality_bases", "n_reads"))
+        out["bed_bit_exact"] = bool(exact)
+        out["bed_bit_exact_positions"] = L
+        out["cpu_baseline"] = {"value": L / cdt, "unit": "bases/s", "cores": 1, "kind": "port",
+                               "sample": f"the whole contig, {L} positions, oracle/callable_oracle.c single thread, {cdt:.1f}s"}
+        if not exact:
+            log("[bench] WARNING: long-read GPU BED/summary differs from the oracle")
+    out["_cached"] = save_records(cache_dir, "long", rec, ref) if cache_dir else False
     return out
+
+
+def site_config(dev_id, opt, args, cache_dir):
+    """configs[4]: chrY-shaped, 40x, config-2 read model with bases, 200 000 sites, min_quality 20; the full histogram
+    compared with the oracle's."""
+    import oracle
+    from decodingustools_amd import Engine, synth
+    L = args.site_length
+    t0 = time.perf_counter()
+    seed = synth.seed_for(5, 23)
+    ref = synth.make_reference(L, seed)
+    rec = synth.short_read_contig(L, 40, seed, with_seq=True, ref=ref, max_live_assert=0)
+    rng = np.random.default_rng(5)
+    sites = rng.choice(np.arange(1, L + 1), size=min(200_000, L), replace=False).astype(np.uint32)
+    gen = time.perf_counter() - t0
+    with Engine(opt, dev_id) as eng:
+        ms_all, calls = [], []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            hist = eng.site_pileup(20, L, L, rec, sites)
+            calls.append(time.perf_counter() - t0)
+            kms_, nb = eng.site_pileup_stats()
+            ms_all.append(kms_)
+    kms_ = min(ms_all)
+    ach = nb / (kms_ * 1e-3) / 1e9 if kms_ > 0 else 0.0
+    out = {
+        "workload": "find-y-branch pileup path: chrY 40x synthetic, 200 000-site list, device kernel only",
+        "contig_len": L, "reads": rec.n, "sites": int(sites.shape[0]), "sites_hit": int((hist.sum(1) > 0).sum()),
+        "kernel_ms": kms_, "call_s_incl_h2d": min(calls), "call_s_first": calls[0], "generated_in_s": round(gen, 1),
+        "roofline": {"bound": "hbm", "kernel": "k_site_pileup", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_launch": nb,
+                     "note": "nominal: SURVEY 8d's byte count includes the 4-bit bases of every read; the kernel touches the bases at sites only"}}
+    if args.cpu_sample != 0:
+        t0 = time.perf_counter()
+        exp = oracle.site_pileup(10, 20, L, ref, rec, sites)
+        cdt = time.perf_counter() - t0
+        out["hist_exact"] = bool(np.array_equal(exp["hist"], hist))
+        out["hist_exact_rows"] = int(sites.shape[0])
+        out["cpu_baseline"] = {"value": rec.n / cdt, "unit": "reads/s", "cores": 1, "kind": "port",
+                               "sample": f"all {rec.n} reads x {sites.shape[0]} sites, oracle/callable_oracle.c single thread, {cdt:.1f}s"}
+        if not out["hist_exact"]:
+            log("[bench] WARNING: site histogram differs from the oracle")
+    out["_cached"] = save_records(cache_dir, "site", rec, ref, {"sites": sites}) if cache_dir else False
+    return out
+
+
+def files_config(dev_id, opt, rec, ref, L, first_bed_path, tmpd):
+    """SURVEY 8d timing (ii): the headline input as a BGZF BAM + .bai + FASTA + .fai on disk (written outside the timed
+    call by the harness's own writer) -> dut_coverage_files -> BED + summary.json; the BED must equal the first pass's."""
+    import contextlib
+    import io
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_bench_lib as EL
+    from decodingustools_amd import build as _b
+    bam, fa = os.path.join(tmpd, "chr21.bam"), os.path.join(tmpd, "chr21.fa")
+    t0 = time.perf_counter()
+    EL.write_bam_native(tmpd, bam, "chr21", L, rec, threads=min(16, int(os.environ.get("DUT_THREADS", "16"))))
+    EL.write_single_ref_bai(bam + ".bai", rec.n)
+    EL.write_fasta(fa, "chr21", ref)
+    wrote = time.perf_counter() - t0
+    out = {"workload": "coverage chr21.bam -r chr21.fa -o out.bed (BGZF inflate + record parse + admission + H2D + kernels + BED + summary.json)",
+           "bam_bytes": os.path.getsize(bam), "records": rec.n, "files_written_in_s": round(wrote, 1),
+           "host_threads": int(os.environ.get("DUT_THREADS", "0")) or None, "runs": []}
+    # the product's own command line tool, a fresh process per run as a user would start it (DUT_TIMING: its host stages)
+    for rep in range(2):
+        bed = os.path.join(tmpd, f"files{rep}.bed")
+        env = dict(os.environ, DUT_TIMING="1")
+        t0 = time.perf_counter()
+        r = subprocess.run([_b.CLI, "coverage", bam, "-r", fa, "-o", bed], cwd=tmpd, env=env, capture_output=True, text=True, timeout=300)
+        dt = time.perf_counter() - t0
+        if r.returncode != 0:
+            out["error"] = (r.stderr or "")[-400:]
+            return out
+        stages = {}
+        for ln in (r.stderr or "").splitlines():
+            m = ln.split("]", 1)
+            if ln.startswith("[dut-timing]") and len(m) == 2 and not m[1].startswith("   "):
+                parts = m[1].rsplit(None, 2)
+                if len(parts) == 3 and parts[2] == "ms":
+                    stages[parts[0].strip()] = stages.get(parts[0].strip(), 0.0) + float(parts[1])
+        out["runs"].append({"wall_s": dt, "stages_ms": stages})
+    best = min(x["wall_s"] for x in out["runs"])
+    out["seconds"] = best
+    out["value"] = L / best
+    out["unit"] = "bases/s"
+    out["bed_equals_first_pass"] = open(os.path.join(tmpd, "files1.bed")).read() == open(first_bed_path).read()
+    return out
+
+
+def wgs_point(args, dev_id, torch, dist, coll_dev):
+    """configs[3] on this ONE GPU: the fixed whole-genome input of the N > 1 runs, all 25 contigs resident -- the 1-GPU
+    point of the strong-scaling curve."""
+    full = run_wgs(args, 0, 1, dev_id, torch, dist, coll_dev)
+    keep = {k: full[k] for k in ("value", "unit", "ms_per_step", "scaling", "timing", "roofline", "callable_fraction")}
+    keep["workload"] = full["config"]["workload"]
+    keep["total_bases"] = full["config"]["total_bases"]
+    keep["per_rank_first_pass_s"] = full["sharding"]["per_rank_first_pass_s"]
+    keep["build_s"] = full["sharding"]["build_s"]
+    keep["roofline"].pop("traffic_from_profiles", None)
+    return keep
 
 
 # ------------------------------------------------------------------------------------------------
@@ -401,21 +558,92 @@ def run_chr21(args, rank, world, dev_id, torch, dist, coll_dev):
         if not exact:
             log("[bench] WARNING: GPU BED/summary differs from the oracle")
     eng.close()
-    del rec, ref
-    if world == 1 and not args.no_secondary:
-        out["configs"] = secondary_configs(dev_id, opt, args)
+    if world != 1:
+        return out
+    # ---- the secondary measurements, each under the time budget; none may cost the headline ----
+    t_start = args._t_start
+    cache_dir = None
     profiled = any("rocprof" in os.environ.get(k, "") for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES"))
-    if world == 1 and rank == 0 and not args.no_traffic and not profiled:
-        t0 = time.perf_counter()
-        nbytes, detail = measure_traffic(args)
-        if nbytes is not None:
-            out["roofline"]["traffic"] = nbytes
-            out["roofline"]["traffic_detail"] = detail
-            log(f"[bench] k_pileup HBM traffic by PMC: {nbytes / 1e6:.1f} MB per launch against "
-                f"{out['roofline']['algorithmic_bytes_per_launch'] / 1e6:.1f} MB algorithmic ({time.perf_counter() - t0:.0f}s)")
+    want_traffic = not args.no_traffic and not profiled
+    if want_traffic:
+        try:
+            cache_dir = tempfile.mkdtemp(prefix="bench_inputs_", dir="/tmp")
+            if not save_records(cache_dir, "chr21", rec, ref):
+                cache_dir = None
+        except Exception:
+            cache_dir = None
+
+    def left():
+        return args.time_budget - (time.perf_counter() - t_start)
+    skipped = []
+    if not args.no_files:
+        if left() > 60:
+            try:
+                out["end_to_end_from_bam"] = files_config(dev_id, opt, rec, ref, L, gbed_path, tmpd)
+                log(f"[bench] BAM + FASTA files -> BED: {out['end_to_end_from_bam'].get('seconds')} s")
+            except Exception as e:
+                out["end_to_end_from_bam"] = {"error": str(e)}
         else:
-            out["roofline"]["traffic_error"] = detail
-            log(f"[bench] traffic not measured: {detail}")
+            skipped.append("end_to_end_from_bam")
+    del rec, ref
+    out["configs"] = {}
+    if not args.no_secondary:
+        for key, need, fn in (("long_read_chrY_50x", 150, lambda: long_read_config(dev_id, opt, args, cache_dir, tmpd)),
+                              ("site_pileup_chrY_40x", 90, lambda: site_config(dev_id, opt, args, cache_dir))):
+            if left() < need:
+                skipped.append(key)
+                continue
+            try:
+                out["configs"][key] = fn()
+            except Exception as e:                          # a secondary line must not cost the headline
+                out["configs"][key] = {"error": str(e)}
+    if want_traffic and cache_dir:
+        if left() > 100:
+            t0 = time.perf_counter()
+            tr, why = measure_traffic(cache_dir)
+            if tr is not None:
+                k0 = tr.get("k_pileup_form0")
+                if k0:
+                    out["roofline"]["traffic"] = k0["bytes"]
+                    out["roofline"]["traffic_detail"] = k0
+                lr = out["configs"].get("long_read_chrY_50x", {})
+                if "roofline" in lr and tr.get("k_pileup_form2"):
+                    lr["roofline"]["traffic"] = tr["k_pileup_form2"]["bytes"]
+                    lr["roofline"]["traffic_detail"] = tr["k_pileup_form2"]
+                sp = out["configs"].get("site_pileup_chrY_40x", {})
+                if "roofline" in sp and tr.get("k_site_pileup"):
+                    d = tr["k_site_pileup"]
+                    rf = sp["roofline"]
+                    rf["traffic"] = d["bytes"]
+                    rf["traffic_detail"] = d
+                    rf["traffic_raw_bytes"] = int((d["FETCH_SIZE_KB"] + d["WRITE_SIZE_KB"]) * 1024)
+                    if sp.get("kernel_ms"):
+                        rf["measured_achieved"] = d["bytes"] / (sp["kernel_ms"] * 1e-3) / 1e9
+                        rf["measured_frac"] = rf["measured_achieved"] / PEAK_HBM_GBS
+                log(f"[bench] HBM traffic by PMC ({time.perf_counter() - t0:.0f}s): " +
+                    ", ".join(f"{k} {v['bytes'] / 1e6:.1f} MB" for k, v in tr.items()))
+            else:
+                out["roofline"]["traffic_error"] = why
+                log(f"[bench] traffic not measured: {why}")
+        else:
+            skipped.append("traffic")
+    if cache_dir:
+        import shutil
+        shutil.rmtree(cache_dir, ignore_errors=True)
+    for v in out["configs"].values():
+        if isinstance(v, dict):
+            v.pop("_cached", None)
+    if not args.no_wgs_point:
+        if left() > 170:
+            try:
+                out["configs"]["wgs_1gpu"] = wgs_point(args, dev_id, torch, dist, coll_dev)
+            except Exception as e:
+                out["configs"]["wgs_1gpu"] = {"error": str(e)}
+        else:
+            skipped.append("wgs_1gpu")
+    if skipped:
+        out["skipped_for_time_budget"] = skipped
+    out["bench_wall_s"] = round(time.perf_counter() - t_start, 1)
     return out
 
 
@@ -445,7 +673,7 @@ def run_wgs(args, rank, world, dev_id, torch, dist, coll_dev):
         mine_ms = sum(kms.values())
         info = torch.tensor([float(shard.bases), mine_ms, float(sum(c.first_pass_s for c in shard.mine)),
                              float(sum(c.aligned_bases for c in shard.mine)), kms.get("pileup", 0.0),
-                             float(sum(sum(c.engine.contig_bytes()) for c in shard.mine))],
+                             float(sum(sum(c.engine.contig_bytes()) for c in shard.mine)), build_s],
                             dtype=torch.float64, device=coll_dev)
         infos = [torch.zeros_like(info) for _ in range(world)]
         if world > 1:
@@ -483,7 +711,8 @@ def run_wgs(args, rank, world, dev_id, torch, dist, coll_dev):
                          "per_rank_first_pass_s": [x[2] for x in infos],
                          "lpt_imbalance": max(loads) / (sum(loads) / len(loads)),
                          "contigs_of_rank": [[n for (_, n, _), r in zip(shard.contigs, shard.rank_of) if r == k] for k in range(world)],
-                         "build_s_rank0": build_s},
+                         "build_s": [x[6] for x in infos],
+                         "host_threads_per_rank": int(os.environ.get("DUT_THREADS", "0")) or None, "gen_threads": args.gen_threads},
             # the dominant kernel over the whole job: every rank's algorithmic bytes / every rank's k_pileup time
             "roofline": roofline(alg, pile_ms, ms_step, kms, world),
             "callable_fraction": callable_b / max(total_bases, 1),
@@ -492,6 +721,87 @@ def run_wgs(args, rank, world, dev_id, torch, dist, coll_dev):
         out["roofline"]["all_kernel_ms_of"] = "rank 0"
     shard.close()
     return out
+
+
+def host_cpu_budget():
+    """CPUs this process may actually use: the affinity mask, cut by the cgroup's CFS quota (a GPU box shows 256
+    CPUs and grants 16 CPUs' worth of time)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(math.ceil(int(txt[0]) / int(txt[1])))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, int(math.ceil(q / per))))
+            break
+        except Exception:
+            continue
+    return max(1, n)
+
+
+def launch_ranks(args, argv):
+    """`bench.py --gpus N` (N > 1) started plainly, with no launcher around it: this process touches neither the GPU
+    nor the engine; it compiles what is stale, starts the N ranks as fresh processes under torch.distributed.run (one per
+    GPU, rendezvous on 127.0.0.1), hands each its share of the host (DUT_THREADS = cpu budget / N), relays rank 0's single
+    JSON line and exits with the children's status.  It never prints a line of its own."""
+    import socket
+    import subprocess
+    from decodingustools_amd import build as _native_build
+    _native_build.build()
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    budget = host_cpu_budget()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("DUT_THREADS", str(max(2, min(64, budget // args.gpus))))
+    env.setdefault("DUT_COPY_THREADS", str(max(2, min(8, budget // args.gpus))))
+    env["BENCH_HOST_BUDGET"] = str(budget)
+    launcher = os.environ.get("BENCH_LAUNCHER", "torch.distributed.run")
+    cmd = [sys.executable, "-m", launcher, "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    log(f"[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks (host budget {budget} CPUs, "
+        f"DUT_THREADS={env['DUT_THREADS']} per rank)")
+    try:
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env, cwd=ROOT)
+    except Exception as e:
+        log(f"[bench] cannot start the ranks: {e}")
+        return 3
+    lines = [ln for ln in (r.stdout or "").splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        log(f"[bench] the ranks ended with status {r.returncode} and {len(lines)} JSON line(s): no result")
+        return r.returncode or 4
+    try:
+        ok = json.loads(lines[0]).get("n_gpus") == args.gpus
+    except Exception:
+        ok = False
+    if not ok:
+        log(f"[bench] the line the ranks printed is not an n_gpus = {args.gpus} line: not relayed")
+        return 5
+    print(lines[0], flush=True)
+    return 0
+
+
+def launch_check(args, rank, world, dist, torch):
+    """--launch-check: the ranks rendezvous, exchange their numbers and rank 0 prints a line -- nothing touches the GPU or
+    the engine (the CPU test of the self-launch path)."""
+    t = torch.tensor([rank], dtype=torch.int64)
+    got = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(got, t)
+    else:
+        got = [t]
+    if rank == 0:
+        print(json.dumps({"launch_check": True, "n_gpus": world, "ranks": [int(x.item()) for x in got],
+                          "dut_threads": os.environ.get("DUT_THREADS"), "host_budget": os.environ.get("BENCH_HOST_BUDGET")}), flush=True)
 
 
 def main():
@@ -508,26 +818,54 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=-1,
                     help="positions of the CPU baseline / bit-exactness sample (-1 = the whole contig, 0 = skip)")
     ap.add_argument("--wgs-scale", type=float, default=1.0, help="wgs workload: contig lengths x this (rehearsals)")
-    ap.add_argument("--gen-threads", type=int, default=4, help="wgs workload: contigs generated ahead on host threads")
+    ap.add_argument("--gen-threads", type=int, default=0, help="wgs workload: contigs generated ahead on host threads (0: by the host budget)")
     ap.add_argument("--long-length", type=int, default=57_227_415, help="secondary config 3: contig length (chrY)")
     ap.add_argument("--site-length", type=int, default=57_227_415, help="secondary config 5: contig length (chrY)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary configs[2] / configs[4] lines")
+    ap.add_argument("--no-wgs-point", action="store_true", help="N = 1: skip configs.wgs_1gpu (the whole genome on this one GPU)")
+    ap.add_argument("--no-files", action="store_true", help="N = 1: skip end_to_end_from_bam (BAM + FASTA files -> BED)")
     ap.add_argument("--no-traffic", action="store_true",
                     help="skip the two rocprofv3 --pmc child passes that measure roofline.traffic (N = 1)")
+    ap.add_argument("--time-budget", type=float, default=480.0,
+                    help="N = 1: seconds after which the remaining secondary measurements are skipped (the headline never is)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse the multi-rank logic on one GPU)")
+    ap.add_argument("--launch-check", action="store_true", help="rendezvous of the ranks only: no GPU, no engine (tests)")
+    ap.add_argument("--pmc-child", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    args._t_start = time.perf_counter()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly for several GPUs: this process becomes the launcher, before anything touches a GPU
+        sys.exit(launch_ranks(args, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: using WORLD_SIZE")
+        log(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to measure something else than what was asked for")
+        sys.exit(2)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    budget = int(os.environ.get("BENCH_HOST_BUDGET", "0")) or host_cpu_budget()
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    # every rank its share of the host (a launcher other than this script's own may not have set it)
+    os.environ.setdefault("DUT_THREADS", str(max(2, min(64, budget // max(1, local_world)))))
+    if args.gen_threads <= 0:
+        args.gen_threads = max(1, min(8, budget // max(1, local_world) // 2))
 
     # torch first: it brings its own HIP runtime, and the engine's library must resolve against that one
     # (loading the engine before torch leaves the process with two runtimes and no usable device)
     import torch
     import torch.distributed as dist
+    if args.launch_check:
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        try:
+            launch_check(args, rank, world, dist, torch)
+        finally:
+            if world > 1:
+                dist.destroy_process_group()
+        return
     # the native pieces are (re)built before anything initialises the GPU: a process that has must not
     # start compilers (normally nothing is stale and this returns at once; every rank checks).  Compile
     # only -- the library itself is loaded further down, after the device is set.
@@ -546,6 +884,9 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_id))
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+    if args.pmc_child:
+        pmc_child(args.pmc_child, dev_id)
+        return
     workload = args.workload if args.workload != "auto" else ("chr21" if world == 1 else "wgs")
     try:
         out = (run_chr21 if workload == "chr21" else run_wgs)(args, rank, world, dev_id, torch, dist, coll_dev)

@@ -388,7 +388,8 @@ def coverage_files_sharded(bam_file: str, reference_file: str, output_bed: str, 
 
     def fetch(slot, tid, name):
         b, f = readers[slot]
-        return b.fetch_contig(tid), f.fetch(name)
+        # a zero-length contig fetches nothing (the reference's loops over it run zero times, mod.rs:65-147)
+        return b.fetch_contig(tid), (f.fetch(name) if b.target_lens[tid] > 0 else np.zeros(0, np.uint8))
     try:
         descr = []
         for t, (nm, ln) in enumerate(zip(bam.target_names, bam.target_lens)):

@@ -1,6 +1,6 @@
-// host_parallel.h -- the host side's thread helper: DUT_THREADS (default: the machine's cores, at
-// most 16) threads -- the caller and a pool of persistent workers --, work handed out in chunks through an atomic
-// counter.
+// host_parallel.h -- the host side's thread helper: DUT_THREADS threads (default: what the box gives this process --
+// its affinity mask cut by the cgroup's CPU quota, shared among the ranks of the node, at most 64) -- the caller and a
+// pool of persistent workers --, work handed out in chunks through an atomic counter.
 #pragma once
 #include <algorithm>
 #include <atomic>
@@ -13,15 +13,47 @@
 #include <vector>
 
 #include <pthread.h>
+#include <sched.h>
+#include <cstdio>
 
 namespace dut {
+
+// CPUs this process may use: the affinity mask, cut by the cgroup's CFS quota (a box can show 256 CPUs and grant 16
+// CPUs' worth of time: threads beyond the quota only add throttling)
+inline int cpu_budget()
+{
+    int n = (int)std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min(n, c); }
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0}; long long per = 0;
+        if (fscanf(f, "%31s %lld", q, &per) == 2 && q[0] != 'm' && per > 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + per - 1) / per));
+        }
+        fclose(f);
+    } else if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+        long long quota = -1, per = 0;
+        if (fscanf(g, "%lld", &quota) != 1) quota = -1;
+        fclose(g);
+        if (FILE *h = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(h, "%lld", &per) != 1) per = 0; fclose(h); }
+        if (quota > 0 && per > 0) n = std::min<long long>(n, std::max<long long>(1, (quota + per - 1) / per));
+    }
+    return n;
+}
 
 inline int worker_threads()
 {
     static const int n = [] {
         const char *e = getenv("DUT_THREADS");
         int v = e ? atoi(e) : 0;
-        if (v <= 0) v = (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+        if (v <= 0) {
+            // one process per GPU: the ranks of a node share its CPUs (LOCAL_WORLD_SIZE is what torch.distributed.run sets)
+            const char *lw = getenv("LOCAL_WORLD_SIZE");
+            const int ranks = lw && atoi(lw) > 0 ? atoi(lw) : 1;
+            v = std::max(1, std::min(64, cpu_budget() / ranks));
+        }
         return v;
     }();
     return n;

@@ -22,6 +22,7 @@ cl_status cl_contig_begin(cl_ctx *, int32_t, uint32_t, const uint8_t *, uint64_t
 cl_status cl_push_reads(cl_ctx *, const cl_read_tile *) { return CL_ERR_DEVICE; }
 cl_status cl_contig_prefetch_qual(cl_ctx *, const uint8_t *, uint64_t) { return CL_ERR_DEVICE; }
 cl_status cl_contig_finish(cl_ctx *, cl_contig_summary *, const cl_interval **, size_t *) { return CL_ERR_DEVICE; }
+cl_status cl_contig_abort(cl_ctx *) { return CL_OK; }
 cl_status cl_site_pileup(cl_ctx *, uint8_t, uint32_t, uint64_t, const cl_site_tile *, const uint32_t *, size_t, uint32_t *) { return CL_ERR_DEVICE; }
 }
 

@@ -298,16 +298,16 @@ def test_site_pileup_chrY_full_size_rows_and_oracle_windows():
 
 
 def test_bench_whole_genome_line_over_two_ranks(tmp_path):
-    """The harness the driver runs for N > 1 (`bench.py --gpus N` under torch.distributed.run), rehearsed with two ranks
-    on the box's one GPU (gloo for the collectives; nccl needs one device per rank) at 1/64 scale: one JSON line from
-    rank 0, strong scaling over the fixed 25-contig input, both ranks' bases adding up to it, the gathered summaries
-    checked against every rank's own first pass inside the run."""
+    """`bench.py --gpus 2` started plainly, with no launcher around it: the script starts its own two ranks (one process
+    per GPU under torch.distributed.run; here both on the box's one GPU, gloo for the collectives since nccl needs one
+    device per rank) at 1/64 scale: one JSON line from rank 0, strong scaling over the fixed 25-contig input, both
+    ranks' bases adding up to it, the gathered summaries checked against every rank's own first pass inside the run."""
     import json
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--wgs-scale", str(1.0 / 64), "--min-time", "0.05"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -321,3 +321,4 @@ def test_bench_whole_genome_line_over_two_ranks(tmp_path):
     assert sorted(sum(d["sharding"]["contigs_of_rank"], [])) == sorted(n for _, n, _ in genome)
     assert d["value"] > 0 and d["roofline"]["bound"] == "hbm" and 0 < d["roofline"]["frac"] < 1
     assert d["sharding"]["lpt_imbalance"] < 1.05
+    assert len(d["sharding"]["build_s"]) == 2 and d["sharding"]["host_threads_per_rank"] >= 2

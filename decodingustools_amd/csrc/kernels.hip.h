@@ -595,21 +595,28 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
         }
         // ---- (2) the window's pieces, streamed: entry {x, y}: x + 16 u = byte offset of unit u's qualities from qbase;
         //      y = start (11 bits) | end - 1 (11) | - | counter set (bit 29) | - | valid (bit 31).  A piece covers the
-        //      unit of its start and at most the next one. ----
+        //      unit of its start and at most the next one.  Lane t takes entries t, t + 256, ...: a wave's 64 entries are
+        //      consecutive pieces of (mostly) one read, their quality bytes ~1 KB of one stretch of memory. ----
         {
-            constexpr int E = 2;                                 // entries per lane and trip: four quality loads in flight
+#ifndef CL_RT_E
+#define CL_RT_E 2
+#endif
+            constexpr int E = CL_RT_E;                           // entries per lane and trip: 2 E quality loads in flight
             const uint2 *ent = a.runtab + wm.rlo;
             const uint32_t nent = CL_ABL(2u) ? 0u : wm.rn;
+            // (every load of the loop is unconditional -- an index past the end is clamped and its entry marked invalid --:
+            // behind a load in a conditional block hipcc waits for vmcnt(0))
             auto fetch = [&](uint32_t b, uint2 (&d)[E]) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     const uint32_t idx = b + (uint32_t)j * kBlock + tid;
-                    d[j] = make_uint2((uint32_t)kQualPad, 0u);   // a lane without an entry loads the window's first bytes
-                    if (idx < nent) d[j] = ent[idx];
+                    const bool in = idx < nent;
+                    d[j] = ent[in ? idx : nent - 1u];
+                    d[j].y = in ? d[j].y : 0u;
                 }
             };
             uint2 d[E], dn[E];
-            fetch(0u, d);
+            if (nent) fetch(0u, d);
             for (uint32_t b = 0; b < nent; b += kBlock * E) {     // block-uniform
                 fetch(b + kBlock * E, dn);                        // the next trip's entries are requested first
                 Q16 v[E][2];
@@ -618,8 +625,13 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
                 for (int j = 0; j < E; ++j) {
                     u0[j] = (d[j].y & 2047u) >> 4;
                     two[j] = (((d[j].y >> 11) & 2047u) >> 4) - u0[j];          // 0 or 1
-                    __builtin_memcpy(&v[j][0], qbase + (d[j].x + (u0[j] << 4)), 16);
-                    __builtin_memcpy(&v[j][1], qbase + (d[j].x + ((u0[j] + two[j]) << 4)), 16);
+                    if (CL_ABL(16u)) {                               // timing experiment: no quality bytes are loaded
+                        v[j][0].w[0] = d[j].x; v[j][0].w[1] = d[j].y; v[j][0].w[2] = d[j].x ^ d[j].y; v[j][0].w[3] = u0[j];
+                        v[j][1] = v[j][0];
+                    } else {
+                        __builtin_memcpy(&v[j][0], qbase + (d[j].x + (u0[j] << 4)), 16);
+                        __builtin_memcpy(&v[j][1], qbase + (d[j].x + ((u0[j] + two[j]) << 4)), 16);
+                    }
                 }
                 if (!CL_ABL(4u)) {
 #pragma unroll

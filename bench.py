@@ -372,12 +372,17 @@ def site_config(dev_id, opt, args, cache_dir):
             calls.append(time.perf_counter() - t0)
             kms_, nb = eng.site_pileup_stats()
             ms_all.append(kms_)
+        # the tile is resident now: another site list (here the same one) costs a run only
+        t0 = time.perf_counter()
+        hist2 = eng.site_run(20, sites)
+        rerun = time.perf_counter() - t0
     kms_ = min(ms_all)
     ach = nb / (kms_ * 1e-3) / 1e9 if kms_ > 0 else 0.0
     out = {
         "workload": "find-y-branch pileup path: chrY 40x synthetic, 200 000-site list, device kernel only",
         "contig_len": L, "reads": rec.n, "sites": int(sites.shape[0]), "sites_hit": int((hist.sum(1) > 0).sum()),
-        "kernel_ms": kms_, "call_s_incl_h2d": min(calls), "call_s_first": calls[0], "generated_in_s": round(gen, 1),
+        "kernel_ms": kms_, "call_s_incl_h2d": min(calls), "call_s_first": calls[0], "run_s_on_resident_tile": rerun,
+        "resident_rerun_equal": bool(np.array_equal(hist, hist2)), "generated_in_s": round(gen, 1),
         "roofline": {"bound": "hbm", "kernel": "k_site_pileup", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_launch": nb,
                      "note": "nominal: SURVEY 8d's byte count includes the 4-bit bases of every read; the kernel touches the bases at sites only"}}

@@ -117,6 +117,8 @@ SYMBOLS = [
     ("cl_debug_depths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("cl_site_pileup", C.c_int, [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(cl_site_tile),
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
+    ("cl_site_upload", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(cl_site_tile)]),
+    ("cl_site_run", C.c_int, [C.c_void_p, C.c_uint8, C.c_void_p, C.c_size_t, C.c_void_p]),
     ("cl_site_pileup_stats", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("dut_profiler_new", C.c_void_p, [C.c_char_p]),
     ("dut_profiler_free", None, [C.c_void_p]),

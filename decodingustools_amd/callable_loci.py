@@ -196,6 +196,24 @@ class Engine:
                                              _ptr(sites), sites.shape[0], _ptr(hist)))
         return hist
 
+    def _site_tile(self, rec: ContigRecords):
+        t = _lib.cl_site_tile()
+        t.n_reads = rec.n
+        t.pos = _ptr(rec.pos); t.mapq = _ptr(rec.mapq); t.cigar_off = _ptr(rec.cigar_off)
+        t.cigar = _ptr(rec.cigar); t.seq_off = _ptr(rec.seq_off); t.seq4 = _ptr(rec.seq4)
+        return t
+
+    def site_upload(self, contig_len, ref_len, rec: ContigRecords):
+        """The tile goes to HBM once and stays resident for any number of site_run calls."""
+        t = self._site_tile(rec)
+        self._check(self._lib.cl_site_upload(self._h, contig_len, ref_len, C.byref(t)))
+
+    def site_run(self, min_quality, sites):
+        sites = np.ascontiguousarray(sites, np.uint32)
+        hist = np.zeros((sites.shape[0], 16), np.uint32)
+        self._check(self._lib.cl_site_run(self._h, min_quality, _ptr(sites), sites.shape[0], _ptr(hist)))
+        return hist
+
     def site_pileup_stats(self):
         """(kernel milliseconds, algorithmic bytes) of the last site_pileup."""
         ms = C.c_double(); b = C.c_uint64()

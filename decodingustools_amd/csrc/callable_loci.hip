@@ -266,6 +266,15 @@ constexpr size_t kStagingSets = 2;
 static std::mutex g_staging_mu;
 static std::vector<std::unique_ptr<StagingSet>> g_staging;
 
+// config 5: the resident tile of the site pileup (cl_site_upload) and the buffers of a run
+struct SiteResident {
+    DevBuf<SiteRec> rec; DevBuf<uint8_t> seq; DevBuf<uint32_t> cig, p0, ix, hist, bk; DevBuf<unsigned long long> base;
+    uint64_t n = 0, ncig = 0, nbase = 0, ref_len = 0;
+    uint32_t contig_len = 0;
+    bool resident = false;
+    void release() { rec.release(); seq.release(); cig.release(); p0.release(); ix.release(); hist.release(); bk.release(); base.release(); resident = false; }
+};
+
 struct cl_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -359,6 +368,7 @@ struct cl_ctx {
     hipEvent_t site_ev[2] = {nullptr, nullptr};
     double site_ms = 0.0;
     uint64_t site_bytes = 0;
+    SiteResident site;
 };
 
 static void swap_staging(cl_ctx *c, StagingSet &o)
@@ -986,7 +996,7 @@ void cl_destroy(cl_ctx *c)
     c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_ck_x.release(); c->d_ck_y.release(); c->d_runtab.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_ck_x.release(); c->d_ck_y.release(); c->d_runtab.release(); c->site.release();
     for (int i = 0; i < 2; ++i) if (c->site_ev[i]) (void)hipEventDestroy(c->site_ev[i]);
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
@@ -1592,109 +1602,138 @@ cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low,
 }
 
 
-static cl_status cl_site_pileup_impl(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, uint64_t ref_len,
-                         const cl_site_tile *t, const uint32_t *sites, size_t n_sites, uint32_t *hist)
+// ---- config 5: the tile goes to HBM once (cl_site_upload: packed records built straight into the pinned buffers, the
+//      4-bit bases and the CIGAR words through the staging ring) and stays resident; any number of site lists can then be
+//      run over it (cl_site_run).  cl_site_pileup is the two in one call. ----
+static cl_status cl_site_upload_impl(cl_ctx *c, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *t)
 {
-    if (!c || !t || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
+    if (!c || !t) return CL_ERR_INVALID;
     HIP_TRY(c, hipSetDevice(c->device));
-    if (n_sites == 0) return CL_OK;
-    if (n_sites > 0x0FFFFFFFu) return fail(c, CL_ERR_RANGE, "too many sites");
+    drop_prefetch(c);                                        // the ring is needed below
+    SiteResident &S = c->site;
+    S.resident = false;
     const uint64_t n = t->n_reads;
     if (n > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "too many reads");
-    // sites sorted by 0-based position (vcf_pos - 1, caller.rs:94); vcf_pos 0 can never match
-    std::vector<uint32_t> order(n_sites);
-    for (size_t i = 0; i < n_sites; ++i) order[i] = (uint32_t)i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return sites[a] < sites[b]; });
-    std::vector<uint32_t> pos0, idx;
-    pos0.reserve(n_sites); idx.reserve(n_sites);
-    for (size_t i = 0; i < n_sites; ++i) {
-        const uint32_t s = sites[order[i]];
-        if (s == 0) continue;
-        pos0.push_back(s - 1); idx.push_back(order[i]);
-    }
-    memset(hist, 0, n_sites * 16 * sizeof(uint32_t));
-    if (n == 0 || pos0.empty()) return CL_OK;
-    for (uint64_t i = 0; i < n; ++i)
-        if (t->cigar_off[i + 1] < t->cigar_off[i] || t->seq_off[i + 1] < t->seq_off[i])
-            return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
-    const uint64_t ncig = t->cigar_off[n], nbase = t->seq_off[n];
-    // bucket index: first sorted site at or after every 256th position
-    const uint32_t n_buckets = (uint32_t)(((uint64_t)pos0.back() >> 8) + 2);
-    std::vector<uint32_t> bucket(n_buckets);
+    if (n && (!t->pos || !t->mapq || !t->cigar_off || !t->seq_off)) return fail(c, CL_ERR_INVALID, "null tile array");
+    StageTimer tmr;
     {
-        size_t j = 0;
-        for (uint32_t bk = 0; bk < n_buckets; ++bk) {
-            while (j < pos0.size() && pos0[j] < ((uint64_t)bk << 8)) ++j;
-            bucket[bk] = (uint32_t)j;
-        }
+        std::atomic<int> bad{0};
+        dut::parallel_for(n, 262144, [&](size_t i) { if (t->cigar_off[i + 1] < t->cigar_off[i] || t->seq_off[i + 1] < t->seq_off[i]) bad = 1; });
+        if (bad) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
     }
-    // one packed record per read (+ the sentinel with the totals) and the 64-bit base offset of every workgroup's reads
+    const uint64_t ncig = n ? t->cigar_off[n] : 0, nbase = n ? t->seq_off[n] : 0;
     const uint64_t n_blocks = (n + kBlock - 1) / kBlock;
-    std::unique_ptr<SiteRec[]> h_rec(new SiteRec[n + 1]);
-    std::unique_ptr<unsigned long long[]> h_base(new unsigned long long[n_blocks + 1]);
-    {
-        SiteRec *hr = h_rec.get();
-        unsigned long long *hb = h_base.get();
-        dut::parallel_for(n, 262144, [&](size_t i) {
-            const uint32_t nc = t->cigar_off[i + 1] - t->cigar_off[i];
-            const uint64_t sl = t->seq_off[i + 1] - t->seq_off[i];
-            SiteRec r;
-            r.pos = t->pos[i]; r.cigar_off = t->cigar_off[i]; r.seq_lo = (uint32_t)t->seq_off[i];
-            r.meta = (uint32_t)t->mapq[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<uint64_t>(sl, 0xFFFFull) << 16);
-            hr[i] = r;
-            if (i % kBlock == 0) hb[i / kBlock] = t->seq_off[i];
-        });
-        hr[n].pos = 0; hr[n].cigar_off = t->cigar_off[n]; hr[n].seq_lo = (uint32_t)t->seq_off[n]; hr[n].meta = 0;
-        hb[n_blocks] = t->seq_off[n];
-    }
     // a workgroup's reads must lie within 2^32 bases of its first one (256 reads: always, short of 16 M-base reads)
     for (uint64_t b = 0; b < n_blocks; ++b)
         if (t->seq_off[std::min<uint64_t>(n, (b + 1) * kBlock)] - t->seq_off[b * kBlock] > 0xFFFF0000ull)
             return fail(c, CL_ERR_RANGE, "reads too long for the site pileup");
-    DevBuf<SiteRec> d_rec; DevBuf<uint8_t> d_seq; DevBuf<uint32_t> d_cig, d_p0, d_ix, d_hist, d_bk;
-    DevBuf<unsigned long long> d_base;
-    cl_status rc = CL_OK;
-    auto cleanup = [&]() { d_rec.release(); d_seq.release(); d_cig.release(); d_p0.release(); d_ix.release(); d_hist.release();
-                           d_base.release(); d_bk.release(); };
-#define SITE_TRY(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { rc = fail(c, CL_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e__)); cleanup(); return rc; } } while (0)
-    // (plain synchronous copies: for large pageable blocks the runtime pins the caller's pages in place, which was measured
-    // faster here than staging them through the ring)
-#define SITE_RING(dst, src, bytes) do { if (bytes) SITE_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice)); } while (0)
-    SITE_TRY(d_rec.reserve(n + 1)); SITE_TRY(d_base.reserve(n_blocks + 1));
-    SITE_TRY(d_cig.reserve(ncig + 8)); SITE_TRY(d_seq.reserve((nbase + 1) / 2 + 1));
-    SITE_TRY(d_p0.reserve(pos0.size())); SITE_TRY(d_ix.reserve(pos0.size())); SITE_TRY(d_hist.reserve(n_sites * 16));
-    SITE_TRY(d_bk.reserve(n_buckets));
-    SITE_TRY(hipMemsetAsync(d_hist.p, 0, n_sites * 16 * 4, c->stream));
-    SITE_RING(d_rec.p, h_rec.get(), (n + 1) * sizeof(SiteRec));
-    SITE_RING(d_base.p, h_base.get(), (n_blocks + 1) * sizeof(unsigned long long));
-    SITE_RING(d_cig.p, t->cigar, ncig * 4);
-    SITE_RING(d_seq.p, t->seq4, (nbase + 1) / 2);
-    SITE_RING(d_p0.p, pos0.data(), pos0.size() * 4);
-    SITE_RING(d_ix.p, idx.data(), idx.size() * 4);
-    SITE_RING(d_bk.p, bucket.data(), (size_t)n_buckets * 4);
+    HIP_TRY(c, S.rec.reserve(n + 1)); HIP_TRY(c, S.base.reserve(n_blocks + 1));
+    HIP_TRY(c, S.cig.reserve(ncig + 8)); HIP_TRY(c, S.seq.reserve((nbase + 1) / 2 + 16));
+    tmr.lap("site upload: checks + device buffers");
+    cl_status rs = CL_OK;
+    // the bases: the bulk of the tile (0.5 byte per aligned base)
+    if (nbase && (rs = ring_copy(c, S.seq.p, t->seq4, (nbase + 1) / 2)) != CL_OK) return rs;
+    tmr.lap("site upload: bases");
+    // one packed record per read (+ the sentinel with the totals), built in the pinned buffers
+    {
+        const int32_t *hp = t->pos; const uint8_t *hm = t->mapq; const uint32_t *hc = t->cigar_off; const uint64_t *hs = t->seq_off;
+        rs = ring_start(c, reinterpret_cast<uint8_t *>(S.rec.p), (n + 1) * sizeof(SiteRec), [hp, hm, hc, hs, n](uint64_t off, uint64_t len, uint8_t *out) {
+            SiteRec *o = reinterpret_cast<SiteRec *>(out);
+            const size_t i0 = off / sizeof(SiteRec), i1 = (off + len) / sizeof(SiteRec);
+            for (size_t i = i0; i < i1; ++i) {
+                SiteRec r;
+                if (i < n) {
+                    const uint32_t nc = hc[i + 1] - hc[i];
+                    const uint64_t sl = hs[i + 1] - hs[i];
+                    r.pos = hp[i]; r.cigar_off = hc[i]; r.seq_lo = (uint32_t)hs[i];
+                    r.meta = (uint32_t)hm[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<uint64_t>(sl, 0xFFFFull) << 16);
+                } else { r.pos = 0; r.cigar_off = n ? hc[n] : 0u; r.seq_lo = n ? (uint32_t)hs[n] : 0u; r.meta = 0; }
+                o[i - i0] = r;
+            }
+        });
+        // ... beside it, the 64-bit base offset of every workgroup's first read
+        std::vector<unsigned long long> h_base(n_blocks + 1);
+        for (uint64_t b = 0; b < n_blocks; ++b) h_base[b] = t->seq_off[b * kBlock];
+        h_base[n_blocks] = nbase;
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+        HIP_TRY(c, hipMemcpyAsync(S.base.p, h_base.data(), (n_blocks + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (ncig && (rs = ring_copy(c, S.cig.p, t->cigar, ncig * 4)) != CL_OK) return rs;
+    tmr.lap("site upload: records + cigar");
+    S.n = n; S.ncig = ncig; S.nbase = nbase; S.contig_len = contig_len; S.ref_len = ref_len;
+    S.resident = true;
+    return CL_OK;
+}
+
+// the site list as the kernel wants it: sorted by 0-based position (vcf_pos - 1, caller.rs:94) with the original
+// indices, vcf_pos 0 left out (it can never match), and the first sorted site at or after every 256th position
+struct SitePrep { std::vector<uint32_t> pos0, idx, bucket; uint32_t n_buckets = 0; };
+static void site_prepare(const uint32_t *sites, size_t n_sites, SitePrep &P)
+{
+    std::vector<unsigned long long> key(n_sites);
+    for (size_t i = 0; i < n_sites; ++i) key[i] = ((unsigned long long)sites[i] << 32) | (unsigned long long)i;
+    std::sort(key.begin(), key.end());
+    P.pos0.reserve(n_sites); P.idx.reserve(n_sites);
+    for (size_t i = 0; i < n_sites; ++i) {
+        const uint32_t s = (uint32_t)(key[i] >> 32);
+        if (s == 0) continue;
+        P.pos0.push_back(s - 1); P.idx.push_back((uint32_t)key[i]);
+    }
+    if (P.pos0.empty()) return;
+    P.n_buckets = (uint32_t)(((uint64_t)P.pos0.back() >> 8) + 2);
+    P.bucket.resize(P.n_buckets);
+    size_t j = 0;
+    for (uint32_t bk = 0; bk < P.n_buckets; ++bk) {
+        while (j < P.pos0.size() && P.pos0[j] < ((uint64_t)bk << 8)) ++j;
+        P.bucket[bk] = (uint32_t)j;
+    }
+}
+
+static cl_status cl_site_run_impl(cl_ctx *c, uint8_t min_quality, const uint32_t *sites, size_t n_sites, uint32_t *hist, const SitePrep *ready)
+{
+    if (!c || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
+    SiteResident &S = c->site;
+    if (!S.resident) return fail(c, CL_ERR_INVALID, "cl_site_run without cl_site_upload");
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (n_sites == 0) return CL_OK;
+    if (n_sites > 0x0FFFFFFFu) return fail(c, CL_ERR_RANGE, "too many sites");
+    StageTimer tmr;
+    SitePrep mine;
+    if (!ready) { site_prepare(sites, n_sites, mine); ready = &mine; }
+    const std::vector<uint32_t> &pos0 = ready->pos0, &idx = ready->idx, &bucket = ready->bucket;
+    const uint32_t n_buckets = ready->n_buckets;
+    memset(hist, 0, n_sites * 16 * sizeof(uint32_t));
+    if (S.n == 0 || pos0.empty()) return CL_OK;
+    tmr.lap("site run: sort + buckets");
+    HIP_TRY(c, S.p0.reserve(pos0.size())); HIP_TRY(c, S.ix.reserve(pos0.size())); HIP_TRY(c, S.hist.reserve(n_sites * 16));
+    HIP_TRY(c, S.bk.reserve(n_buckets));
+    HIP_TRY(c, hipMemsetAsync(S.hist.p, 0, n_sites * 16 * 4, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S.p0.p, pos0.data(), pos0.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S.ix.p, idx.data(), idx.size() * 4, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(S.bk.p, bucket.data(), (size_t)n_buckets * 4, hipMemcpyHostToDevice, c->stream));
     SiteArgs A;
-    A.rec = d_rec.p; A.seq_base = d_base.p; A.cigar = d_cig.p; A.seq4 = d_seq.p; A.n = (uint32_t)n;
-    A.min_quality = min_quality; A.contig_len = contig_len; A.ref_len = ref_len;
-    A.sorted_pos0 = d_p0.p; A.sorted_idx = d_ix.p; A.bucket = d_bk.p; A.n_buckets = n_buckets; A.n_sites = (uint32_t)pos0.size();
-    A.hist = d_hist.p;
-    if (!c->site_ev[0]) { SITE_TRY(hipEventCreate(&c->site_ev[0])); SITE_TRY(hipEventCreate(&c->site_ev[1])); }
-    SITE_TRY(hipEventRecord(c->site_ev[0], c->stream));
-    hipLaunchKernelGGL(k_site_pileup, dim3((uint32_t)n_blocks), dim3(kBlock), 0, c->stream, A);
-    SITE_TRY(hipGetLastError());
-    SITE_TRY(hipEventRecord(c->site_ev[1], c->stream));
-    SITE_TRY(hipMemcpyAsync(hist, d_hist.p, n_sites * 16 * 4, hipMemcpyDeviceToHost, c->stream));
-    SITE_TRY(hipStreamSynchronize(c->stream));
+    A.rec = S.rec.p; A.seq_base = S.base.p; A.cigar = S.cig.p; A.seq4 = S.seq.p; A.n = (uint32_t)S.n;
+    A.min_quality = min_quality; A.contig_len = S.contig_len; A.ref_len = S.ref_len;
+    A.sorted_pos0 = S.p0.p; A.sorted_idx = S.ix.p; A.bucket = S.bk.p; A.n_buckets = n_buckets; A.n_sites = (uint32_t)pos0.size();
+    A.hist = S.hist.p;
+    if (!c->site_ev[0]) { HIP_TRY(c, hipEventCreate(&c->site_ev[0])); HIP_TRY(c, hipEventCreate(&c->site_ev[1])); }
+    HIP_TRY(c, hipEventRecord(c->site_ev[0], c->stream));
+    hipLaunchKernelGGL(k_site_pileup, dim3((uint32_t)((S.n + kBlock - 1) / kBlock)), dim3(kBlock), 0, c->stream, A);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipEventRecord(c->site_ev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(hist, S.hist.p, n_sites * 16 * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     {
         float t = 0.f;
-        SITE_TRY(hipEventElapsedTime(&t, c->site_ev[0], c->site_ev[1]));
+        HIP_TRY(c, hipEventElapsedTime(&t, c->site_ev[0], c->site_ev[1]));
         c->site_ms = t;
         // 4-bit bases + per-read pos/mapq/offsets + CIGAR words read, the sites' positions /
         // indices read and their 16 counters written
-        c->site_bytes = (nbase + 1) / 2 + n * sizeof(SiteRec) + ncig * 4 + (uint64_t)pos0.size() * 8 + (uint64_t)n_sites * 64;
+        c->site_bytes = (S.nbase + 1) / 2 + S.n * sizeof(SiteRec) + S.ncig * 4 + (uint64_t)pos0.size() * 8 + (uint64_t)n_sites * 64;
     }
-#undef SITE_RING
-#undef SITE_TRY
-    cleanup();
+    tmr.lap("site run: kernel + histogram back");
     return CL_OK;
 }
 
@@ -1706,11 +1745,38 @@ cl_status cl_site_pileup_stats(cl_ctx *c, double *kernel_ms, uint64_t *bytes)
     return CL_OK;
 }
 
+cl_status cl_site_upload(cl_ctx *c, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *t)
+{
+    // no exception leaves the library through the C ABI
+    try { return cl_site_upload_impl(c, contig_len, ref_len, t); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
+cl_status cl_site_run(cl_ctx *c, uint8_t min_quality, const uint32_t *sites, size_t n_sites, uint32_t *hist)
+{
+    try { return cl_site_run_impl(c, min_quality, sites, n_sites, hist, nullptr); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
 cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, uint64_t ref_len,
                          const cl_site_tile *t, const uint32_t *sites, size_t n_sites, uint32_t *hist)
 {
-    // no exception leaves the library through the C ABI
-    try { return cl_site_pileup_impl(c, min_quality, contig_len, ref_len, t, sites, n_sites, hist); }
+    if (!c || !t || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
+    if (n_sites == 0) return CL_OK;
+    try {
+        if (n_sites > 0x0FFFFFFFu) return fail(c, CL_ERR_RANGE, "too many sites");
+        // the site list is sorted on a thread of its own while the tile travels
+        SitePrep prep;
+        bool prep_ok = false;
+        dut::Thread th = dut::spawn_or_run([&]() { site_prepare(sites, n_sites, prep); prep_ok = true; });
+        cl_status s = cl_site_upload_impl(c, contig_len, ref_len, t);
+        if (th.joinable()) th.join();
+        if (s != CL_OK) return s;
+        if (!prep_ok) return fail(c, CL_ERR_NOMEM, "out of memory");
+        return cl_site_run_impl(c, min_quality, sites, n_sites, hist, &prep);
+    }
     catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
     catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
 }

@@ -193,6 +193,12 @@ cl_status cl_site_pileup(cl_ctx *ctx, uint8_t min_quality, uint32_t contig_len,
                          uint64_t ref_len, const cl_site_tile *tile,
                          const uint32_t *sites, size_t n_sites, uint32_t *hist);
 
+/* The same in two steps: the tile goes to HBM once (through the pinned staging ring) and stays resident -- until the
+ * next cl_site_upload or cl_destroy -- and any number of site lists are run over it (find-y-branch --show-snps asks the
+ * same reads about several lists; caller.rs:8-59 fetches the region again each time).  cl_site_pileup = both. */
+cl_status cl_site_upload(cl_ctx *ctx, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *tile);
+cl_status cl_site_run(cl_ctx *ctx, uint8_t min_quality, const uint32_t *sites, size_t n_sites, uint32_t *hist);
+
 /* Measurement: duration of the last cl_site_pileup's kernel (HIP events on the context's stream, milliseconds)
  * and its algorithmic bytes (4-bit bases, per-read fields and CIGAR words read, the sites'
  * counters written). */

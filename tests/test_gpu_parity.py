@@ -1046,3 +1046,30 @@ def test_run_table_with_truncated_qualities_and_long_runs(tmp_path):
         pytest.skip("shape does not select the run-table form")
     ref = synth.make_reference(L, 92)
     compare([("chrT", 1, L, ref, rec)], dict(min_depth=1), tmp_path, "runtabT")
+
+
+def test_site_tile_stays_resident_for_several_site_lists():
+    """cl_site_upload once, cl_site_run with different lists, qualities and an empty list; a second upload replaces the
+    tile; cl_site_run before any upload is an error."""
+    from decodingustools_amd import EngineError
+    L = 300_000
+    ref = synth.make_reference(L, 15)
+    rec = synth.short_read_contig(L, 35, synth.seed_for(5, 7), with_seq=True, ref=ref)
+    rng = np.random.default_rng(19)
+    lists = [rng.choice(np.arange(1, L + 20), size=n, replace=False).astype(np.uint32) for n in (4000, 1, 900)]
+    lists.append(np.array([0, 7, 7, L, L + 5, 2**31], np.uint32))            # vcf_pos 0, a duplicate, the end, beyond it
+    with Engine(CallableOptions(), 0) as eng:
+        with pytest.raises(EngineError):
+            eng.site_run(20, lists[0])
+        eng.site_upload(L, ref.shape[0], rec)
+        for mq, sites in ((20, lists[0]), (0, lists[1]), (61, lists[2]), (10, lists[3]), (20, lists[0])):
+            exp = oracle.site_pileup(10, mq, L, ref, rec, sites)
+            assert np.array_equal(eng.site_run(mq, sites), exp["hist"]), (mq, sites.shape)
+        assert eng.site_run(20, np.zeros(0, np.uint32)).shape == (0, 16)
+        sub = rec.slice(0, rec.n // 3)
+        eng.site_upload(L, ref.shape[0], sub)
+        exp = oracle.site_pileup(10, 20, L, ref, sub, lists[0])
+        assert np.array_equal(eng.site_run(20, lists[0]), exp["hist"])
+        # the one-call form leaves its tile resident too
+        assert np.array_equal(eng.site_pileup(20, L, ref.shape[0], rec, lists[2]), oracle.site_pileup(10, 20, L, ref, rec, lists[2])["hist"])
+        assert np.array_equal(eng.site_run(20, lists[0]), oracle.site_pileup(10, 20, L, ref, rec, lists[0])["hist"])

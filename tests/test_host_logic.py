@@ -275,3 +275,28 @@ def test_admission_fast_path_threshold_matches_the_oracle(max_depth):
     assert np.array_equal(acc_h, acc_o & (rl > 0))
     if max_depth <= 30:
         assert (acc_o & (rl > 0)).sum() < ((rec.flag & 4) == 0).sum()      # the cap did drop reads here
+
+
+@pytest.mark.parametrize("case", [c for c in __import__("helpers").load_kats()["cases"] if c["name"].startswith(("KAT-7", "KAT-9", "KAT-10", "KAT-11"))],
+                         ids=lambda c: c["name"].split()[0])
+def test_admission_rule_on_the_cap_and_zero_span_kats(case):
+    """dut_admit_reads on the hand-derived cap / zero-span cases: the accepted set is what the per-position counters of
+    the fixture imply (the names of the reads that appear in columns), and equals the oracle engine's."""
+    from helpers import contig_inputs, load_kats
+    K = load_kats()
+    opt_d = {**K["default_options"], **case.get("options", {})}
+    c = case["contigs"][0]
+    rec, _ = contig_inputs(c)
+    acc_h, n_names = admit_reads(CallableOptions(max_depth=opt_d["max_depth"]), 0, c["len"], rec)
+    acc_o = oracle.accepted_reads(make_options(opt_d), 0, c["len"], rec)
+    ops = rec.cigar & 15
+    lens = (rec.cigar >> 4).astype(np.int64)
+    cs = np.concatenate([[0], np.cumsum(np.where(np.isin(ops, [0, 2, 3, 7, 8]), lens, 0))])
+    rl = cs[rec.cigar_off[1:].astype(np.int64)] - cs[rec.cigar_off[:-1].astype(np.int64)]
+    assert np.array_equal(acc_h, acc_o & (rl > 0))
+    assert n_names == case["stats"][c["name"]]["n_reads"]
+    # the accepted reads' spans add up to the fixture's raw depth
+    raw = np.zeros(len(case["per_position"][c["name"]]["raw"]), np.int64)
+    for i in np.flatnonzero(acc_h):
+        raw[rec.pos[i]:rec.pos[i] + rl[i]] += 1
+    assert raw.tolist() == case["per_position"][c["name"]]["raw"]

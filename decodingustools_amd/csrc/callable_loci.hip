@@ -545,8 +545,7 @@ cl_status harvest_events(cl_ctx *c)
 }
 
 // which form of k_pileup a resident contig gets: by its shape, decided once at upload and kept in the context
-// (kernels.hip.h: LONG = 0 short reads, 1 long match runs, 2 the run table; 4 = the block-parallel CIGAR scan that
-// the run table replaced, reachable in tuning builds only)
+// (kernels.hip.h: LONG = 0 short reads, 1 long match runs, 2 the run table)
 int pick_form(const cl_ctx *c)
 {
     int form = 0;
@@ -557,7 +556,7 @@ int pick_form(const cl_ctx *c)
         form = c->n_qual < 56ull * c->n_cigar ? 2 : 1;
     }
 #ifdef CL_TUNING
-    if (const char *fl = getenv("CL_FORCE_LONG")) form = atoi(fl);
+    if (const char *fl = getenv("CL_FORCE_LONG")) { const int f = atoi(fl); if (f == 0 || f == 1 || f == 2) form = f; }
 #endif
     return form;
 }
@@ -873,11 +872,7 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     // (the ORF template parameter once selected a shorter threshold test for min_base_quality <= 128; one form
     // serves every threshold now and only ORF = true is instantiated)
 #define CL_LAUNCH(DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
-#ifdef CL_TUNING
-#define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else if (c->form == 4) CL_LAUNCH(DEEP_, 4); else if (c->form == 1) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
-#else
 #define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else if (c->form == 1) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
-#endif
     // the 32-bit counter variant is used only when the window bounds asked for it (kNeedDeep)
     if (!c->deep) CL_LAUNCH_L(false); else CL_LAUNCH_L(true);
 #undef CL_LAUNCH_L
@@ -1304,7 +1299,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // forms read the arrays as pushed, and every read's end.
     // The run-table form reads neither CIGARs nor offsets: pos, mapq and end of the windows' candidates, and the table
     // that the walk in size_for_extent() builds from the staged CIGARs.
-    const bool need_soa = form == 1 || form == 4, need_cigar = form != 2;
+    const bool need_soa = form == 1, need_cigar = form != 2;
     HIP_TRY(c, c->d_end.reserve(n + 1));
     if (need_cigar) {
         HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));      // four words are loaded at a read's first op

@@ -248,13 +248,10 @@ struct PileupArgs {
 // Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave): a wave's list holds every fourth
 // read, and consecutive candidates alternate between the two 8-bit counter sets.
 //
-// LONG = 1 or 4 (contigs with >= 8 CIGAR operations per read on average): the lane-serial CIGAR walk is
-// replaced by an operation-parallel one -- live reads are compacted; LONG = 1: a wave takes 64 operations
-// of a read at a time, two DPP scans give every operation its reference / query start, each lane consumes
-// its own M/=/X run (runs longer than 64 bases go through the list and the quad loop); LONG = 4 (operations
-// average < 56 bases): the (read, 64-operation block) pairs that can touch the window form one flat list,
-// a wave trip takes four of them, one per row of 16 lanes, four operations per lane, starting from the
-// blocks' checkpoints.
+// LONG = 1 (contigs with >= 8 CIGAR operations per read on average and long match runs, HiFi-like): the lane-serial
+// CIGAR walk is replaced by an operation-parallel one -- live reads are compacted, a wave takes 64 operations of a
+// read at a time, two DPP scans give every operation its reference / query start, each lane consumes its own M/=/X
+// run (runs longer than 64 bases go through the list and the quad loop).
 //
 // LONG = 2 (the run-table form; what a contig with short match runs gets): no CIGAR is decoded on the device at
 // all.  The host's walk over the CIGARs at upload leaves, per window, a flat table of the M/=/X pieces of its reads --
@@ -365,7 +362,7 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 #endif
 
 template <int T, bool DEBUG, bool ORF, bool DEEP, int LONG>
-__global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1 || LONG == 4) ? 4 : CL_MINWAVES)) void k_pileup(PileupArgs a)
+__global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
@@ -392,15 +389,8 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
     // hipcc turns them into a scalar loop over the active lanes.)
     __shared__ unsigned long long s_wtot[kWaves][12];          // [10], [11]: sums of the reads the window owns (LONG = 0)
     // LONG: the live reads of a pass, two entries each: {candidate number, op index, x, y}, {op end, quality offset, quality length, -}
-    __shared__ __attribute__((aligned(16))) uint4 s_live[(LONG == 1 || LONG == 4) ? 2 * kBlock : 1];
+    __shared__ __attribute__((aligned(16))) uint4 s_live[LONG == 1 ? 2 * kBlock : 1];
     __shared__ uint32_t s_nlive;
-    // LONG = 4: first block number of every live read of the pass (+ the total at [n])
-    __shared__ uint32_t s_blk[LONG == 4 ? kBlock + 1 : 1];
-    // LONG = 4: per-wave unit lists, entries {quality offset of the run's window position 0 (+ 16 u = the unit's bytes),
-    // run start (11 bits) | run end - 1 (11) | unit index u (7) | counter set (1) | - | valid (1)}
-    constexpr int kUCap = LONG == 4 ? 352 : 1;     // entries per wave
-    constexpr int kUFlush = 128;                   // a trip leaves fewer than this many entries waiting
-    __shared__ __attribute__((aligned(8))) uint2 s_ul[LONG == 4 ? kWaves : 1][kUCap];
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
     // each XCD one contiguous range of windows so neighbouring windows share its L2.
@@ -530,38 +520,6 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
         else if (mode8) { if (a.upl == 2u) consume(std::integral_constant<int, 0>{}, I2{}, n_use); else consume(std::integral_constant<int, 0>{}, I3{}, n_use); }
         else consume(std::integral_constant<int, 1>{}, I3{}, n_use);
     };
-    // LONG = 4: the wave's unit list, one entry per lane and four quality loads in flight per lane
-    uint2 *ul = s_ul[LONG == 4 ? wv : 0];
-    uint32_t n_ul = 0;
-    auto consume_units = [&](uint32_t n) {
-        constexpr int UL = 4;
-        if (CL_ABL(4u)) return;                 // timing experiments: units located and listed, nothing applied
-        for (uint32_t b0 = 0; b0 < n; b0 += 64u * UL) {
-            uint2 d[UL];
-            Q16 v[UL];
-#pragma unroll
-            for (int j = 0; j < UL; ++j) {
-                const uint32_t idx = b0 + lane + 64u * (uint32_t)j;
-                d[j] = make_uint2((uint32_t)kQualPad, 0u);                   // a lane without an entry loads the window's first bytes
-                if (idx < n) d[j] = ul[idx];
-                __builtin_memcpy(&v[j], qbase + (d[j].x + (((d[j].y >> 22) & 127u) << 4)), 16);
-            }
-#pragma unroll
-            for (int j = 0; j < UL; ++j) {
-                if (d[j].y >> 31) {
-                    const uint32_t u = (d[j].y >> 22) & 127u, srel = d[j].y & 2047u, trel = ((d[j].y >> 11) & 2047u) + 1u;
-                    const uint32_t ps = u << 4;
-                    const uint32_t vs = srel > ps ? srel - ps : 0u;
-                    const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
-                    const uint4 ms = s_mstart[vs], me = s_mend[ve];
-                    const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
-                    if (DEEP) sq32 += apply_unit32<ORF>(v[j], vm, u, s_qcw, a.o);
-                    else if (mode8) sq32 += apply_unit8<ORF>(v[j], vm, u, ((d[j].y >> 29) & 1u) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                    else sq32 += apply_unit16<ORF>(v[j], vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                }
-            }
-        }
-    };
     if constexpr (LONG == 2) {
         // ---- run-table form.  (1) the window's candidates: +-1 at the clipped span ends, and the separable sums of the
         //      reads that start here (contig_profiler.rs:74) ----
@@ -666,7 +624,6 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
         __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
         bool live = false;
         uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
-        uint32_t nblk = 0, lim0 = 0, k0r = 0;        // LONG = 4
         unsigned long long own_len = 0, own_mq = 0;  // separable sums of the reads this window owns (this pass)
         if (v < n_cand) {
             uint32_t e, mq;
@@ -685,7 +642,6 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
                     k1 = nx.y; qlen = nx.z - rr.z;
                 }
                 qrel = rr.z - (uint32_t)qwin;
-                k0r = k;
                 const uint32_t n = k1 - k;
                 if (n <= kLongOps) {
                     Q16 c4;                                      // the first four words (the array is padded)
@@ -732,7 +688,6 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
                     own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
                 }
                 k = a.R.cigar_off[r];
-                k0r = k;
                 k1 = a.R.cigar_off[r + 1];
                 const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
                 qrel = (uint32_t)(q0 - qwin);
@@ -767,24 +722,6 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
                 }
             }
             if (!LONG && live && fetch_cw) cw = a.R.cigar[k];    // invariant: cw == cigar[k] while live
-            if constexpr (LONG == 4) {
-                // blocks of the read that can touch the window: the one the walk starts in (it ends at the next
-                // multiple of 64 in the contig's operation numbering, where the next checkpoint sits), then one
-                // per checkpoint in front of the window's end
-                nblk = 1u; lim0 = k1;
-                if (live && k1 - k0r > kLongOps) {
-                    const uint32_t jn = (k >> 6) + 1u, jmax = (k1 - 1u) >> 6;
-                    lim0 = (jn << 6) < k1 ? (jn << 6) : k1;
-                    if (jn <= jmax) {
-                        uint32_t lo_j = jn, hi_j = jmax + 1u;           // first j in [jn, jmax] with ck_x[j] >= Wend (jmax + 1: none)
-                        while (lo_j < hi_j) {
-                            const uint32_t mid = lo_j + ((hi_j - lo_j) >> 1);
-                            if (a.ck_x[mid] < Wend) lo_j = mid + 1u; else hi_j = mid;
-                        }
-                        nblk += lo_j - jn;
-                    }
-                }
-            }
         }
         win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq);
         if constexpr (LONG) {
@@ -802,159 +739,12 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
                 wb = __shfl(wb, 0, 64);
                 if (live) {
                     const uint32_t idx = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    if constexpr (LONG == 4) {
-                        s_live[2u * idx] = make_uint4(k, x, y, nblk | ((v & 1u) << 31));
-                        s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, lim0);
-                    } else {
-                        s_live[2u * idx] = make_uint4(v, k, x, y);
-                        s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
-                    }
+                    s_live[2u * idx] = make_uint4(v, k, x, y);
+                    s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
                 }
             }
             __syncthreads();
             const uint32_t nl = s_nlive;
-            if constexpr (LONG == 4) {
-                // ---- short runs (an indel every few bases): blocks of <= 64 operations are independent once the
-                //      checkpoints give their reference / query start, so the pass's work is the flat list of
-                //      (read, block) pairs that can touch the window.  A wave trip takes four blocks, one per row of
-                //      16 lanes, four operations per lane (one 16-byte load): the blocks of one trip may belong to
-                //      different reads, every trip is full, nothing is carried from trip to trip, and the next
-                //      trip's operations and checkpoints are requested before this one is consumed. ----
-                {   // exclusive prefix of the block counts over the live reads
-                    uint32_t n = 0;
-                    if (tid < nl) n = s_live[2u * tid].w & 0x7FFFFFFFu;
-                    const uint32_t inc = dpp_incl_scan_u32(n);
-                    if (lane == 63) s_wraw[wv] = inc;
-                    __syncthreads();
-                    uint32_t off = 0;
-                    for (uint32_t i = 0; i < wv; ++i) off += s_wraw[i];
-                    if (tid < nl) s_blk[tid] = off + inc - n;
-                    if (tid == kBlock - 1) s_blk[nl] = off + inc;
-                    __syncthreads();
-                }
-                const uint32_t nb = s_blk[nl];
-                const uint32_t g = lane >> 4, li = lane & 15u;
-                uint32_t ri = 0;                                      // the row's position in the read list (monotone)
-                struct Blk { uint32_t i, base_k, lim, d; };
-                auto locate = [&](uint32_t b, Blk &o) {               // b < nb
-                    while (ri + 1u < nl && s_blk[ri + 1u] <= b) ++ri;
-                    const uint4 A = s_live[2u * ri], B = s_live[2u * ri + 1u];
-                    o.i = ri; o.d = b - s_blk[ri];
-                    o.base_k = o.d ? (((A.x >> 6) + o.d) << 6) : A.x;
-                    o.lim = o.d ? ((o.base_k + 64u) < B.x ? (o.base_k + 64u) : B.x) : B.w;
-                };
-                auto request = [&](const Blk &o, bool on, Q16 &cw4, uint32_t &cx, uint32_t &cy) {
-                    const uint32_t kl = o.base_k + 4u * li;
-                    cw4.w[0] = 5u; cw4.w[1] = 5u; cw4.w[2] = 5u; cw4.w[3] = 5u;      // beyond the block: H, advances nothing
-                    cx = 0u; cy = 0u;
-                    if (on && kl < o.lim) __builtin_memcpy(&cw4, a.R.cigar + kl, 16);   // at most 12 bytes past the read's words
-                    if (on && o.d) { cx = a.ck_x[o.base_k >> 6]; cy = a.ck_y[o.base_k >> 6]; }
-                };
-                Blk cur, nxt;
-                cur.i = 0; cur.base_k = 0; cur.lim = 0; cur.d = 0; nxt = cur;
-                Q16 cw_c, cw_n;
-                uint32_t cx_c = 0, cy_c = 0, cx_n = 0, cy_n = 0;
-                uint32_t tb = 4u * wv;                                // first block of the wave's current trip
-                bool on = tb + g < nb;
-                if (on) locate(tb + g, cur);
-                request(cur, on, cw_c, cx_c, cy_c);
-                while (tb < nb && !(CL_ABL(8u))) {               // wave-uniform (bit 8: timing experiment, no trips)
-                    const uint32_t tbn = tb + 4u * (uint32_t)kWaves;
-                    const bool on_n = tbn + g < nb;
-                    if (on_n) locate(tbn + g, nxt);
-                    request(nxt, on_n, cw_n, cx_n, cy_n);
-                    // ---- this trip ----
-                    const uint4 A = s_live[2u * cur.i], B = s_live[2u * cur.i + 1u];
-                    const uint32_t rqrel = B.y, rqlen = B.z, rset = (A.w >> 31) << 30;
-                    const uint32_t kl = cur.base_k + 4u * li;
-                    uint32_t cwl[4], ax[4], ay[4], tx = 0, ty = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) {
-                        cwl[j] = (on && (kl + j) < cur.lim) ? cw_c.w[j] : 5u;
-                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
-                        ax[j] = ((0x18Du >> op) & 1u) ? l : 0u;
-                        ay[j] = ((0x193u >> op) & 1u) ? l : 0u;
-                        tx += ax[j]; ty += ay[j];
-                    }
-                    const uint32_t ix = dpp_row_incl_scan_u32(tx), iy = dpp_row_incl_scan_u32(ty);
-                    uint32_t xs = (cur.d ? cx_c : A.y) + (ix - tx), ys = (cur.d ? cy_c : A.z) + (iy - ty);
-                    // Every M/=/X run of the trip, clipped to the window, becomes unit entries -- (run, 16 reference
-                    // positions) pairs -- in the wave's unit list; the list is then consumed one entry per lane, four
-                    // quality loads in flight: every lane busy whatever the runs' lengths, one load latency per trip,
-                    // no run-length dependent control flow.  Runs longer than 64 bases (rare in this shape) go
-                    // through the segment list and the quad loop as before.
-                    uint32_t e_qb[4], e_st[4], nu[4], nl = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < 4u; ++j) {
-                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
-                        const bool ism = ((0x181u >> op) & 1u) != 0u;
-                        const uint32_t xe = xs + ax[j];
-                        const uint32_t sp = xs > W ? xs : W;
-                        const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
-                        uint32_t tp = xe < Wend ? xe : Wend;
-                        tp = (xs + lq) < tp ? (xs + lq) : tp;
-                        const bool valid = ism && sp < tp && !(CL_ABL(1u));
-                        const uint32_t sr = sp - W, tr = tp - W;
-                        const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
-                        const bool big = valid && (tr - sr) > 64u;
-                        xs = xe; ys += ay[j];
-                        e_qb[j] = q + (uint32_t)kQualPad - sr;        // + 16 u = the unit's byte offset from qbase
-                        e_st[j] = sr | ((tr - 1u) << 11) | (rset >> 1);       // rset = set << 30 -> bit 29
-                        nu[j] = (valid && !big) ? (((tr - 1u) >> 4) - (sr >> 4) + 1u) : 0u;
-                        nl += nu[j];
-                        const unsigned long long bm = __ballot(big);
-                        if (bm) {                                    // wave-uniform: long runs go through the list
-                            if (big) {
-                                const uint32_t idx = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                                list[idx] = make_uint2(q, sr | ((tr - sr - 1u) << 16) | rset | 0x80000000u);
-                            }
-                            const uint32_t n_list = n_keep + (uint32_t)__popcll(bm);
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            const uint32_t n_full = n_list & ~15u;
-                            if (n_full) consume_list(n_full);
-                            n_keep = n_list - n_full;
-                            uint2 carry = make_uint2(0u, 0u);
-                            if (n_full && lane < n_keep) carry = list[n_full + lane];
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            if (n_full && lane < n_keep) list[lane] = carry;
-                        }
-                    }
-                    {   // emission: lane l's entries sit at wave index [base, base + nl); a trip that does not fit what is
-                        // left of the list goes in pieces, the list being consumed in between (rare)
-                        const uint32_t inc = dpp_incl_scan_u32(nl);
-                        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
-                        const uint32_t base = inc - nl, mx = dpp_wave_max_u32(nl);
-                        uint32_t lo_g = 0;
-                        while (lo_g < tot) {                              // wave-uniform
-                            if (n_ul == (uint32_t)kUCap) { consume_units(n_ul); n_ul = 0; }
-                            const uint32_t room = (uint32_t)kUCap - n_ul;
-                            const uint32_t hi_g = tot < lo_g + room ? tot : lo_g + room;
-                            for (uint32_t i = 0; i < mx; ++i) {
-                                const uint32_t g = base + i;
-                                if (i < nl && g >= lo_g && g < hi_g) {
-                                    uint32_t t = i, qb = e_qb[0], st = e_st[0];
-                                    if (t >= nu[0]) { t -= nu[0]; qb = e_qb[1]; st = e_st[1];
-                                        if (t >= nu[1]) { t -= nu[1]; qb = e_qb[2]; st = e_st[2];
-                                            if (t >= nu[2]) { t -= nu[2]; qb = e_qb[3]; st = e_st[3]; } } }
-                                    ul[n_ul + (g - lo_g)] = make_uint2(qb, st | ((((st & 2047u) >> 4) + t) << 22) | 0x80000000u);
-                                }
-                            }
-                            n_ul += hi_g - lo_g;
-                            lo_g = hi_g;
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        }
-                        if (n_ul >= (uint32_t)kUFlush) { consume_units(n_ul); n_ul = 0; }
-                    }
-                    cur = nxt; on = on_n; cw_c = cw_n; cx_c = cx_n; cy_c = cy_n;
-                    tb = tbn;
-                }
-            } else
             for (uint32_t it = wv; it < nl; it += (uint32_t)kWaves) {
                 const uint4 A = s_live[2u * it], B = s_live[2u * it + 1u];
                 uint32_t rk = A.y, rx = A.z, ry = A.w;
@@ -1168,9 +958,6 @@ __global__ __launch_bounds__(kBlock, DEEP && LONG == 4 ? 3 : ((DEEP || LONG == 1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         consume_list(n_keep);
         sumq += sq32; sq32 = 0;
-    }
-    if constexpr (LONG == 4) {                      // ... and the unit entries still listed
-        if (n_ul) { consume_units(n_ul); n_ul = 0; sumq += sq32; sq32 = 0; }
     }
     __syncthreads();
 

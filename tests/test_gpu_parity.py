@@ -1073,3 +1073,48 @@ def test_site_tile_stays_resident_for_several_site_lists():
         # the one-call form leaves its tile resident too
         assert np.array_equal(eng.site_pileup(20, L, ref.shape[0], rec, lists[2]), oracle.site_pileup(10, 20, L, ref, rec, lists[2])["hist"])
         assert np.array_equal(eng.site_run(20, lists[0]), oracle.site_pileup(10, 20, L, ref, rec, lists[0])["hist"])
+
+
+def test_an_error_behind_a_quality_prefetch_leaves_nothing_in_flight(tmp_path):
+    """a tile with more than 4 MiB of qualities that turns out to be unsorted -- the host driver has
+    started the quality prefetch by then.  The driver abandons the contig (cl_contig_abort: the copiers are joined, the
+    staging ring is free), the context can be destroyed or reused at once, and another context of the device is not
+    blocked by the abandoned transfer."""
+    from decodingustools_amd import EngineError
+    L = 400_000
+    rec = synth.short_read_contig(L, 120, synth.seed_for(2, 5))
+    assert rec.qual.shape[0] > (4 << 20)
+    ref = synth.make_reference(L, 3)
+    bad = ContigRecords(pos=rec.pos.copy(), flag=rec.flag, mapq=rec.mapq, cigar_off=rec.cigar_off, cigar=rec.cigar,
+                        qual_off=rec.qual_off, qual=rec.qual, qname_off=rec.qname_off, qname=rec.qname)
+    bad.pos[rec.n // 2] = bad.pos[rec.n // 2 - 1] - 50                 # one read out of order, far into the tile
+    opt = CallableOptions()
+    for reuse in (False, True):
+        eng = Engine(opt, 0)
+        other = Engine(opt, 0)
+        with pytest.raises(EngineError):
+            process_single_contig(eng, CallableProfiler(str(tmp_path / "x.bed")), ContigProfiler("c", L), opt, 0, bad, ref)
+        # the device's ring is free: another context pushes a large tile at once
+        counter = CallableProfiler(str(tmp_path / "o.bed"))
+        st = ContigProfiler("c", L)
+        process_single_contig(other, counter, st, opt, 0, rec, ref)
+        counter.close()
+        if reuse:                                                        # ... and the failed context works again
+            counter2 = CallableProfiler(str(tmp_path / "r.bed"))
+            st2 = ContigProfiler("c", L)
+            process_single_contig(eng, counter2, st2, opt, 0, rec, ref)
+            counter2.close()
+            assert open(tmp_path / "r.bed").read() == open(tmp_path / "o.bed").read()
+            assert st2.summed_coverage == st.summed_coverage
+        eng.close()                                                      # straight after the error, or after the reuse
+        other.close()
+    # a prefetch that no tile ever claims, then destroy
+    eng = Engine(opt, 0)
+    eng.contig_begin(0, L, ref)
+    eng._check(eng._lib.cl_contig_prefetch_qual(eng._h, rec.qual.ctypes.data, rec.qual.shape[0]))
+    eng.close()
+    eng = Engine(opt, 0)
+    eng.contig_begin(0, L, ref)
+    eng._check(eng._lib.cl_contig_prefetch_qual(eng._h, rec.qual.ctypes.data, rec.qual.shape[0]))
+    eng.contig_abort()
+    eng.close()

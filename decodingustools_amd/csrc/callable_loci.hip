@@ -310,6 +310,10 @@ struct cl_ctx {
     uint64_t q_dev = 0;              // quality bytes of this contig that already are (d_qual + kQualPad ..)
     // reads whose reference span exceeds kWideSpan (ascending read index = ascending position)
     std::vector<uint32_t> h_wide_idx;
+    // short-read form: read i's records are rec[h_rec_of[i] .. h_rec_of[i + 1]) (built at upload, gen_read_recs)
+    std::vector<uint32_t> h_rec_of;
+    std::vector<uint32_t> h_wide_rec_of;   // prefix sums of the wide reads' record counts (n_wide + 1 entries)
+    uint32_t n_rec = 0;
     std::vector<int32_t> h_wide_pos;
     // the index over the CIGARs, built by the one host walk that validates a tile (cl_push_reads): every read's end,
     // and for reads with more than kLongOps operations the (reference, query) position before every 64th operation
@@ -569,13 +573,93 @@ Reads device_reads(const cl_ctx *c)
     return R;
 }
 
+// The records of one read for the short-read form of k_pileup (kernels.hip.h: ReadRec), in order: put(k, rec) for
+// k = 0 .. count - 1; returns the count.  What the reference's column walk sees of the read (mod.rs:22-37): it is in
+// every column of [pos, end) -- the head record --, and the bases of its M/=/X operations that have a quality byte are
+// tested against min_base_quality -- the head's own run and the piece records.  Reads below min_mapping_quality are
+// only counted (mod.rs:25): head alone.  A read without a reference span is in no column: no record.
+template <class Put>
+inline uint32_t gen_read_recs(int32_t pos, uint32_t end, uint32_t mq, uint32_t min_mapq, const uint32_t *cig, uint32_t nops,
+                              unsigned long long q0, unsigned long long ql, Put &&put)
+{
+    const uint32_t span = end - (uint32_t)pos;
+    if (span == 0u) return 0u;
+    ReadRec head;
+    head.pos = pos; head.span = span; head.qual_lo = 0u; head.meta = mq | 0x100u;
+    uint32_t k = 1;
+    if (mq >= min_mapq) {
+        unsigned long long xr = (uint32_t)pos, y = 0;
+        for (uint32_t j = 0; j < nops && xr <= 0xFFFF0000ull; ++j) {
+            const uint32_t cw = cig[j], op = cw & 15u, l = cw >> 4;
+            if ((0x181u >> op) & 1u) {                                     // M = X
+                const unsigned long long lq = y < ql ? std::min<unsigned long long>(ql - y, l) : 0ull;   // bases that have a quality byte
+                for (unsigned long long off = 0; off < lq; off += 0xFFFFull) {
+                    const uint32_t len = (uint32_t)std::min<unsigned long long>(lq - off, 0xFFFFull);
+                    const unsigned long long px = xr + off;
+                    if (px > 0xFFFF0000ull) break;                          // flagged kErrRange by cl_push_reads
+                    if (k == 1u && !(head.meta >> 16) && px == (uint32_t)pos) {
+                        head.qual_lo = (uint32_t)(q0 + y + off); head.meta |= len << 16;
+                    } else {
+                        ReadRec r;
+                        r.pos = (int32_t)(uint32_t)px; r.span = 0u; r.qual_lo = (uint32_t)(q0 + y + off); r.meta = mq | (len << 16);
+                        put(k++, r);
+                    }
+                }
+                xr += l; y += l;
+            } else if ((0x18Du >> op) & 1u) xr += l;                       // D N
+            else if ((0x193u >> op) & 1u) y += l;                          // I S
+        }
+    }
+    put(0u, head);
+    return k;
+}
+
+// h_rec_of: the prefix sums of the reads' record counts (two parallel sweeps over the staged reads)
+cl_status build_rec_index(cl_ctx *c)
+{
+    const size_t n = c->h_pos.size();
+    std::vector<uint32_t> &ro = c->h_rec_of;
+    ro.assign(n + 1, 0u);
+    const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
+    const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
+    const uint32_t min_mapq = c->opt.min_mapping_quality;
+    const size_t grain = dut::grain_for(n, 65536), nchunk = n ? (n + grain - 1) / grain : 0;
+    std::vector<uint64_t> tot(nchunk + 1, 0);
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        const size_t a = k * grain, b = std::min(n, a + grain);
+        uint64_t t = 0;
+        for (size_t i = a; i < b; ++i) {
+            const uint32_t nc = hc[i + 1] - hc[i];
+            const unsigned long long ql = hq[i + 1] - hq[i];
+            uint32_t cnt;
+            // one M/=/X operation as long as the qualities (96 reads in 100 of aligner output): one record, no walk
+            if (nc == 1u && he[i] != (uint32_t)hp[i] && ql < 0x10000ull && ((0x181u >> (hcig[hc[i]] & 15u)) & 1u) && (hcig[hc[i]] >> 4) == ql) cnt = 1u;
+            else cnt = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], nc, hq[i], ql, [](uint32_t, const ReadRec &) {});
+            ro[i + 1] = cnt;
+            t += cnt;
+        }
+        tot[k + 1] = t;
+    });
+    for (size_t k = 0; k < nchunk; ++k) tot[k + 1] += tot[k];
+    if (tot[nchunk] >= (1ull << 29)) return fail(c, CL_ERR_RANGE, "more than 2^29 read records in one contig");
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        const size_t a = k * grain, b = std::min(n, a + grain);
+        uint32_t run = (uint32_t)tot[k];
+        for (size_t i = a; i < b; ++i) { run += ro[i + 1]; ro[i + 1] = run; }
+    });
+    c->n_rec = (uint32_t)tot[nchunk];
+    return CL_OK;
+}
+
 // The windows' candidate ranges: an index of the resident reads (binary searches over the sorted positions), built on
 // the host at upload -- where the positions still are -- instead of in every run (round 1 ran the same rules as a
 // device function in front of every pileup launch; the parity tests hold the results of this one against the oracle).
-void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &flags)
+void host_window_bounds(const cl_ctx *c, const std::vector<uint32_t> &wro_v, std::vector<WinMeta> &win, uint32_t &flags)
 {
     const uint32_t n = (uint32_t)c->h_pos.size(), n_wide = (uint32_t)c->h_wide_pos.size();
     const int32_t *pos = c->h_pos.data(), *wpos = c->h_wide_pos.data();
+    static const uint32_t kZero[1] = {0u};
+    const uint32_t *wro = wro_v.empty() ? kZero : wro_v.data();      // (no wide read: wlo = wn = 0 everywhere)
     auto lb = [](const int32_t *p, uint32_t cnt, long long key) {
         return (uint32_t)(std::lower_bound(p, p + cnt, key, [](int32_t v, long long k) { return (long long)v < k; }) - p);
     };
@@ -595,7 +679,15 @@ void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &fl
         m.q0 = c->h_qual_off[first]; m.rlo = 0; m.rn = 0;
         // k_pileup addresses the quality bytes of a window with 32-bit offsets
         if (m.hi > first && c->h_qual_off[m.hi] - c->h_qual_off[first] > 0xFFFF0000ull) fl.fetch_or(kErrRange);
-        // more reads than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
+        if (c->form == 0) {
+            // the short-read form's candidates are records: those of the reads [lo, hi) lie side by side, the wide reads'
+            // are listed in wide_rec (wro: the prefix sums of the wide reads' record counts)
+            const uint32_t *ro = c->h_rec_of.data();
+            m.lo = ro[m.lo]; m.hi = ro[m.hi];
+            const uint32_t w1 = wro[m.wlo + m.wn];
+            m.wlo = wro[m.wlo]; m.wn = w1 - m.wlo;
+        }
+        // more candidates than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
         if ((m.hi - m.lo) + m.wn > 32767u) fl.fetch_or(kNeedDeep);
         win[w] = m;
     });
@@ -835,7 +927,7 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
         // ... beside it, the windows' candidate ranges
         std::vector<WinMeta> win;
         uint32_t flags = 0;
-        host_window_bounds(c, win, flags);
+        host_window_bounds(c, c->h_wide_rec_of, win, flags);
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
         c->n_runtab = 0;
@@ -1299,7 +1391,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // forms read the arrays as pushed, and every read's end.
     // The run-table form reads neither CIGARs nor offsets: pos, mapq and end of the windows' candidates, and the table
     // that the walk in size_for_extent() builds from the staged CIGARs.
-    const bool need_soa = form == 1, need_cigar = form != 2;
+    const bool need_soa = form == 1, need_cigar = form == 1;
     HIP_TRY(c, c->d_end.reserve(n + 1));
     if (need_cigar) {
         HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));      // four words are loaded at a read's first op
@@ -1327,33 +1419,38 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if ((rs = ring_copy(c, c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long))) != CL_OK) return rs;
     }
-    if (form != 0 || c->n_long)
+    if (form != 0)
         if ((rs = ring_copy(c, c->d_end.p, c->h_end.data(), n * sizeof(uint32_t))) != CL_OK) return rs;
     if (c->n_long && need_cigar) {                           // entries of operations inside other reads are never read
         const size_t nck = (c->n_cigar >> 6) + 1;
         if ((rs = ring_copy(c, c->d_ck_x.p, c->h_ck_x.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_ck_y.p, c->h_ck_y.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
     }
+    c->h_rec_of.clear(); c->h_wide_rec_of.clear(); c->n_rec = 0;
     if (form == 0) {
-        // the packed records of the short-read form: pos, CIGAR offset, low half of the quality offset, mapq and the two
-        // lengths when they fit their fields (else the marker: the kernel takes them from the next record); rec[n] is the
-        // sentinel with the totals.  Built straight into the pinned buffers.
-        HIP_TRY(c, c->d_rec.reserve(n + 1));
-        const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data();
-        const uint32_t *hc = c->h_cigar_off.data(); const unsigned long long *hq = c->h_qual_off.data();
-        rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), (uint64_t)(n + 1) * sizeof(ReadRec),
-                        [hp, hm, hc, hq, n](uint64_t off, uint64_t len, uint8_t *out) {
+        // the records of the short-read form (kernels.hip.h: ReadRec): the host's walk over the CIGARs, so that the
+        // device decodes none -- north_star's "CIGAR-expanded ref spans" on the host side of the boundary.  Counted
+        // first (the reads' record ranges are what the windows' candidate ranges index), then built straight into the
+        // pinned buffers: a buffer covers a range of record numbers, the reads it belongs to are found by binary search.
+        if ((rs = build_rec_index(c)) != CL_OK) return rs;
+        const uint32_t n_rec = c->n_rec;
+        HIP_TRY(c, c->d_rec.reserve((size_t)n_rec + 1));
+        const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
+        const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
+        const uint32_t *ro = c->h_rec_of.data();
+        const uint32_t min_mapq = c->opt.min_mapping_quality;
+        rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), ((uint64_t)n_rec + 1) * sizeof(ReadRec),
+                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq](uint64_t off, uint64_t len, uint8_t *out) {
             ReadRec *o = reinterpret_cast<ReadRec *>(out);
-            const size_t i0 = off / sizeof(ReadRec), i1 = (off + len) / sizeof(ReadRec);
-            for (size_t i = i0; i < i1; ++i) {
-                ReadRec r;
-                if (i < n) {
-                    const uint32_t nc = hc[i + 1] - hc[i];
-                    const unsigned long long ql = hq[i + 1] - hq[i];
-                    r.pos = hp[i]; r.cigar_off = hc[i]; r.qual_lo = (uint32_t)hq[i];
-                    r.meta = (uint32_t)hm[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<unsigned long long>(ql, 0xFFFFull) << 16);
-                } else { r.pos = 0; r.cigar_off = hc[n]; r.qual_lo = (uint32_t)hq[n]; r.meta = 0; }
-                o[i - i0] = r;
+            const uint64_t j0 = off / sizeof(ReadRec), j1 = (off + len) / sizeof(ReadRec);
+            if (j1 > n_rec) memset(static_cast<void *>(o + (std::max<uint64_t>(n_rec, j0) - j0)), 0, (j1 - std::max<uint64_t>(n_rec, j0)) * sizeof(ReadRec));   // the padding record
+            if (j0 >= n_rec) return;
+            // the read that holds record j0: the last one whose range starts at or before it
+            size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
+            for (; i < n && ro[i] < j1; ++i) {
+                const uint64_t jb = ro[i];
+                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i], hq[i + 1] - hq[i],
+                              [&](uint32_t k, const ReadRec &r) { const uint64_t j = jb + k; if (j >= j0 && j < j1) o[j - j0] = r; });
             }
         });
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
@@ -1362,7 +1459,18 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     tmr.lap("upload: records");
     if (need_cigar && (rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
     tmr.lap("upload: cigar");
-    if (c->n_wide) {
+    std::vector<uint32_t> wide_rec;                      // short-read form: the wide reads' records, read by read
+    if (c->n_wide && form == 0) {
+        c->h_wide_rec_of.assign(c->n_wide + 1, 0u);
+        for (uint32_t j = 0; j < c->n_wide; ++j) {
+            const uint32_t i = c->h_wide_idx[j];
+            for (uint32_t r = c->h_rec_of[i]; r < c->h_rec_of[i + 1]; ++r) wide_rec.push_back(r);
+            c->h_wide_rec_of[j + 1] = (uint32_t)wide_rec.size();
+        }
+        HIP_TRY(c, c->d_wide_idx.reserve(wide_rec.size() + 1));
+        if (!wide_rec.empty())
+            HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, wide_rec.data(), wide_rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    } else if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_pos.p, c->h_wide_pos.data(), c->n_wide * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
@@ -1382,6 +1490,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // host time).
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear();
+    std::vector<uint32_t>().swap(c->h_rec_of); c->h_wide_rec_of.clear();
     give_staging(c);
     std::vector<uint8_t>().swap(c->h_qual);
     tmr.lap("upload: done");

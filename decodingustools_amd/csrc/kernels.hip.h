@@ -89,13 +89,19 @@ struct Reads {
     uint32_t n;
 };
 
-// One read as the short-read form of k_pileup takes it: one aligned 16-byte load instead of five scattered ones.
-// Built on the host at upload from the pushed arrays.  meta = mapq | n_cigar << 8 | qual_len << 16, where n_cigar
-// 255 / qual_len 0xFFFF mean "take it from the next record's offsets" (rec[n] is a sentinel holding the totals).
-// qual_lo = the low 32 bits of the read's quality offset: a window's candidates lie within 2^32 bytes of its q0.
+// The short-read form of k_pileup reads RECORDS, 16 bytes each, one aligned load; the host builds them at upload
+// (callable_loci.hip: gen_read_recs) in read order, the records of a read side by side:
+//   head record  {pos, span, qual_lo, mapq | 0x100 | seglen << 16}: the read as the pileup holds it, [pos, pos + span)
+//                (span = bam_cigar2rlen: D and N included) -- the +-1 scatter and, in the window that holds pos, the
+//                separable sums.  When the read's first M/=/X run starts at pos (the usual case) the head carries it too:
+//                seglen bases whose quality bytes start at qual_lo; else seglen = 0.
+//   piece record {pos of the run, 0, qual_lo, mapq | seglen << 16}: one further M/=/X run (or the next 65 535 bases of
+//                a longer one), clipped to the bases that have a quality byte.
+// qual_lo = the low 32 bits of the run's quality offset: a window's candidates lie within 2^32 bytes of its q0.
+// A read without a reference span has no record at all.
 struct __attribute__((aligned(16))) ReadRec {
     int32_t  pos;
-    uint32_t cigar_off;
+    uint32_t span;
     uint32_t qual_lo;
     uint32_t meta;
 };
@@ -368,7 +374,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
     constexpr int kWaves = kBlock / 64;
     constexpr int kSegRound = 2;                    // segments a lane may emit per round
-    constexpr int kListCap = LONG == 2 ? 1 : 64 * kSegRound + 16;   // entries of one wave's list (+ carried-over entries)
+    constexpr int kListCap = LONG == 2 ? 1 : (LONG == 0 ? 64 + 16 : 64 * kSegRound + 16);   // entries of one wave's list (+ carried-over entries)
     constexpr uint32_t kLutLds = 256;
     // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
     // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
@@ -413,10 +419,12 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
     const unsigned long long qwin = wm.q0;
     const uint8_t *qbase = a.R.qual + qwin - kQualPad;
 
-    // reference bytes of this thread's positions: needed last, requested first
+    // reference bytes of this thread's positions: needed last
     uint32_t refw[PER / 4];
+#ifndef CL_REF_LATE
 #pragma unroll
     for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
+#endif
 
     // ---- clear ----
     {
@@ -616,6 +624,87 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
                 sumq += sq32; sq32 = 0;
             }
         }
+    } else if constexpr (LONG == 0) {
+        // ---- short-read form: the candidates are RECORDS (ReadRec), 256 at a time, one lane per record, the records
+        //      dealt round-robin to the 4 waves; waves never synchronise during the pass.  No CIGAR is decoded on the device:
+        //      the host's walk at upload turned every read into a head record (its span: the +-1 scatter, mod.rs:22-28, and
+        //      the sums of the window that holds its start, contig_profiler.rs:74) that also carries the read's first
+        //      M/=/X run when that starts at the read's position -- all there is to 96 reads in 100 of aligner output --
+        //      and one piece record per further run (mod.rs:30-37 visits exactly those bases). ----
+        for (uint32_t base = 0; base < (CL_ABL(2u) ? 0u : n_cand); base += kBlock) {
+            const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets
+            uint32_t r = lo + (v - wn);
+            if (v < wn) r = a.wide_idx[wlo + v];
+            __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 records
+            uint2 seg = make_uint2(0u, 0u);
+            uint32_t own_l = 0, own_m = 0;              // spans below 2^16: the wave's sums fit 32 bits
+            bool big = false;                           // a head record with a wider span (rare: exact 64-bit sums below)
+            uint32_t big_span = 0, big_mq = 0;
+            if (v < n_cand) {
+                uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
+                // (one 16-byte load: left alone, hipcc splits it and fetches fields behind the tests that need them)
+                asm volatile("" : "+v"(rr.x), "+v"(rr.y), "+v"(rr.z), "+v"(rr.w));
+                const uint32_t x = rr.x, span = rr.y, mq = rr.w & 255u, seglen = rr.w >> 16;
+                const bool hq = mq >= a.o.min_mapq;
+                if ((rr.w & 0x100u) && span) {                   // head record: the read as the pileup holds it, [x, x + span)
+                    const uint32_t e = x + span;
+                    if (x >= W) {                                // every read starts in exactly one window
+                        if (span < 0x10000u) { own_l = span; own_m = hq ? mq * span : 0u; }
+                        else { big = true; big_span = span; big_mq = hq ? mq : 0u; }
+                    }
+                    if (e > W) {
+                        const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
+                        uint32_t ib, vb, ie, ve2;            // word index and addend of the +1 and of the -1
+                        if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
+                        else {
+                            ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
+                            ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                        }
+                        atomicAdd(&s_raw[ib], vb);
+                        if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
+                        if (mq <= a.o.max_low_mapq) {
+                            atomicAdd(&s_low[ib], vb);
+                            if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
+                        }
+                    }
+                }
+                // the record's run of seglen bases with a quality byte each, from reference position x
+                const uint32_t sp = x > W ? x : W, te = x + seglen, tp = te < Wend ? te : Wend;
+                if (hq && seglen && sp < tp)
+                    seg = make_uint2(rr.z - (uint32_t)qwin + (sp - x), (sp - W) | ((tp - sp - 1u) << 16) | ((v & 1u) << 30) | 0x80000000u);
+            }
+            win_len += dpp_wave_sum_u32(own_l); win_mq += dpp_wave_sum_u32(own_m);
+            if (__any(big)) {
+                win_len += wave_sum_u64(big ? (unsigned long long)big_span : 0ull);
+                win_mq += wave_sum_u64(big ? (unsigned long long)big_mq * big_span : 0ull);
+            }
+            // -- wave-private list in lane (= position) order: carried-over entries, then this pass's --
+            uint32_t n_list = n_keep;
+            {
+                const bool has = (seg.y >> 31) != 0u;
+                const unsigned long long m = __ballot(has);
+                if (has) {
+                    const uint32_t idx = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    list[idx] = seg;
+                }
+                n_list += (uint32_t)__popcll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            // -- only full groups of 16 entries are consumed now; the < 16 left over move to the front
+            //    of the list and wait for the next pass (or for the flush after the last one) --
+            const uint32_t n_full = n_list & ~15u;
+            if (n_full) consume_list(n_full);
+            n_keep = n_list - n_full;
+            uint2 carry = make_uint2(0u, 0u);
+            if (n_full && lane < n_keep) carry = list[n_full + lane];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();       // the list is rewritten below and in the next pass
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (n_full && lane < n_keep) list[lane] = carry;
+            sumq += sq32; sq32 = 0;
+        }
     } else
     for (uint32_t base = 0; base < (CL_ABL(2u) ? 0u : n_cand); base += kBlock) {
         const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets
@@ -623,76 +712,21 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
         if (v < wn) r = a.wide_idx[wlo + v];
         __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
         bool live = false;
-        uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0, cw = 0;
+        uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0;
         unsigned long long own_len = 0, own_mq = 0;  // separable sums of the reads this window owns (this pass)
         if (v < n_cand) {
             uint32_t e, mq;
-            bool fetch_cw = true;                    // cw still has to be loaded from cigar[k]
-            if constexpr (LONG == 0) {
-                // ---- short-read form: one packed record per read; the whole CIGAR is walked here once (what
-                //      the host does at upload for the long-read forms): the read's end, the malformed shapes htslib asserts
-                //      on, and -- in the window that holds the read's start -- its separable sums
-                //      (contig_profiler.rs:74: summed_coverage = sum of spans, summed_mapq over mapq >= min) ----
-                const uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
-                x = rr.x; k = rr.y; mq = rr.w & 255u;
-                qlen = rr.w >> 16;
-                k1 = k + ((rr.w >> 8) & 255u);
-                if (((rr.w >> 8) & 255u) == 255u || qlen == 0xFFFFu) {          // rare: the next record's offsets
-                    const uint4 nx = *reinterpret_cast<const uint4 *>(a.rec + r + 1);
-                    k1 = nx.y; qlen = nx.z - rr.z;
-                }
-                qrel = rr.z - (uint32_t)qwin;
-                const uint32_t n = k1 - k;
-                if (n <= kLongOps) {
-                    Q16 c4;                                      // the first four words (the array is padded)
-                    __builtin_memcpy(&c4, a.R.cigar + k, 16);
-                    unsigned long long reflen = 0;
-                    uint32_t er = 0;
-#pragma unroll
-                    for (uint32_t d = 0; d < 4u; ++d) {
-                        const uint32_t c = d < n ? c4.w[d] : 5u, l = c >> 4;       // beyond the read: H, advances nothing
-                        const bool radv = ((0x18Du >> (c & 15u)) & 1u) != 0u;
-                        reflen += radv ? l : 0u;
-                        if (radv && l == 0u) er |= kErrCigar;                      // zero-length reference-consuming op
-                    }
-                    for (uint32_t kk = k + 4u; kk < k1; ++kk) {                     // few reads have more than four ops
-                        const uint32_t c = a.R.cigar[kk], l = c >> 4;
-                        const bool radv = ((0x18Du >> (c & 15u)) & 1u) != 0u;
-                        reflen += radv ? l : 0u;
-                        if (radv && l == 0u) er |= kErrCigar;
-                    }
-                    // a read that reaches a column with a single non-match op is undefined in htslib
-                    if (reflen > 0 && n == 1u && !op_match(c4.w[0] & 15u)) er |= kErrCigar;
-                    const unsigned long long ee = (unsigned long long)x + reflen;
-                    if (ee > 0xFFFF0000ull) er |= kErrRange;
-                    e = ee > 0xFFFF0000ull ? x : (uint32_t)ee;
-                    if (er) atomicOr(a.err_flag, er);
-                    if (x >= W) {                                // every read starts in exactly one window
-                        own_len = e - x;
-                        own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
-                    }
-                    cw = n ? c4.w[0] : 0u;
-                    fetch_cw = false;
-                } else {
-                    e = a.end[r];                                // more than kLongOps operations: the host walked them
-                    if (x >= W) {
-                        own_len = e - x;
-                        own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
-                    }
-                }
-            } else {
-                x = (uint32_t)a.R.pos[r];
-                e = a.end[r]; mq = a.R.mapq[r];
-                if (x >= W) {                                    // the window that holds the read's start owns its sums
-                    own_len = e - x;
-                    own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
-                }
-                k = a.R.cigar_off[r];
-                k1 = a.R.cigar_off[r + 1];
-                const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
-                qrel = (uint32_t)(q0 - qwin);
-                qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
+            x = (uint32_t)a.R.pos[r];
+            e = a.end[r]; mq = a.R.mapq[r];
+            if (x >= W) {                                    // the window that holds the read's start owns its sums
+                own_len = e - x;
+                own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
             }
+            k = a.R.cigar_off[r];
+            k1 = a.R.cigar_off[r + 1];
+            const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
+            qrel = (uint32_t)(q0 - qwin);
+            qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
             if (e > W) {
                 const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
                 uint32_t ib, vb, ie, ve2;            // word index and addend of the +1 and of the -1
@@ -721,10 +755,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
                     k = lo_j << 6; x = a.ck_x[lo_j]; y = a.ck_y[lo_j];
                 }
             }
-            if (!LONG && live && fetch_cw) cw = a.R.cigar[k];    // invariant: cw == cigar[k] while live
         }
         win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq);
-        if constexpr (LONG) {
+        {
             // ---- long-read shape: CIGAR operations in parallel.  The live reads of the pass are
             //      compacted into s_live; a wave takes a read and 64 of its operations at a time (one
             //      coalesced load), two wave scans give every operation its reference / query start,
@@ -887,68 +920,6 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
                 }
             }
             __syncthreads();                                         // s_live is rewritten by the next pass
-        } else {
-            const uint32_t setbit = (v & 1u) << 30;      // which 8-bit counter set this read adds to
-            for (;;) {                                   // rounds: wave-uniform loop
-                // -- each lane: next (at most kSegRound) segments of its read.  Wave-uniform loop,
-                //    per-lane predication, one CIGAR op per iteration; invariant: cw == cigar[k] while live --
-                uint2 seg[kSegRound];
-                seg[0] = make_uint2(0u, 0u); seg[1] = make_uint2(0u, 0u);
-                uint32_t nemit = 0;
-                for (;;) {
-                    const bool act = live && nemit < (uint32_t)kSegRound;
-                    if (!__any(act)) break;
-                    const uint32_t op = cw & 15u, l = cw >> 4;
-                    const bool ism = ((0x181u >> op) & 1u) != 0u;        // M = X
-                    const bool radv = ((0x18Du >> op) & 1u) != 0u;       // M D N = X consume reference
-                    const bool qadv = ((0x193u >> op) & 1u) != 0u;       // M I S = X consume query
-                    const uint32_t xe = x + (radv ? l : 0u);
-                    const uint32_t sp = x > W ? x : W;
-                    const uint32_t lq = y < qlen ? ((qlen - y) < l ? (qlen - y) : l) : 0u;   // bases that have a quality byte
-                    uint32_t tp = xe < Wend ? xe : Wend;
-                    tp = (x + lq) < tp ? (x + lq) : tp;
-                    const bool valid = act && ism && sp < tp;
-                    const uint2 d = make_uint2(qrel + y + (sp - x), (sp - W) | ((tp - sp - 1u) << 16) | setbit | 0x80000000u);
-                    if (valid && nemit == 0u) seg[0] = d;
-                    if (valid && nemit == 1u) seg[1] = d;
-                    nemit += valid ? 1u : 0u;
-                    if (act) {
-                        x = xe;
-                        y += qadv ? l : 0u;
-                        k += 1u;
-                        live = k < k1 && x < Wend;
-                        if (live) cw = a.R.cigar[k];
-                    }
-                }
-                // -- wave-private list in lane (= position) order: carried-over entries, first segments,
-                //    then second ones --
-                uint32_t n_list = n_keep;
-    #pragma unroll
-                for (int i = 0; i < kSegRound; ++i) {
-                    const bool has = (seg[i].y >> 31) != 0u;
-                    const unsigned long long m = __ballot(has);
-                    if (has) {
-                        const uint32_t idx = n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                        list[idx] = seg[i];
-                    }
-                    n_list += (uint32_t)__popcll(m);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                // -- only full groups of 16 entries are consumed now; the < 16 left over move to the front
-                //    of the list and wait for the next round (or for the flush after the last pass) --
-                const uint32_t n_full = n_list & ~15u;
-                if (n_full) consume_list(n_full);
-                n_keep = n_list - n_full;
-                uint2 carry = make_uint2(0u, 0u);
-                if (n_full && lane < n_keep) carry = list[n_full + lane];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();       // the list is rewritten below and in the next round
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (n_full && lane < n_keep) list[lane] = carry;
-                if (!__any(live)) break;
-            }
         }
         sumq += sq32; sq32 = 0;
     }
@@ -959,6 +930,10 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
         consume_list(n_keep);
         sumq += sq32; sq32 = 0;
     }
+#ifdef CL_REF_LATE
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
+#endif
     __syncthreads();
 
     // ---- final phase: depths, low-MAPQ rule, state, counts (8 positions per thread) ----

@@ -461,14 +461,14 @@ cl_status ensure_pins(cl_ctx *c)
 // n bytes to `dst` through the ring: fill(off, len, out) writes the bytes [off, off + len) of the transfer into the
 // pinned buffer `out`.  Chunks are dealt round-robin to the copier threads.  Returns at once; ring_finish joins.
 template <class Fill>
-cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill)
+cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill, uint64_t chunk_bytes = PinRing::kPinBytes)
 {
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
     PinRing *R = c->ring.get();
     R->acquire(c);                                        // another context of this device may be using the ring
     c->ring_held = true;
-    const uint64_t CH = PinRing::kPinBytes, nch = (n + CH - 1) / CH;
+    const uint64_t CH = chunk_bytes, nch = (n + CH - 1) / CH;
     const int T = PinRing::threads();
     const int nt = (int)std::min<uint64_t>((uint64_t)T, nch);
     for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
@@ -612,6 +612,19 @@ inline uint32_t gen_read_recs(int32_t pos, uint32_t end, uint32_t mq, uint32_t m
     }
     put(0u, head);
     return k;
+}
+
+// bytes of read records per pinned buffer (DUT_REC_CHUNK: a test hook that puts the buffer seams inside the records of
+// one read with small inputs; a multiple of the record size; read once)
+uint64_t rec_chunk_bytes()
+{
+    static const uint64_t n = [] {
+        const char *e = getenv("DUT_REC_CHUNK");
+        uint64_t v = e ? strtoull(e, nullptr, 0) : PinRing::kPinBytes;
+        v &= ~(uint64_t)(sizeof(ReadRec) - 1);
+        return v < sizeof(ReadRec) ? sizeof(ReadRec) : (v > PinRing::kPinBytes ? PinRing::kPinBytes : v);
+    }();
+    return n;
 }
 
 // h_rec_of: the prefix sums of the reads' record counts (two parallel sweeps over the staged reads)
@@ -1452,7 +1465,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
                 gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i], hq[i + 1] - hq[i],
                               [&](uint32_t k, const ReadRec &r) { const uint64_t j = jb + k; if (j >= j0 && j < j1) o[j - j0] = r; });
             }
-        });
+        }, rec_chunk_bytes());
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
     }

@@ -2,11 +2,14 @@
 //
 // Data flow of one contig (all arrays resident in HBM, layouts in DESIGN.md section 3):
 //
-//   (host, at upload: per window of T reference positions the [lo,hi) range of reads that can touch it -- an
+//   (host, at upload: per window of T reference positions the [lo,hi) range of candidates that can touch it -- an
 //                    index of the resident layout, like the offsets; WinMeta below)
 //   (host, at upload, in the one walk over every CIGAR that validates a tile: every read's end, and for reads of
 //                    more than kLongOps operations a (reference, query) checkpoint before every 64th operation --
 //                    an index over the CIGARs, like the window records)
+//   (host, at upload: short-read contigs become 16-byte RECORDS, a head per read and a piece per further M/=/X run
+//                    (ReadRec); indel-rich long-read contigs a table of match pieces per window (run table) -- in both
+//                    forms k_pileup decodes no CIGAR)
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
 //                    (callable_profiler.rs:100-116) and reduced to the window's run list (the
@@ -209,8 +212,8 @@ __device__ __forceinline__ uint32_t swar_ge7(uint32_t q, uint32_t add, uint32_t 
 struct PileupArgs {
     Reads R;
     Opts o;
-    const ReadRec *rec;           // n + 1 packed records (the short-read form reads these instead of R's per-read arrays)
-    const uint32_t *end;          // per read, from the host (the short-read form reads it for reads of more than kLongOps operations only)
+    const ReadRec *rec;           // the records of the short-read form (it reads these and nothing else per read)
+    const uint32_t *end;          // per read, from the host (long-read forms)
     const WinMeta *win;
     const uint32_t *wide_idx;           // read indices of the wide reads, ascending
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
@@ -236,12 +239,12 @@ struct PileupArgs {
 // ---------------------------------------------------------------------------------------------
 // k_pileup: one workgroup per window of T reference positions.
 //
-// Pass over the window's candidate reads (the wide ones that start before the ordinary range first),
-// 256 at a time, one lane per read, waves never synchronising:
+// Pass over the window's candidates (LONG = 0: the records of its reads, ReadRec; the wide reads' that start before
+// the ordinary range first), 256 at a time, one lane per candidate, waves never synchronising:
 //   * +1/-1 at the clipped span ends into raw / low-mapq difference arrays (mod.rs:22-28: every
 //     read covering a position counts, D/N included)
-//   * the lane walks its CIGAR and writes the window-clipped M/=/X segments of reads with
-//     mapq >= min_mapq into its wave's private LDS list (in lane = position order)
+//   * the lane writes the window-clipped M/=/X segment of its record (mapq >= min_mapq) into its wave's private
+//     LDS list (in lane = position order); no CIGAR is decoded -- the host's walk at upload made the records
 //   * lane quads consume the list: a lane handles units of 16 reference positions = one unaligned
 //     16-byte load of quality bytes, a byte-parallel "quality >= min" test (mod.rs:30-37) and
 //     adds into packed 8-bit (two sets) or 16-bit LDS counters (qc_depth); the sum of the passing
@@ -254,8 +257,8 @@ struct PileupArgs {
 // Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave): a wave's list holds every fourth
 // read, and consecutive candidates alternate between the two 8-bit counter sets.
 //
-// LONG = 1 (contigs with >= 8 CIGAR operations per read on average and long match runs, HiFi-like): the lane-serial
-// CIGAR walk is replaced by an operation-parallel one -- live reads are compacted, a wave takes 64 operations of a
+// LONG = 1 (contigs with >= 8 CIGAR operations per read on average and long match runs, HiFi-like): the one form that
+// still decodes CIGARs on the device, operation-parallel -- live reads are compacted, a wave takes 64 operations of a
 // read at a time, two DPP scans give every operation its reference / query start, each lane consumes its own M/=/X
 // run (runs longer than 64 bases go through the list and the quad loop).
 //
@@ -419,12 +422,10 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
     const unsigned long long qwin = wm.q0;
     const uint8_t *qbase = a.R.qual + qwin - kQualPad;
 
-    // reference bytes of this thread's positions: needed last
+    // reference bytes of this thread's positions: needed last, requested first
     uint32_t refw[PER / 4];
-#ifndef CL_REF_LATE
 #pragma unroll
     for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
-#endif
 
     // ---- clear ----
     {
@@ -930,10 +931,6 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
         consume_list(n_keep);
         sumq += sq32; sq32 = 0;
     }
-#ifdef CL_REF_LATE
-#pragma unroll
-    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
-#endif
     __syncthreads();
 
     // ---- final phase: depths, low-MAPQ rule, state, counts (8 positions per thread) ----

@@ -1118,3 +1118,72 @@ def test_an_error_behind_a_quality_prefetch_leaves_nothing_in_flight(tmp_path):
     eng._check(eng._lib.cl_contig_prefetch_qual(eng._h, rec.qual.ctypes.data, rec.qual.shape[0]))
     eng.contig_abort()
     eng.close()
+
+
+# ---- the record form of the short-read k_pileup: the host's walk at upload turns every read into a head record and
+#      one piece record per further M/=/X run (callable_loci.hip: gen_read_recs) ----
+def record_shapes_contig(L=200_000, seed=4242, n_plain=4000):
+    """A contig the short-read form takes (fewer than 8 operations per read on average) that holds every shape the record
+    builder distinguishes: plain reads; reads that start with S / I / H (the head carries the first run or not); runs
+    behind deletions, insertions and N gaps (piece records); a read of more than 64 operations; match runs longer than
+    65 535 bases (split into several pieces, and wide: their records go through the wide list); quality strings shorter
+    than the CIGAR says and absent altogether; reads below every mapping-quality threshold."""
+    rng = np.random.default_rng(seed)
+    reads = []
+    for i, p in enumerate(rng.integers(0, L - 400, n_plain)):
+        reads.append([int(p), "150M", int(rng.choice([0, 1, 9, 10, 30, 60, 60, 60])), int(rng.choice([5, 19, 20, 35])), 0, f"p{i}"])
+    shapes = ["5S145M", "3I147M", "2S3I95M50M", "10H140M", "75M2D75M", "60M1I30M4D59M", "40M300N60M50S", "1M1D1M1D148M",
+              "20=5X30=1I10X2D84=", "150S", "4I", "30M5000N30M", "7M1I" * 40, "2M1D" * 70 + "10M", "148M2S", "1S1M1S"]
+    for i in range(1200):
+        p = int(rng.integers(0, L - 6000))
+        reads.append([p, shapes[i % len(shapes)], int(rng.choice([0, 5, 10, 30, 60])), int(rng.choice([10, 20, 30])), 0, f"s{i}"])
+    for i, (p, cig) in enumerate([(100, "70000M"), (2047, "66000M5D3000M2I100M"), (4000, "131071M"), (90_000, "10S65535M1D65536M"),
+                                  (90_001, "65536M"), (120_000, "100M70000N100M")]):
+        reads.append([p, cig, [60, 60, 3, 60, 10, 60][i], [30, 22, 30, 19, 40, 30][i], 0, f"w{i}"])
+    reads.sort(key=lambda r: r[0])
+    rec = ContigRecords.from_reads(reads)
+    # every seventh read loses the tail of its quality string, every 31st all of it
+    keep = np.ones(rec.qual.shape[0], bool)
+    qoff = rec.qual_off.astype(np.int64)
+    newoff = [0]
+    for i in range(rec.n):
+        a, b = int(qoff[i]), int(qoff[i + 1])
+        cut = (b - a) if i % 31 == 0 else ((b - a) // 3 if i % 7 == 0 else 0)
+        keep[b - cut:b] = False
+        newoff.append(newoff[-1] + (b - a - cut))
+    rec.qual = np.ascontiguousarray(rec.qual[keep]); rec.qual_off = np.asarray(newoff, np.uint64)
+    rec.validate()
+    assert rec.cigar.shape[0] < 8 * rec.n                       # the short-read form
+    return L, rec, synth.make_reference(L, seed + 1, lowercase=True)
+
+
+@pytest.mark.parametrize("opts", [dict(), dict(min_mapping_quality=0, min_base_quality=0, min_depth=1),
+                                  dict(min_mapping_quality=31, min_base_quality=25, max_depth=20, max_low_mapq=5)])
+def test_record_form_covers_every_read_shape(opts, tmp_path):
+    L, rec, ref = record_shapes_contig()
+    compare([("chrS", 4, L, ref, rec)], opts, tmp_path, "recshapes")
+
+
+_REC_CHUNK_CASE = r"""
+import os, sys, tempfile, pathlib
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import test_gpu_parity as T
+from decodingustools_amd import synth
+L, rec, ref = T.record_shapes_contig(L=120_000, n_plain=1500)
+T.compare([("chrS", 4, L, ref, rec)], dict(min_mapping_quality=0), pathlib.Path(tempfile.mkdtemp()), "recchunk_" + os.environ["DUT_REC_CHUNK"])
+rec = synth.adversarial_contig(5000, 1200, 1004, max_len=300, overhang=True)
+T.compare([("chrA", 1, 5000, synth.make_reference(5000, 54), rec)], dict(min_depth=2, min_depth_for_low_mapq=3), pathlib.Path(tempfile.mkdtemp()), "recchunk_adv")
+print("REC_CHUNK_OK")
+"""
+
+
+@pytest.mark.parametrize("chunk", ["16", "48", "1040"])
+def test_records_through_small_pinned_buffers(chunk):
+    """The records go to HBM through pinned buffers of DUT_REC_CHUNK bytes, each filled from the record number it
+    starts at: with 1, 3 or 65 records per buffer the seams fall between the head of a read and its pieces and inside the
+    pieces of one long run.  (The knob is read once per process.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUT_REC_CHUNK=chunk)
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _REC_CHUNK_CASE], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "REC_CHUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

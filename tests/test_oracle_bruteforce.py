@@ -62,3 +62,16 @@ def test_short_and_long_read_generators(tmp_path):
     opt = make_options(dict(max_depth=1_000_000))
     check([("s", 0, L, synth.make_reference(L, 1), synth.short_read_contig(L, 25, 2))], opt, tmp_path)
     check([("l", 0, L, synth.make_reference(L, 3), synth.long_read_contig(L, 12, 4))], opt, tmp_path)
+
+
+def test_record_shapes_contig(tmp_path):
+    """The contig the GPU tests of the record form use (tests/test_gpu_parity.py: record_shapes_contig): leading clips
+    and insertions, runs longer than 65 535 bases, truncated and absent quality strings -- the two restatements agree on
+    it before the device is held against the C oracle."""
+    import importlib.util, os
+    spec = importlib.util.spec_from_file_location("_tgp", os.path.join(os.path.dirname(__file__), "test_gpu_parity.py"))
+    T = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(T)
+    L, rec, ref = T.record_shapes_contig(L=120_000, n_plain=1500)
+    for o in (dict(max_depth=1_000_000), dict(max_depth=1_000_000, min_mapping_quality=0, min_base_quality=0, min_depth=1)):
+        check([("chrS", 4, L, ref, rec)], make_options(o), tmp_path)

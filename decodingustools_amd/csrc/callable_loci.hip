@@ -312,6 +312,11 @@ struct cl_ctx {
     std::vector<uint32_t> h_wide_idx;
     // short-read form: read i's records are rec[h_rec_of[i] .. h_rec_of[i + 1]) (built at upload, gen_read_recs)
     std::vector<uint32_t> h_rec_of;
+    // short-read form, aligned quality layout: read i's quality bytes are moved on the device from offset h_qual_off[i]
+    // to h_qual_off[i] + h_shift[i] (n + 1 entries; all zero when the layout is not used), see build_qual_alignment
+    std::vector<uint32_t> h_shift;
+    std::vector<uint8_t> h_phase;                     // (position - query offset) mod 16 of each read's first M/=/X run
+    bool qual_aligned = false;
     std::vector<uint32_t> h_wide_rec_of;   // prefix sums of the wide reads' record counts (n_wide + 1 entries)
     uint32_t n_rec = 0;
     std::vector<int32_t> h_wide_pos;
@@ -334,7 +339,10 @@ struct cl_ctx {
     DevBuf<uint8_t> d_qual;
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
-    DevBuf<ReadRec> d_rec;           // n + 1 packed records for the short-read form of k_pileup
+    DevBuf<ReadRec> d_rec;           // the records of the short-read form of k_pileup
+    DevBuf<uint8_t> d_qual_al;       // short-read form: the quality bytes in the aligned layout (k_repack_qual)
+    DevBuf<uint32_t> d_rec_shift;    // per record: how far its read's quality bytes move (upload only)
+    DevBuf<unsigned long long> d_rec_base;   // per 64 records: a 64-bit quality offset at or below theirs (upload only)
     DevBuf<uint32_t> d_win_off, d_wide_idx;
     DevBuf<WinMeta> d_win;
     DevBuf<int32_t> d_wide_pos;
@@ -580,8 +588,12 @@ Reads device_reads(const cl_ctx *c)
 // only counted (mod.rs:25): head alone.  A read without a reference span is in no column: no record.
 template <class Put>
 inline uint32_t gen_read_recs(int32_t pos, uint32_t end, uint32_t mq, uint32_t min_mapq, const uint32_t *cig, uint32_t nops,
-                              unsigned long long q0, unsigned long long ql, Put &&put)
+                              unsigned long long q0, unsigned long long ql, Put &&put, uint32_t *phase = nullptr)
 {
+    // *phase: (reference position - query offset) mod 16 of the first run that gets a record -- where the read's quality
+    // bytes have to start, mod 16, for that run's 16-position units to be 16-byte aligned in memory
+    if (phase) *phase = 0u;
+    bool first_run = true;
     const uint32_t span = end - (uint32_t)pos;
     if (span == 0u) return 0u;
     ReadRec head;
@@ -597,6 +609,7 @@ inline uint32_t gen_read_recs(int32_t pos, uint32_t end, uint32_t mq, uint32_t m
                     const uint32_t len = (uint32_t)std::min<unsigned long long>(lq - off, 0xFFFFull);
                     const unsigned long long px = xr + off;
                     if (px > 0xFFFF0000ull) break;                          // flagged kErrRange by cl_push_reads
+                    if (first_run) { first_run = false; if (phase) *phase = (uint32_t)((px - (y + off)) & 15ull); }
                     if (k == 1u && !(head.meta >> 16) && px == (uint32_t)pos) {
                         head.qual_lo = (uint32_t)(q0 + y + off); head.meta |= len << 16;
                     } else {
@@ -633,6 +646,8 @@ cl_status build_rec_index(cl_ctx *c)
     const size_t n = c->h_pos.size();
     std::vector<uint32_t> &ro = c->h_rec_of;
     ro.assign(n + 1, 0u);
+    c->h_phase.assign(n + 1, 0);
+    uint8_t *phase = c->h_phase.data();
     const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
     const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
     const uint32_t min_mapq = c->opt.min_mapping_quality;
@@ -644,11 +659,13 @@ cl_status build_rec_index(cl_ctx *c)
         for (size_t i = a; i < b; ++i) {
             const uint32_t nc = hc[i + 1] - hc[i];
             const unsigned long long ql = hq[i + 1] - hq[i];
-            uint32_t cnt;
+            uint32_t cnt, ph = 0;
             // one M/=/X operation as long as the qualities (96 reads in 100 of aligner output): one record, no walk
-            if (nc == 1u && he[i] != (uint32_t)hp[i] && ql < 0x10000ull && ((0x181u >> (hcig[hc[i]] & 15u)) & 1u) && (hcig[hc[i]] >> 4) == ql) cnt = 1u;
-            else cnt = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], nc, hq[i], ql, [](uint32_t, const ReadRec &) {});
+            if (nc == 1u && he[i] != (uint32_t)hp[i] && ql < 0x10000ull && ((0x181u >> (hcig[hc[i]] & 15u)) & 1u) && (hcig[hc[i]] >> 4) == ql) {
+                cnt = 1u; ph = hm[i] >= min_mapq ? ((uint32_t)hp[i] & 15u) : 0u;
+            } else cnt = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], nc, hq[i], ql, [](uint32_t, const ReadRec &) {}, &ph);
             ro[i + 1] = cnt;
+            phase[i] = (uint8_t)ph;
             t += cnt;
         }
         tot[k + 1] = t;
@@ -664,6 +681,47 @@ cl_status build_rec_index(cl_ctx *c)
     return CL_OK;
 }
 
+// The aligned quality layout of the short-read form.  k_pileup applies units of 16 reference positions = 16 quality
+// bytes per lane; as the reads lie in the pushed array those 16 bytes start at any byte address, and a wave's
+// byte-unaligned 16-byte loads cost the vector memory pipe 66 cycles where 16-byte aligned ones cost 38-51
+// (profiles/r03_ubench_memory_pipe.txt; the kernel is 7 % faster with aligned addresses).  So the bytes are moved once,
+// on the device at upload (k_repack_qual), each read's string to an offset congruent mod 16 to the phase of its first
+// run: read i goes from h_qual_off[i] to h_qual_off[i] + h_shift[i], h_shift = the running sum of the pads (0..15 bytes
+// per read, 7.5 on average: +5 % of HBM for the qualities).  pad_i = (phase_i - phase_(i-1) - len_(i-1)) mod 16 needs
+// the neighbours only, so the sum is two parallel sweeps.  Not used (all shifts zero) when the pads would pass 2^32.
+void build_qual_alignment(cl_ctx *c)
+{
+    const size_t n = c->h_pos.size();
+    c->h_shift.assign(n + 1, 0u);
+    c->qual_aligned = false;
+    if (n == 0) return;
+    static const bool off = [] { const char *e = getenv("DUT_QUAL_ALIGN"); return e && *e == '0'; }();   // (A/B switch)
+    if (off) return;
+    const uint8_t *ph = c->h_phase.data(); const unsigned long long *hq = c->h_qual_off.data();
+    uint32_t *sh = c->h_shift.data();
+    const size_t grain = dut::grain_for(n, 65536), nchunk = (n + grain - 1) / grain;
+    std::vector<uint64_t> tot(nchunk + 1, 0);
+    auto pad_of = [&](size_t i) -> uint32_t {
+        if (i == 0) return (uint32_t)((ph[0] - hq[0]) & 15ull);
+        return (uint32_t)(((unsigned long long)ph[i] - ph[i - 1] - (hq[i] - hq[i - 1])) & 15ull);
+    };
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        const size_t a = k * grain, b = std::min(n, a + grain);
+        uint64_t t = 0;
+        for (size_t i = a; i < b; ++i) t += pad_of(i);
+        tot[k + 1] = t;
+    });
+    for (size_t k = 0; k < nchunk; ++k) tot[k + 1] += tot[k];
+    if (tot[nchunk] >= 0xFFFFFF00ull) return;
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        const size_t a = k * grain, b = std::min(n, a + grain);
+        uint32_t run = (uint32_t)tot[k];
+        for (size_t i = a; i < b; ++i) { run += pad_of(i); sh[i] = run; }
+    });
+    sh[n] = (uint32_t)tot[nchunk];
+    c->qual_aligned = true;
+}
+
 // The windows' candidate ranges: an index of the resident reads (binary searches over the sorted positions), built on
 // the host at upload -- where the positions still are -- instead of in every run (round 1 ran the same rules as a
 // device function in front of every pileup launch; the parity tests hold the results of this one against the oracle).
@@ -673,6 +731,7 @@ void host_window_bounds(const cl_ctx *c, const std::vector<uint32_t> &wro_v, std
     const int32_t *pos = c->h_pos.data(), *wpos = c->h_wide_pos.data();
     static const uint32_t kZero[1] = {0u};
     const uint32_t *wro = wro_v.empty() ? kZero : wro_v.data();      // (no wide read: wlo = wn = 0 everywhere)
+    const uint32_t *sh = (c->form == 0 && c->h_shift.size() == (size_t)n + 1) ? c->h_shift.data() : nullptr;
     auto lb = [](const int32_t *p, uint32_t cnt, long long key) {
         return (uint32_t)(std::lower_bound(p, p + cnt, key, [](int32_t v, long long k) { return (long long)v < k; }) - p);
     };
@@ -689,9 +748,11 @@ void host_window_bounds(const cl_ctx *c, const std::vector<uint32_t> &wro_v, std
             m.wn = lb(wpos, n_wide, W - (long long)c->span_n + 1) - m.wlo;
         }
         const uint32_t first = m.wn ? c->h_wide_idx[m.wlo] : m.lo;      // lo <= n: the offsets array has n + 1 entries
-        m.q0 = c->h_qual_off[first]; m.rlo = 0; m.rn = 0;
+        // (short-read form: the offsets of the aligned layout, build_qual_alignment; zero shifts when it is not used)
+        const unsigned long long qf = c->h_qual_off[first] + (sh ? sh[first] : 0u), qh = c->h_qual_off[m.hi] + (sh ? sh[m.hi] : 0u);
+        m.q0 = qf; m.rlo = 0; m.rn = 0;
         // k_pileup addresses the quality bytes of a window with 32-bit offsets
-        if (m.hi > first && c->h_qual_off[m.hi] - c->h_qual_off[first] > 0xFFFF0000ull) fl.fetch_or(kErrRange);
+        if (m.hi > first && qh - qf > 0xFFFF0000ull) fl.fetch_or(kErrRange);
         if (c->form == 0) {
             // the short-read form's candidates are records: those of the reads [lo, hi) lie side by side, the wide reads'
             // are listed in wide_rec (wro: the prefix sums of the wide reads' record counts)
@@ -1001,7 +1062,9 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     // built at upload; CL_K_PREP stays in the timing table as an empty slot)
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     PileupArgs a;
-    a.R = R; a.o = c->dopt; a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
+    a.R = R; a.o = c->dopt;
+    if (c->form == 0 && c->qual_aligned) a.R.qual = c->d_qual_al.p + kQualPad;     // the aligned layout (k_repack_qual)
+ a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
     a.wide_idx = c->d_wide_idx.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
@@ -1091,7 +1154,7 @@ void cl_destroy(cl_ctx *c)
     drop_prefetch(c);                                     // its copiers write into d_qual: joined before anything is released
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
-    c->d_qual_off.release(); c->d_qual.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
+    c->d_qual_off.release(); c->d_qual.release(); c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
     c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
@@ -1448,12 +1511,25 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if ((rs = build_rec_index(c)) != CL_OK) return rs;
         const uint32_t n_rec = c->n_rec;
         HIP_TRY(c, c->d_rec.reserve((size_t)n_rec + 1));
+        // the aligned quality layout (build_qual_alignment): its buffer first -- without it the shifts stay zero and
+        // k_pileup reads the bytes where they were pushed
+        build_qual_alignment(c);
+        if (c->qual_aligned) {
+            const size_t need = (size_t)c->n_qual + c->h_shift[n] + 2 * kQualPad + 64;
+            if (c->d_qual_al.reserve(need) != hipSuccess || c->d_rec_shift.reserve((size_t)n_rec + 1) != hipSuccess ||
+                c->d_rec_base.reserve((size_t)n_rec / 64 + 2) != hipSuccess) {
+                (void)hipGetLastError();
+                c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release();
+                std::fill(c->h_shift.begin(), c->h_shift.end(), 0u);
+                c->qual_aligned = false;
+            }
+        }
         const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
         const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
-        const uint32_t *ro = c->h_rec_of.data();
+        const uint32_t *ro = c->h_rec_of.data(), *sh = c->h_shift.data();
         const uint32_t min_mapq = c->opt.min_mapping_quality;
         rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), ((uint64_t)n_rec + 1) * sizeof(ReadRec),
-                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq](uint64_t off, uint64_t len, uint8_t *out) {
+                        [hp, hm, he, hc, hcig, hq, ro, sh, n, n_rec, min_mapq](uint64_t off, uint64_t len, uint8_t *out) {
             ReadRec *o = reinterpret_cast<ReadRec *>(out);
             const uint64_t j0 = off / sizeof(ReadRec), j1 = (off + len) / sizeof(ReadRec);
             if (j1 > n_rec) memset(static_cast<void *>(o + (std::max<uint64_t>(n_rec, j0) - j0)), 0, (j1 - std::max<uint64_t>(n_rec, j0)) * sizeof(ReadRec));   // the padding record
@@ -1462,12 +1538,43 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
             size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
             for (; i < n && ro[i] < j1; ++i) {
                 const uint64_t jb = ro[i];
-                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i], hq[i + 1] - hq[i],
+                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i] + sh[i], hq[i + 1] - hq[i],
                               [&](uint32_t k, const ReadRec &r) { const uint64_t j = jb + k; if (j >= j0 && j < j1) o[j - j0] = r; });
             }
         }, rec_chunk_bytes());
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
+        if (c->qual_aligned && n_rec) {
+            // what k_repack_qual needs beside the records: per record how far its read's bytes move, per 64 records a
+            // 64-bit offset at or below theirs (the records hold the low halves)
+            rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec_shift.p), (uint64_t)n_rec * sizeof(uint32_t),
+                            [ro, sh, n](uint64_t off, uint64_t len, uint8_t *out) {
+                uint32_t *o = reinterpret_cast<uint32_t *>(out);
+                const uint64_t j0 = off / sizeof(uint32_t), j1 = (off + len) / sizeof(uint32_t);
+                size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
+                for (; i < n && ro[i] < j1; ++i)
+                    for (uint64_t j = std::max<uint64_t>(ro[i], j0), je = std::min<uint64_t>(ro[i + 1], j1); j < je; ++j) o[j - j0] = sh[i];
+            });
+            if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+            if (rs != CL_OK) return rs;
+            const size_t nb = ((size_t)n_rec + 63) / 64;
+            std::vector<unsigned long long> base(nb);
+            std::atomic<bool> far{false};
+            dut::parallel_for(nb, 4096, [&](size_t b) {
+                const size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)(b * 64)) - ro) - 1;
+                base[b] = hq[i] + sh[i];
+                // the block's last record belongs to read ie: its bytes end within 2^32 of the base
+                const size_t je = std::min<size_t>(b * 64 + 63, (size_t)n_rec - 1);
+                const size_t ie = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)je) - ro) - 1;
+                if (hq[ie + 1] + sh[ie + 1] - base[b] > 0xFFFF0000ull) far.store(true);
+            });
+            if (far.load()) return fail(c, CL_ERR_RANGE, "the quality bytes of 64 consecutive read records span more than 2^32 bytes");
+            HIP_TRY(c, hipMemcpyAsync(c->d_rec_base.p, base.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            hipLaunchKernelGGL(k_repack_qual, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, c->d_rec.p, c->d_rec_shift.p, c->d_rec_base.p,
+                               n_rec, c->d_qual.p + kQualPad, c->d_qual_al.p + kQualPad);
+            HIP_TRY(c, hipGetLastError());
+        }
     }
     tmr.lap("upload: records");
     if (need_cigar && (rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
@@ -1504,6 +1611,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear();
     std::vector<uint32_t>().swap(c->h_rec_of); c->h_wide_rec_of.clear();
+    std::vector<uint32_t>().swap(c->h_shift); std::vector<uint8_t>().swap(c->h_phase);
     give_staging(c);
     std::vector<uint8_t>().swap(c->h_qual);
     tmr.lap("upload: done");

@@ -502,7 +502,11 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
                 for (int j = 0; j < UPL; ++j) {
                     const uint32_t un = u + 4u * j;
                     uu[j] = un < sv.u1 ? un : sv.u1;
+#ifdef CL_X_ALIGNED
+                    __builtin_memcpy(&v[j], reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(qbase + (sv.qoff + (uu[j] << 4))) & ~(uintptr_t)15), 16);   // timing experiment: wrong results
+#else
                     __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
+#endif
                 }
 #pragma unroll
                 for (int j = 0; j < UPL; ++j) {
@@ -1314,6 +1318,36 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
     if (w == n_win - 1 && lane == 0) {                     // the last run ends where classification ends
         const uint32_t last = idx0 + seam + n_inner;
         if (last > 0 && last - 1 < iv_cap) iv[last - 1].end = extent;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_repack_qual (short-read form, once per upload): the quality bytes of every record's run move from where the tile
+// put them to the aligned layout -- each read's string shifted by its running pad so that the first run's bytes for
+// reference positions 16u .. 16u + 15 are one 16-byte aligned block (callable_loci.hip: build_qual_alignment).  A lane
+// quad per record; a record's bytes are written by it alone (runs never overlap in the array), 16 at a time and the tail
+// byte by byte.  rec.qual_lo is the low half of the run's new offset; base[b] <= the offsets of the block's records,
+// within 2^32 of them.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_repack_qual(const ReadRec *__restrict__ rec, const uint32_t *__restrict__ shift,
+                                                         const unsigned long long *__restrict__ base, uint32_t n_rec,
+                                                         const uint8_t *__restrict__ raw, uint8_t *__restrict__ al)
+{
+    const uint32_t j = blockIdx.x * 64u + (threadIdx.x >> 2), ql = threadIdx.x & 3u;
+    if (j >= n_rec) return;
+    const uint4 rr = *reinterpret_cast<const uint4 *>(rec + j);
+    const uint32_t len = rr.w >> 16;
+    if (len == 0u) return;
+    const unsigned long long b = base[blockIdx.x];
+    const unsigned long long dst = b + (uint32_t)(rr.z - (uint32_t)b), src = dst - shift[j];
+    for (uint32_t k = ql * 16u; k < len; k += 64u) {
+        if (len - k >= 16u) {
+            Q16 v;
+            __builtin_memcpy(&v, raw + src + k, 16);
+            __builtin_memcpy(al + dst + k, &v, 16);
+        } else {
+            for (uint32_t i = k; i < len; ++i) al[dst + i] = raw[src + i];
+        }
     }
 }
 

@@ -1151,8 +1151,10 @@ void cl_destroy(cl_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    StageTimer tmr;
     drop_prefetch(c);                                     // its copiers write into d_qual: joined before anything is released
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    tmr.lap("destroy: sync");
     c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
     c->d_qual_off.release(); c->d_qual.release(); c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
@@ -1164,9 +1166,12 @@ void cl_destroy(cl_ctx *c)
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
             for (int i = 0; i <= CL_K_COUNT; ++i) (void)hipEventDestroy(c->ev[s][i]);
+    tmr.lap("destroy: device buffers");
     c->ring.reset();
+    tmr.lap("destroy: staging ring");
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
+    tmr.lap("destroy: stream, context");
 }
 
 const char *cl_last_error(const cl_ctx *c) { return c ? c->err.c_str() : "null context"; }
@@ -1574,6 +1579,14 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
             hipLaunchKernelGGL(k_repack_qual, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, c->d_rec.p, c->d_rec_shift.p, c->d_rec_base.p,
                                n_rec, c->d_qual.p + kQualPad, c->d_qual_al.p + kQualPad);
             HIP_TRY(c, hipGetLastError());
+            // The bytes as pushed and the two upload-only arrays are not read again while this contig is resident.  When
+            // the device is filling up (many resident contexts: a whole genome on one GPU) they are given back now; else
+            // they stay for the next contig (a free + malloc of gigabytes per contig costs more than it saves).
+            size_t fr = 0, tot = 0;
+            if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < tot / 3) {
+                HIP_TRY(c, hipStreamSynchronize(c->stream));
+                c->d_qual.release(); c->d_rec_shift.release(); c->d_rec_base.release();
+            }
         }
     }
     tmr.lap("upload: records");
@@ -1594,8 +1607,10 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_pos.p, c->h_wide_pos.data(), c->n_wide * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
-    HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
-    HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
+    if (c->d_qual.p) {                                   // (given back already when the aligned copy replaced it)
+        HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
+        HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
+    }
     HIP_TRY(c, hipMemsetAsync(c->d_errflag.p, 0, 2 * sizeof(uint32_t), c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     // a read overhanging the contig end makes the reference walk (and classify as REF_N, mod.rs:100-101) positions

@@ -315,7 +315,6 @@ struct cl_ctx {
     // short-read form, aligned quality layout: read i's quality bytes are moved on the device from offset h_qual_off[i]
     // to h_qual_off[i] + h_shift[i] (n + 1 entries; all zero when the layout is not used), see build_qual_alignment
     std::vector<uint32_t> h_shift;
-    std::vector<uint8_t> h_phase;                     // (position - query offset) mod 16 of each read's first M/=/X run
     bool qual_aligned = false;
     std::vector<uint32_t> h_wide_rec_of;   // prefix sums of the wide reads' record counts (n_wide + 1 entries)
     uint32_t n_rec = 0;
@@ -324,6 +323,10 @@ struct cl_ctx {
     // and for reads with more than kLongOps operations the (reference, query) position before every 64th operation
     // of the contig's CIGAR array
     RawVec<uint32_t> h_end, h_ck_x, h_ck_y;
+    // per read, from the same walk: how many records the short-read form gets for it and the phase of its first run
+    // (gen_read_recs); their prefix sums are taken at upload
+    RawVec<uint32_t> h_rec_cnt;
+    RawVec<uint8_t> h_phase;
     uint32_t n_long = 0;                 // reads with more than kLongOps operations
     uint32_t host_err = 0;               // kErrCigar / kErrRange found by that walk (reported by cl_contig_collect)
     uint32_t bounds_err = 0;             // kErrRange raised by the window bounds (reported by cl_contig_collect)
@@ -640,34 +643,20 @@ uint64_t rec_chunk_bytes()
     return n;
 }
 
-// h_rec_of: the prefix sums of the reads' record counts (two parallel sweeps over the staged reads)
+// h_rec_of: the prefix sums of the reads' record counts (counted by cl_push_reads' walk)
 cl_status build_rec_index(cl_ctx *c)
 {
     const size_t n = c->h_pos.size();
     std::vector<uint32_t> &ro = c->h_rec_of;
-    ro.assign(n + 1, 0u);
-    c->h_phase.assign(n + 1, 0);
-    uint8_t *phase = c->h_phase.data();
-    const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
-    const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
-    const uint32_t min_mapq = c->opt.min_mapping_quality;
-    const size_t grain = dut::grain_for(n, 65536), nchunk = n ? (n + grain - 1) / grain : 0;
+    ro.resize(n + 1);
+    ro[0] = 0u;
+    const uint32_t *cnt = c->h_rec_cnt.data();
+    const size_t grain = dut::grain_for(n, 262144), nchunk = n ? (n + grain - 1) / grain : 0;
     std::vector<uint64_t> tot(nchunk + 1, 0);
     dut::parallel_for(nchunk, 1, [&](size_t k) {
         const size_t a = k * grain, b = std::min(n, a + grain);
         uint64_t t = 0;
-        for (size_t i = a; i < b; ++i) {
-            const uint32_t nc = hc[i + 1] - hc[i];
-            const unsigned long long ql = hq[i + 1] - hq[i];
-            uint32_t cnt, ph = 0;
-            // one M/=/X operation as long as the qualities (96 reads in 100 of aligner output): one record, no walk
-            if (nc == 1u && he[i] != (uint32_t)hp[i] && ql < 0x10000ull && ((0x181u >> (hcig[hc[i]] & 15u)) & 1u) && (hcig[hc[i]] >> 4) == ql) {
-                cnt = 1u; ph = hm[i] >= min_mapq ? ((uint32_t)hp[i] & 15u) : 0u;
-            } else cnt = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], nc, hq[i], ql, [](uint32_t, const ReadRec &) {}, &ph);
-            ro[i + 1] = cnt;
-            phase[i] = (uint8_t)ph;
-            t += cnt;
-        }
+        for (size_t i = a; i < b; ++i) t += cnt[i];
         tot[k + 1] = t;
     });
     for (size_t k = 0; k < nchunk; ++k) tot[k + 1] += tot[k];
@@ -675,7 +664,7 @@ cl_status build_rec_index(cl_ctx *c)
     dut::parallel_for(nchunk, 1, [&](size_t k) {
         const size_t a = k * grain, b = std::min(n, a + grain);
         uint32_t run = (uint32_t)tot[k];
-        for (size_t i = a; i < b; ++i) { run += ro[i + 1]; ro[i + 1] = run; }
+        for (size_t i = a; i < b; ++i) { run += cnt[i]; ro[i + 1] = run; }
     });
     c->n_rec = (uint32_t)tot[nchunk];
     return CL_OK;
@@ -1193,6 +1182,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->q_dev = 0;
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->n_long = 0; c->host_err = 0; c->bounds_err = 0;
+    c->h_rec_cnt.clear(); c->h_phase.clear();
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -1326,6 +1316,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
     try {
+        c->h_rec_cnt.reserve(rbase + n); c->h_phase.reserve(rbase + n + 1);
         c->h_end.reserve(rbase + n);                           // entries [rbase, rbase + n) are written below; the
         c->h_ck_x.reserve(((cbase + ncig) >> 6) + 2);          // sizes follow when the tile is accepted (a refused
         c->h_ck_y.reserve(((cbase + ncig) >> 6) + 2);          // tile leaves only unused capacity behind)
@@ -1333,6 +1324,9 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
     uint32_t *const h_end = c->h_end.data() + rbase, *const h_ck_x = c->h_ck_x.data(), *const h_ck_y = c->h_ck_y.data();
+    uint32_t *const h_rec_cnt = c->h_rec_cnt.data() + rbase;
+    uint8_t *const h_phase = c->h_phase.data() + rbase;
+    const uint32_t min_mapq = c->opt.min_mapping_quality;
     dut::parallel_for(nchunk, 1, [&](size_t k) {
         Chunk &o = ch[k];
         const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
@@ -1342,7 +1336,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             if (p < 0 || (uint32_t)p >= c->contig_len) { if (!o.bad) o.bad = 1; }
             else if (p < last) { if (!o.bad) o.bad = 2; }
             last = p;
-            h_end[i] = (uint32_t)p;
+            h_end[i] = (uint32_t)p; h_rec_cnt[i] = 0u; h_phase[i] = 0;
             if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i]) { if (!o.bad) o.bad = 3; continue; }
             if (t->cigar_off[i] < cig0 || t->cigar_off[i + 1] > cig0 + ncig) { if (!o.bad) o.bad = 3; continue; }
             const uint32_t q0i = t->cigar_off[i], q1i = t->cigar_off[i + 1], nops = q1i - q0i;
@@ -1380,6 +1374,17 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             else o.err |= kErrRange;
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
+            // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
+            {
+                const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
+                const uint32_t mq = t->mapq[i];
+                uint32_t cnt, ph = 0;
+                // one M/=/X operation as long as the qualities (96 reads in 100 of aligner output): one record, no walk
+                if (nops == 1u && h_end[i] != (uint32_t)p && ql < 0x10000ull && ((0x181u >> (t->cigar[q0i] & 15u)) & 1u) && (t->cigar[q0i] >> 4) == ql) {
+                    cnt = 1u; ph = mq >= min_mapq ? ((uint32_t)p & 15u) : 0u;
+                } else cnt = gen_read_recs(p, h_end[i], mq, min_mapq, t->cigar + q0i, nops, 0ull, ql, [](uint32_t, const ReadRec &) {}, &ph);
+                h_rec_cnt[i] = cnt; h_phase[i] = (uint8_t)ph;
+            }
         }
     });
     tmr.lap("push: validate + spans");
@@ -1400,6 +1405,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             c->h_cigar_off.resize(n_pos + 1); c->h_qual_off.resize(n_pos + 1);
             c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide); c->n_long = n_long; c->host_err = host_err;
             c->h_end.resize(n_pos); c->h_ck_x.resize((n_cig >> 6) + 2); c->h_ck_y.resize((n_cig >> 6) + 2);
+            c->h_rec_cnt.resize(n_pos); c->h_phase.resize(n_pos);
             c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end;
         }
     } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->n_long, c->host_err, c->has_long, c->span_n, c->span_w, c->host_max_end};
@@ -1412,6 +1418,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
         }
         c->h_end.resize(rbase + n); c->h_ck_x.resize(((cbase + ncig) >> 6) + 2); c->h_ck_y.resize(((cbase + ncig) >> 6) + 2);
+        c->h_rec_cnt.resize(rbase + n); c->h_phase.resize(rbase + n);
         c->h_pos.append(t->pos, n);
         c->h_mapq.append(t->mapq, n);
         c->h_cigar.append(t->cigar + cig0, ncig);
@@ -1514,6 +1521,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         // first (the reads' record ranges are what the windows' candidate ranges index), then built straight into the
         // pinned buffers: a buffer covers a range of record numbers, the reads it belongs to are found by binary search.
         if ((rs = build_rec_index(c)) != CL_OK) return rs;
+        tmr.lap("upload: record index");
         const uint32_t n_rec = c->n_rec;
         HIP_TRY(c, c->d_rec.reserve((size_t)n_rec + 1));
         // the aligned quality layout (build_qual_alignment): its buffer first -- without it the shifts stay zero and
@@ -1529,6 +1537,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
                 c->qual_aligned = false;
             }
         }
+        tmr.lap("upload: alignment index + buffers");
         const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
         const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
         const uint32_t *ro = c->h_rec_of.data(), *sh = c->h_shift.data();
@@ -1549,6 +1558,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         }, rec_chunk_bytes());
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
+        tmr.lap("upload: records built + sent");
         if (c->qual_aligned && n_rec) {
             // what k_repack_qual needs beside the records: per record how far its read's bytes move, per 64 records a
             // 64-bit offset at or below theirs (the records hold the low halves)
@@ -1626,7 +1636,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear();
     std::vector<uint32_t>().swap(c->h_rec_of); c->h_wide_rec_of.clear();
-    std::vector<uint32_t>().swap(c->h_shift); std::vector<uint8_t>().swap(c->h_phase);
+    std::vector<uint32_t>().swap(c->h_shift); c->h_phase.clear(); c->h_rec_cnt.clear();
     give_staging(c);
     std::vector<uint8_t>().swap(c->h_qual);
     tmr.lap("upload: done");

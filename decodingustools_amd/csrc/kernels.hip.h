@@ -1340,14 +1340,16 @@ __global__ __launch_bounds__(kBlock) void k_repack_qual(const ReadRec *__restric
     if (len == 0u) return;
     const unsigned long long b = base[blockIdx.x];
     const unsigned long long dst = b + (uint32_t)(rr.z - (uint32_t)b), src = dst - shift[j];
+    if (len < 16u) {
+        if (ql == 0u) for (uint32_t i = 0; i < len; ++i) al[dst + i] = raw[src + i];
+        return;
+    }
+    // 16 bytes at a time; the last block of a run is moved back to end with the run (bytes written twice get the same value)
     for (uint32_t k = ql * 16u; k < len; k += 64u) {
-        if (len - k >= 16u) {
-            Q16 v;
-            __builtin_memcpy(&v, raw + src + k, 16);
-            __builtin_memcpy(al + dst + k, &v, 16);
-        } else {
-            for (uint32_t i = k; i < len; ++i) al[dst + i] = raw[src + i];
-        }
+        const uint32_t kk = k + 16u <= len ? k : len - 16u;
+        Q16 v;
+        __builtin_memcpy(&v, raw + src + kk, 16);
+        __builtin_memcpy(al + dst + kk, &v, 16);
     }
 }
 

@@ -24,13 +24,16 @@ EL.write_bam_native(out, bam, "chr21", L, rec, threads=int(os.environ.get("E2E_W
 EL.write_fasta(fa, "chr21", ref)
 print(f"wrote {os.path.getsize(bam) / 1e6:.0f} MB BAM in {time.time() - t0:.1f} s", flush=True)
 del rec
+quiet = os.environ.get("E2E_QUIET") == "1"
 for threads in os.environ.get("E2E_THREADS", "16,1").split(","):
-    env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads)
-    for rep in range(2):
-        t0 = time.time()
-        r = subprocess.run([os.environ.get("E2E_CLI", _b.CLI), "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")], cwd=out, env=env, capture_output=True, text=True)
-        dt = time.time() - t0
-        print(f"--- DUT_THREADS={threads} run {rep}: {dt:.2f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)
-        print(r.stderr.strip(), flush=True)
+    for rep in range(int(os.environ.get("E2E_REPS", 2))):
+        for leave in os.environ.get("E2E_LEAVE", "0").split(","):     # DUT_CLI_LEAVE=1: the tool leaves the device context to the exit
+            env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads, DUT_CLI_LEAVE=leave)
+            t0 = time.time()
+            r = subprocess.run([os.environ.get("E2E_CLI", _b.CLI), "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")], cwd=out, env=env, capture_output=True, text=True)
+            dt = time.time() - t0
+            print(f"--- DUT_THREADS={threads} DUT_CLI_LEAVE={leave} run {rep}: {dt:.3f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)
+            if not quiet or rep == 0:
+                print(r.stderr.strip(), flush=True)
 if os.path.exists(os.path.join(out, "o.bed")):
     print(json.dumps(dict(bed_lines=sum(1 for _ in open(os.path.join(out, "o.bed"))))))

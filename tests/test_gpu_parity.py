@@ -1187,3 +1187,56 @@ def test_records_through_small_pinned_buffers(chunk):
     env = dict(os.environ, DUT_REC_CHUNK=chunk)
     r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _REC_CHUNK_CASE], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "REC_CHUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+_NO_ALIGN_CASE = r"""
+import os, sys, tempfile, pathlib
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import test_gpu_parity as T
+from decodingustools_amd import synth
+L, rec, ref = T.record_shapes_contig(L=120_000, n_plain=1500)
+T.compare([("chrS", 4, L, ref, rec)], dict(min_mapping_quality=0), pathlib.Path(tempfile.mkdtemp()), "noalign")
+L = 300_000
+T.compare([("chr21", 20, L, synth.make_reference(L, 7), synth.short_read_contig(L, 30, 8))], dict(), pathlib.Path(tempfile.mkdtemp()), "noalign_s")
+print("NO_ALIGN_OK")
+"""
+
+
+def test_short_read_form_without_the_aligned_quality_layout():
+    """DUT_QUAL_ALIGN=0: the records point at the quality bytes where the tile put them (what the engine also falls back
+    to when the second quality buffer cannot be had) -- same results.  (The switch is read once per process.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUT_QUAL_ALIGN="0")
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _NO_ALIGN_CASE], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "NO_ALIGN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_aligned_layout_over_several_tiles_and_contigs(tmp_path):
+    """The pads of the aligned layout depend on the previous read, across tile seams too; a context that keeps its
+    buffers from one contig to the next (larger, then smaller, then larger) must not read stale bytes: tiled pushes on a
+    long-lived engine give what a single push on a fresh engine gives (which the other tests hold against the oracle)."""
+    opt = CallableOptions()
+    contigs = []
+    for k, (L, depth, seed) in enumerate([(400_000, 30, 11), (90_000, 45, 12), (250_000, 12, 13)]):
+        contigs.append((k, L, synth.make_reference(L, seed + 100), synth.short_read_contig(L, depth, seed)))
+
+    def push(eng, r):
+        eng.push_reads(r.pos, r.mapq, r.cigar_off, r.cigar, r.qual_off, r.qual)
+    want = []
+    for tid, L, ref, rec in contigs:
+        with Engine(opt, 0) as eng:
+            eng.contig_begin(tid, L, ref); push(eng, rec)
+            want.append(eng.contig_finish())
+    with Engine(opt, 0) as eng:
+        for (tid, L, ref, rec), w in zip(contigs, want):
+            eng.contig_begin(tid, L, ref)
+            cuts = [0, 1, 2, 1000, 1001, rec.n // 3, rec.n // 3 + 7, rec.n]      # small tiles are staged, large ones go directly
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                if b > a:
+                    push(eng, rec.slice(a, b))
+            got = eng.contig_finish()
+            assert got.as_dict() == w.as_dict() and np.array_equal(got.intervals, w.intervals), tid
+            eng.contig_run()
+            again = eng.contig_collect()
+            assert again.as_dict() == w.as_dict() and np.array_equal(again.intervals, w.intervals), tid

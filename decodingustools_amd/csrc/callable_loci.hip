@@ -327,6 +327,7 @@ struct cl_ctx {
     // (gen_read_recs); their prefix sums are taken at upload
     RawVec<uint32_t> h_rec_cnt;
     RawVec<uint8_t> h_phase;
+    bool rec_counted = true;           // false: a tile of long-read shape skipped the count (cl_contig_upload makes up for it if the contig gets the short-read form after all)
     uint32_t n_long = 0;                 // reads with more than kLongOps operations
     uint32_t host_err = 0;               // kErrCigar / kErrRange found by that walk (reported by cl_contig_collect)
     uint32_t bounds_err = 0;             // kErrRange raised by the window bounds (reported by cl_contig_collect)
@@ -650,6 +651,19 @@ cl_status build_rec_index(cl_ctx *c)
     std::vector<uint32_t> &ro = c->h_rec_of;
     ro.resize(n + 1);
     ro[0] = 0u;
+    if (!c->rec_counted) {
+        // some tile looked like long reads and skipped the count, yet the contig as a whole gets the short-read form
+        const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
+        const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
+        const uint32_t min_mapq = c->opt.min_mapping_quality;
+        uint32_t *cw = c->h_rec_cnt.data(); uint8_t *pw = c->h_phase.data();
+        dut::parallel_for(n, dut::grain_for(n, 65536), [&](size_t i) {
+            uint32_t ph = 0;
+            cw[i] = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], 0ull, hq[i + 1] - hq[i], [](uint32_t, const ReadRec &) {}, &ph);
+            pw[i] = (uint8_t)ph;
+        });
+        c->rec_counted = true;
+    }
     const uint32_t *cnt = c->h_rec_cnt.data();
     const size_t grain = dut::grain_for(n, 262144), nchunk = n ? (n + grain - 1) / grain : 0;
     std::vector<uint64_t> tot(nchunk + 1, 0);
@@ -1182,7 +1196,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->q_dev = 0;
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->n_long = 0; c->host_err = 0; c->bounds_err = 0;
-    c->h_rec_cnt.clear(); c->h_phase.clear();
+    c->h_rec_cnt.clear(); c->h_phase.clear(); c->rec_counted = true;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -1327,6 +1341,9 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     uint32_t *const h_rec_cnt = c->h_rec_cnt.data() + rbase;
     uint8_t *const h_phase = c->h_phase.data() + rbase;
     const uint32_t min_mapq = c->opt.min_mapping_quality;
+    // (a tile of long-read shape -- 8 or more operations per read -- will not get the short-read form: its reads'
+    // records are not counted here, that would be a second pass over every operation)
+    const bool count_recs = ncig < 8ull * n;
     dut::parallel_for(nchunk, 1, [&](size_t k) {
         Chunk &o = ch[k];
         const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
@@ -1375,7 +1392,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
             // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
-            {
+            if (count_recs) {
                 const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
                 const uint32_t mq = t->mapq[i];
                 uint32_t cnt, ph = 0;
@@ -1419,6 +1436,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         }
         c->h_end.resize(rbase + n); c->h_ck_x.resize(((cbase + ncig) >> 6) + 2); c->h_ck_y.resize(((cbase + ncig) >> 6) + 2);
         c->h_rec_cnt.resize(rbase + n); c->h_phase.resize(rbase + n);
+        if (!count_recs) c->rec_counted = false;
         c->h_pos.append(t->pos, n);
         c->h_mapq.append(t->mapq, n);
         c->h_cigar.append(t->cigar + cig0, ncig);

@@ -1240,3 +1240,28 @@ def test_aligned_layout_over_several_tiles_and_contigs(tmp_path):
             eng.contig_run()
             again = eng.contig_collect()
             assert again.as_dict() == w.as_dict() and np.array_equal(again.intervals, w.intervals), tid
+
+
+def test_a_long_read_shaped_tile_in_a_short_read_contig(tmp_path):
+    """cl_push_reads counts a read's records while it walks its CIGAR -- except in tiles of 8 or more operations per read,
+    which would get a long-read form on their own.  When such a tile is part of a contig that still averages fewer than 8
+    (the short-read form), cl_contig_upload makes up for the count: same results as one push, and as the oracle."""
+    L = 60_000
+    rng = np.random.default_rng(5)
+    reads = [[int(p), "150M", 60, 30, 0, f"a{i}"] for i, p in enumerate(np.sort(rng.integers(0, 40_000, 3000)))]
+    tail = [[int(p), "5M1I5M1D" * 12 + "20M", int(rng.choice([5, 60])), 25, 0, f"b{i}"] for i, p in enumerate(np.sort(rng.integers(40_000, L - 400, 25)))]
+    rec = ContigRecords.from_reads(reads + tail)
+    assert rec.cigar.shape[0] < 8 * rec.n
+    ref = synth.make_reference(L, 6)
+    compare([("chrT", 2, L, ref, rec)], dict(), tmp_path, "mixedtile")
+    opt = CallableOptions()
+
+    def push(eng, r):
+        eng.push_reads(r.pos, r.mapq, r.cigar_off, r.cigar, r.qual_off, r.qual)
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(2, L, ref); push(eng, rec)
+        want = eng.contig_finish()
+        eng.contig_begin(2, L, ref)
+        push(eng, rec.slice(0, len(reads))); push(eng, rec.slice(len(reads), rec.n))     # the second tile: 49 operations per read
+        got = eng.contig_finish()
+    assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)

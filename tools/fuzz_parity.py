@@ -22,7 +22,7 @@ while time.time() < t_end:
                min_mapping_quality=int(rng.choice([0, 1, 10, 30, 61])), min_base_quality=int(rng.choice([0, 1, 13, 20, 40, 127, 128, 129, 200, 255])),
                min_depth_for_low_mapq=int(rng.integers(0, 15)), max_low_mapq=int(rng.choice([0, 1, 5, 60])),
                max_low_mapq_fraction=float(rng.choice([0.0, 0.05, 0.1, 0.5, 0.999])))
-    kind = int(rng.integers(0, 6))
+    kind = int(rng.integers(0, 7))
     L = int(rng.choice([1, 300, 2047, 2048, 2049, 4097, 10_000, 40_000, 100_000]))
     if kind == 0:
         rec = synth.adversarial_contig(L, int(rng.integers(0, 1500)), seed, max_len=int(rng.choice([2, 50, 300, 3000])) if L > 1 else 1,
@@ -39,11 +39,17 @@ while time.time() < t_end:
     elif kind == 4:
         L = max(L, 10_000)
         rec = T._stacked_multi_op_reads(int(rng.integers(50, 2500)), min(3000, L // 3), min(9000, L - 200), seed, long_every=int(rng.integers(3, 15)))
+    elif kind == 6:
+        # every shape the record builder of the short-read form distinguishes (leading clips, > 65 535-base runs, wide
+        # reads, truncated and absent quality strings), at a random size and seed
+        L, rec, ref6 = T.record_shapes_contig(L=int(rng.choice([20_000, 70_000, 150_000])), seed=seed, n_plain=int(rng.integers(100, 4000)), short_form=False)   # (few plain reads: the same shapes through a long-read form)
     else:
         L = max(L, 2048)
         a = synth.short_read_contig(L, 20, seed, max_live_assert=100_000)
         rec = a
     ref = synth.make_reference(L, seed + 1, lowercase=bool(rng.integers(0, 2))) if rng.random() < 0.9 else None
+    if kind == 6 and ref is not None:
+        ref = ref6
     with tempfile.TemporaryDirectory() as d:
         T.compare([(f"f{seed}", int(rng.integers(0, 3)), L, ref, rec)], opt, pathlib.Path(d), f"fuzz{seed}")
     print(f"round {rnd} seed {seed} kind {kind} L {L} reads {rec.n} ok", flush=True)

@@ -1015,6 +1015,45 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
             if (rs != CL_OK) return rs;
             tr.lap("upload: run table (walk + H2D)");
         }
+        // DUT_VALIDATE=1 (tooling: tools/fuzz_parity.py sets it): what the kernels will index is checked on the host before
+        // anything is launched -- candidate ranges against the resident arrays, and every entry of the run table (read
+        // back from the device) against the quality array -- so that a bad index is an error message, not a GPU fault
+        static const bool validate = [] { const char *e = getenv("DUT_VALIDATE"); return e && *e == '1'; }();
+        if (validate && !(flags & kErrRange)) {
+            const uint64_t n_cand = c->form == 0 ? c->n_rec : c->h_pos.size();
+            uint64_t n_wide_list = c->h_wide_idx.size();
+            if (c->form == 0 && !c->h_wide_rec_of.empty()) n_wide_list = c->h_wide_rec_of.back();
+            std::vector<uint2> tab;
+            if (c->form == 2 && c->n_runtab) {
+                tab.resize(c->n_runtab);
+                HIP_TRY(c, hipMemcpy(tab.data(), c->d_runtab.p, c->n_runtab * sizeof(uint2), hipMemcpyDeviceToHost));
+            }
+            const uint64_t qend = c->n_qual + 2 * (uint64_t)kQualPad;
+            for (uint32_t w = 0; w < c->n_win; ++w) {
+                const WinMeta &m = win[w];
+                char msg[256];
+                if (m.lo > m.hi || m.hi > n_cand || (uint64_t)m.wlo + m.wn > n_wide_list) {
+                    snprintf(msg, sizeof(msg), "validate: window %u: candidates [%u, %u) of %llu, wide [%u, +%u) of %llu", w, m.lo, m.hi, (unsigned long long)n_cand, m.wlo, m.wn, (unsigned long long)n_wide_list);
+                    return fail(c, CL_ERR_DEVICE, msg);
+                }
+                if (c->form != 2) continue;
+                if ((uint64_t)m.rlo + m.rn > c->n_runtab) {
+                    snprintf(msg, sizeof(msg), "validate: window %u: run table entries [%u, +%u) of %llu", w, m.rlo, m.rn, (unsigned long long)c->n_runtab);
+                    return fail(c, CL_ERR_DEVICE, msg);
+                }
+                for (uint32_t i = 0; i < m.rn; ++i) {
+                    const uint2 d = tab[(size_t)m.rlo + i];
+                    const uint32_t sr = d.y & 2047u, er = (d.y >> 11) & 2047u, u0 = sr >> 4, u1 = er >> 4;
+                    // the kernel adds the unit's 16 u to x in 32 bits and that to the window's base (allocation-relative: q0)
+                    const unsigned long long off = m.q0 + (uint32_t)(d.x + (u1 << 4)) + 16ull;   // end of the last byte it loads for the entry
+                    if (!(d.y >> 31) || er < sr || u1 > u0 + 1u || off > qend || m.q0 + (uint32_t)(d.x + (u0 << 4)) + 16ull > qend) {
+                        snprintf(msg, sizeof(msg), "validate: window %u entry %u: x %u y 0x%08x (start %u end-1 %u), q0 %llu: loads up to byte %llu of %llu",
+                                 w, i, d.x, d.y, sr, er, (unsigned long long)m.q0, off, (unsigned long long)qend);
+                        return fail(c, CL_ERR_DEVICE, msg);
+                    }
+                }
+            }
+        }
         if (c->n_win) HIP_TRY(c, hipMemcpyAsync(c->d_win.p, win.data(), (size_t)c->n_win * sizeof(WinMeta), hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         // a window with more candidates than the 16-bit counters / differences hold: the 32-bit form from the start

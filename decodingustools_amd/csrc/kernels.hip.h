@@ -576,14 +576,17 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
             const uint2 *ent = a.runtab + wm.rlo;
             const uint32_t nent = CL_ABL(2u) ? 0u : wm.rn;
             // (every load of the loop is unconditional -- an index past the end is clamped and its entry marked invalid --:
-            // behind a load in a conditional block hipcc waits for vmcnt(0))
+            // behind a load in a conditional block hipcc waits for vmcnt(0).  A clamped lane keeps the last entry's start
+            // and end and only loses the valid bit: its two quality loads then go where that entry's go.  With the
+            // whole word cleared they went to unit 0 of the window, up to 2 047 bytes in front of the entry's bytes -- in
+            // front of the quality array itself when the window's last piece belongs to the contig's first read.)
             auto fetch = [&](uint32_t b, uint2 (&d)[E]) {
 #pragma unroll
                 for (int j = 0; j < E; ++j) {
                     const uint32_t idx = b + (uint32_t)j * kBlock + tid;
                     const bool in = idx < nent;
                     d[j] = ent[in ? idx : nent - 1u];
-                    d[j].y = in ? d[j].y : 0u;
+                    d[j].y = in ? d[j].y : (d[j].y & 0x7FFFFFFFu);
                 }
             };
             uint2 d[E], dn[E];

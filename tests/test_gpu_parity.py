@@ -1265,3 +1265,17 @@ def test_a_long_read_shaped_tile_in_a_short_read_contig(tmp_path):
         push(eng, rec.slice(0, len(reads))); push(eng, rec.slice(len(reads), rec.n))     # the second tile: 49 operations per read
         got = eng.contig_finish()
     assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
+
+
+def test_run_table_window_whose_last_piece_belongs_to_the_first_read(tmp_path):
+    """Found by tools/fuzz_parity.py (seed 300026): a sparse long-read contig whose first window holds pieces of the
+    contig's FIRST read only, starting 865 positions into the window.  The lanes behind a window's last entry repeat
+    that entry with the valid bit cleared; when they cleared the whole word instead, their (unused) quality loads went to
+    unit 0 of the window -- 865 bytes in front of the quality array: a memory access fault when that page is not mapped."""
+    L = 40_000
+    rec = _eqx_split(synth.long_read_contig(L, 5, 300026), 300026)
+    assert rec.cigar.shape[0] >= 8 * rec.n and rec.qual.shape[0] < 56 * rec.cigar.shape[0] and int(rec.pos[0]) > 64
+    ref = synth.make_reference(L, 300027)
+    compare([("chrF", 1, L, ref, rec)], dict(min_depth=4, max_depth=0, min_mapping_quality=1, min_base_quality=255, min_depth_for_low_mapq=5,
+                                             max_low_mapq=1, max_low_mapq_fraction=0.5), tmp_path, "fuzz300026")
+    compare([("chrF", 1, L, ref, rec)], dict(), tmp_path, "fuzz300026b")

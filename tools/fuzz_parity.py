@@ -11,6 +11,7 @@ import test_gpu_parity as T
 from decodingustools_amd import synth
 from decodingustools_amd.records import ContigRecords
 
+os.environ.setdefault("DUT_VALIDATE", "1")      # the engine checks what its kernels will index before it launches them
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 100_000
 t_end = time.time() + budget

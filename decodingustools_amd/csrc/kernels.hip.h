@@ -502,11 +502,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
                 for (int j = 0; j < UPL; ++j) {
                     const uint32_t un = u + 4u * j;
                     uu[j] = un < sv.u1 ? un : sv.u1;
-#ifdef CL_X_ALIGNED
-                    __builtin_memcpy(&v[j], reinterpret_cast<const uint8_t *>(reinterpret_cast<uintptr_t>(qbase + (sv.qoff + (uu[j] << 4))) & ~(uintptr_t)15), 16);   // timing experiment: wrong results
-#else
                     __builtin_memcpy(&v[j], qbase + (sv.qoff + (uu[j] << 4)), 16);
-#endif
                 }
 #pragma unroll
                 for (int j = 0; j < UPL; ++j) {

@@ -337,9 +337,6 @@ struct cl_ctx {
     // device residents
     DevBuf<int32_t> d_pos;
     DevBuf<uint8_t> d_mapq;
-    DevBuf<uint32_t> d_cigar_off;
-    DevBuf<uint32_t> d_cigar;
-    DevBuf<unsigned long long> d_qual_off;
     DevBuf<uint8_t> d_qual;
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
@@ -357,7 +354,6 @@ struct cl_ctx {
     DevBuf<WinPartial> d_winpart;
     DevBuf<FinPartial> d_fin;
     DevBuf<uint32_t> d_errflag;        // [0] error bits raised by the kernels of a run, [1] unused
-    DevBuf<uint32_t> d_ck_x, d_ck_y;
     DevBuf<uint2> d_runtab;            // run-table form: the windows' match pieces (host_build_runs)
     uint64_t n_runtab = 0;
     DevBuf<uint32_t> d_lut;
@@ -561,18 +557,17 @@ cl_status harvest_events(cl_ctx *c)
 }
 
 // which form of k_pileup a resident contig gets: by its shape, decided once at upload and kept in the context
-// (kernels.hip.h: LONG = 0 short reads, 1 long match runs, 2 the run table)
+// (kernels.hip.h: LONG = 0 records (short reads), 2 the run table (long reads))
 int pick_form(const cl_ctx *c)
 {
     int form = 0;
-    // long-read shape (8 or more CIGAR operations per read on average): no lane-serial CIGAR walk ...
-    if (c->n_reads && c->n_cigar >= 8ull * c->n_reads) {
-        // ... with short runs (operations average < 56 bases -- the measured crossover lies between 50 and 70): the
-        // host's walk leaves a table of match pieces per window; else a wave takes 64 operations of a read at a time
-        form = c->n_qual < 56ull * c->n_cigar ? 2 : 1;
-    }
+    // long-read shape (8 or more CIGAR operations per read on average): the host's walk leaves a table of match pieces
+    // per window (the run-table form).  It also wins where the operation-parallel form of rounds 1-2 was used -- long
+    // match runs, HiFi-like: 0.157 against 0.292 ms at 20 Mb with 800-base runs, 0.185 against 0.382 with 150-base runs
+    // (profiles/r03_hifi_forms.txt) --, so every long-read shape gets it.
+    if (c->n_reads && c->n_cigar >= 8ull * c->n_reads) form = 2;
 #ifdef CL_TUNING
-    if (const char *fl = getenv("CL_FORCE_LONG")) { const int f = atoi(fl); if (f == 0 || f == 1 || f == 2) form = f; }
+    if (const char *fl = getenv("CL_FORCE_LONG")) { const int f = atoi(fl); if (f == 0 || f == 2) form = f; }
 #endif
     return form;
 }
@@ -580,8 +575,7 @@ int pick_form(const cl_ctx *c)
 Reads device_reads(const cl_ctx *c)
 {
     Reads R;
-    R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.cigar_off = c->d_cigar_off.p; R.cigar = c->d_cigar.p;
-    R.qual_off = c->d_qual_off.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
+    R.pos = c->d_pos.p; R.mapq = c->d_mapq.p; R.qual = c->d_qual.p + kQualPad; R.n = c->n_reads;
     return R;
 }
 
@@ -1080,7 +1074,7 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     // (the ORF template parameter once selected a shorter threshold test for min_base_quality <= 128; one form
     // serves every threshold now and only ORF = true is instantiated)
 #define CL_LAUNCH(DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
-#define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else if (c->form == 1) CL_LAUNCH(DEEP_, 1); else CL_LAUNCH(DEEP_, 0); } while (0)
+#define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else CL_LAUNCH(DEEP_, 0); } while (0)
     // the 32-bit counter variant is used only when the window bounds asked for it (kNeedDeep)
     if (!c->deep) CL_LAUNCH_L(false); else CL_LAUNCH_L(true);
 #undef CL_LAUNCH_L
@@ -1108,7 +1102,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (c->form == 0 && c->qual_aligned) a.R.qual = c->d_qual_al.p + kQualPad;     // the aligned layout (k_repack_qual)
  a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
     a.wide_idx = c->d_wide_idx.p;
-    a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.ck_x = c->d_ck_x.p; a.ck_y = c->d_ck_y.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
+    a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
     if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
@@ -1197,13 +1191,13 @@ void cl_destroy(cl_ctx *c)
     drop_prefetch(c);                                     // its copiers write into d_qual: joined before anything is released
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     tmr.lap("destroy: sync");
-    c->d_pos.release(); c->d_mapq.release(); c->d_cigar_off.release(); c->d_cigar.release();
-    c->d_qual_off.release(); c->d_qual.release(); c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
+    c->d_pos.release(); c->d_mapq.release();
+    c->d_qual.release(); c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
     c->d_wide_idx.release(); c->d_wide_pos.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_lut.release(); c->d_summary.release();
-    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_ck_x.release(); c->d_ck_y.release(); c->d_runtab.release(); c->site.release();
+    c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_runtab.release(); c->site.release();
     for (int i = 0; i < 2; ++i) if (c->site_ev[i]) (void)hipEventDestroy(c->site_ev[i]);
     if (c->ev_made)
         for (int s = 0; s < cl_ctx::kEvSets; ++s)
@@ -1532,17 +1526,10 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     const int form = c->form;
     StageTimer tmr0;
     // What the device needs of the per-read fields depends on the form of k_pileup the contig gets: the short-read form
-    // reads one packed record per read (and the ends of its reads with more than kLongOps operations); the long-read
-    // forms read the arrays as pushed, and every read's end.
-    // The run-table form reads neither CIGARs nor offsets: pos, mapq and end of the windows' candidates, and the table
-    // that the walk in size_for_extent() builds from the staged CIGARs.
-    const bool need_soa = form == 1, need_cigar = form == 1;
+    // reads records (built below) and nothing else per read; the run-table form pos, mapq and end of the windows'
+    // candidates, and the table that the walk in size_for_extent() builds from the staged CIGARs.  No form reads a CIGAR
+    // or an offset array: neither is uploaded.
     HIP_TRY(c, c->d_end.reserve(n + 1));
-    if (need_cigar) {
-        HIP_TRY(c, c->d_cigar.reserve(c->n_cigar + 8));      // four words are loaded at a read's first op
-        HIP_TRY(c, c->d_ck_x.reserve((c->n_cigar >> 6) + 2));
-        HIP_TRY(c, c->d_ck_y.reserve((c->n_cigar >> 6) + 2));
-    }
     HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
@@ -1558,19 +1545,8 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if ((rs = ring_copy(c, c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_mapq.p, c->h_mapq.data(), n)) != CL_OK) return rs;
     }
-    if (need_soa) {
-        HIP_TRY(c, c->d_cigar_off.reserve(n + 1));
-        HIP_TRY(c, c->d_qual_off.reserve(n + 1));
-        if ((rs = ring_copy(c, c->d_cigar_off.p, c->h_cigar_off.data(), (n + 1) * sizeof(uint32_t))) != CL_OK) return rs;
-        if ((rs = ring_copy(c, c->d_qual_off.p, c->h_qual_off.data(), (n + 1) * sizeof(unsigned long long))) != CL_OK) return rs;
-    }
     if (form != 0)
         if ((rs = ring_copy(c, c->d_end.p, c->h_end.data(), n * sizeof(uint32_t))) != CL_OK) return rs;
-    if (c->n_long && need_cigar) {                           // entries of operations inside other reads are never read
-        const size_t nck = (c->n_cigar >> 6) + 1;
-        if ((rs = ring_copy(c, c->d_ck_x.p, c->h_ck_x.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
-        if ((rs = ring_copy(c, c->d_ck_y.p, c->h_ck_y.data(), nck * sizeof(uint32_t))) != CL_OK) return rs;
-    }
     c->h_rec_of.clear(); c->h_wide_rec_of.clear(); c->n_rec = 0;
     if (form == 0) {
         // the records of the short-read form (kernels.hip.h: ReadRec): the host's walk over the CIGARs, so that the
@@ -1657,8 +1633,6 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         }
     }
     tmr.lap("upload: records");
-    if (need_cigar && (rs = ring_copy(c, c->d_cigar.p, c->h_cigar.data(), c->n_cigar * sizeof(uint32_t))) != CL_OK) return rs;
-    tmr.lap("upload: cigar");
     std::vector<uint32_t> wide_rec;                      // short-read form: the wide reads' records, read by read
     if (c->n_wide && form == 0) {
         c->h_wide_rec_of.assign(c->n_wide + 1, 0u);

@@ -5,11 +5,11 @@
 //   (host, at upload: per window of T reference positions the [lo,hi) range of candidates that can touch it -- an
 //                    index of the resident layout, like the offsets; WinMeta below)
 //   (host, at upload, in the one walk over every CIGAR that validates a tile: every read's end, and for reads of
-//                    more than kLongOps operations a (reference, query) checkpoint before every 64th operation --
-//                    an index over the CIGARs, like the window records)
+//                    more than kLongOps operations a (reference, query) checkpoint before every 64th operation, where
+//                    the host's later walks enter such a read)
 //   (host, at upload: short-read contigs become 16-byte RECORDS, a head per read and a piece per further M/=/X run
-//                    (ReadRec); indel-rich long-read contigs a table of match pieces per window (run table) -- in both
-//                    forms k_pileup decodes no CIGAR)
+//                    (ReadRec); long-read contigs a table of match pieces per window (run table) -- k_pileup decodes
+//                    no CIGAR in either form, and no CIGAR is uploaded)
 //   k_pileup<T>      one workgroup per window: the three per-position counters of
 //                    process_position (mod.rs:17-42) are built in LDS (never in HBM), classified
 //                    (callable_profiler.rs:100-116) and reduced to the window's run list (the
@@ -29,7 +29,7 @@ namespace clk {
 
 constexpr int kBlock = 256;          // threads per workgroup (4 waves)
 constexpr uint32_t kLongOps = 64;    // reads with more CIGAR ops get a checkpoint (reference, query position) before
-                                     // every 64th op (op numbering of the contig's CIGAR array), built on the host
+                                     // every 64th op (op numbering of the contig's CIGAR array): host side only
 constexpr int kQualPad = 32;         // bytes of padding in front of / behind the quality array
 constexpr uint32_t kWideSpan = 16384; // reads spanning more reference than this are "wide": looked up per window
                                       // in their own list instead of widening every window's candidate range
@@ -83,11 +83,8 @@ struct Opts {
 };
 
 struct Reads {
-    const int32_t  *pos;
+    const int32_t  *pos;        // run-table form: the windows' candidates (+-1 span scatter, owner sums)
     const uint8_t  *mapq;
-    const uint32_t *cigar_off;
-    const uint32_t *cigar;
-    const unsigned long long *qual_off;
     const uint8_t  *qual;       // points kQualPad bytes into the allocation
     uint32_t n;
 };
@@ -213,12 +210,11 @@ struct PileupArgs {
     Reads R;
     Opts o;
     const ReadRec *rec;           // the records of the short-read form (it reads these and nothing else per read)
-    const uint32_t *end;          // per read, from the host (long-read forms)
+    const uint32_t *end;          // per read, from the host (run-table form)
     const WinMeta *win;
     const uint32_t *wide_idx;           // read indices of the wide reads, ascending
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
-    const uint32_t *ck_x, *ck_y;  // CIGAR checkpoints of long reads (host)
     const uint2    *runtab;       // run-table form (LONG = 2): per window, the M/=/X pieces of its reads (host, at upload)
     uint8_t        *state;        // n_win*T bytes; written by the DEBUG instantiation only (test dumps)
     uint16_t       *runs;         // per window T entries: the run starts strictly inside the window, rel. position | state << 12
@@ -257,17 +253,14 @@ struct PileupArgs {
 // Candidates are dealt to waves round-robin (candidate = base + 4*lane + wave): a wave's list holds every fourth
 // read, and consecutive candidates alternate between the two 8-bit counter sets.
 //
-// LONG = 1 (contigs with >= 8 CIGAR operations per read on average and long match runs, HiFi-like): the one form that
-// still decodes CIGARs on the device, operation-parallel -- live reads are compacted, a wave takes 64 operations of a
-// read at a time, two DPP scans give every operation its reference / query start, each lane consumes its own M/=/X
-// run (runs longer than 64 bases go through the list and the quad loop).
-//
-// LONG = 2 (the run-table form; what a contig with short match runs gets): no CIGAR is decoded on the device at
-// all.  The host's walk over the CIGARs at upload leaves, per window, a flat table of the M/=/X pieces of its reads --
+// LONG = 2 (the run-table form; what a contig with 8 or more CIGAR operations per read gets -- indel-rich ONT-like
+// reads and HiFi-like long match runs alike; the operation-parallel form that decoded CIGARs on the device, LONG = 1 of
+// rounds 1-3, lost to it on both and is gone): the host's walk over the CIGARs at upload leaves, per window, a flat
+// table of the M/=/X pieces of its reads --
 // 8 bytes each: {quality offset, window-relative start | end - 1 | counter set}, a piece never longer than two
 // 16-position units, reads below min_mapq already dropped -- and the kernel streams its window's entries coalesced,
 // one entry per lane, two entries and four quality loads in flight per lane.  The +-1 span scatter and the owner sums
-// take pos / end / mapq of the window's candidates as in the other long-read forms.
+// take pos / end / mapq of the window's candidates.
 //
 // DEEP = false: 8/16-bit counters and 16-bit differences; valid while the window has <= 32767 candidates
 // (otherwise host_window_bounds raises kNeedDeep and the contig runs with DEEP = true: one
@@ -371,13 +364,13 @@ __device__ __forceinline__ SegView seg_view(uint2 d, uint32_t ql)
 #endif
 
 template <int T, bool DEBUG, bool ORF, bool DEEP, int LONG>
-__global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
+__global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(PileupArgs a)
 {
     constexpr int PER = T / kBlock;                 // positions per thread in the final phase
     static_assert(PER == 8 || PER == 4, "T must be 2048 or 1024");
     constexpr int kWaves = kBlock / 64;
-    constexpr int kSegRound = 2;                    // segments a lane may emit per round
-    constexpr int kListCap = LONG == 2 ? 1 : (LONG == 0 ? 64 + 16 : 64 * kSegRound + 16);   // entries of one wave's list (+ carried-over entries)
+    static_assert(LONG == 0 || LONG == 2, "forms of k_pileup: 0 records (short reads), 2 run table (long reads)");
+    constexpr int kListCap = LONG == 2 ? 1 : 64 + 16;   // entries of one wave's list: a pass's 64 + the < 16 carried over
     constexpr uint32_t kLutLds = 256;
     // +-1 differences of raw_depth / low_mapq_count.  DEEP: one 32-bit word per position.  Otherwise two
     // positions per word as 16-bit halves: the low half is biased by 0x8000 so that adding -1 (a
@@ -397,9 +390,6 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
     // per-wave totals: cnt[6], n_cov, sum_qc, sum_q, n_inner.  (Same-address LDS atomics are avoided:
     // hipcc turns them into a scalar loop over the active lanes.)
     __shared__ unsigned long long s_wtot[kWaves][12];          // [10], [11]: sums of the reads the window owns (LONG = 0)
-    // LONG: the live reads of a pass, two entries each: {candidate number, op index, x, y}, {op end, quality offset, quality length, -}
-    __shared__ __attribute__((aligned(16))) uint4 s_live[LONG == 1 ? 2 * kBlock : 1];
-    __shared__ uint32_t s_nlive;
 
     // XCD-aware window order: blocks b, b+8, b+16.. share an XCD (round-robin dispatch), give
     // each XCD one contiguous range of windows so neighbouring windows share its L2.
@@ -709,223 +699,6 @@ __global__ __launch_bounds__(kBlock, (DEEP || LONG == 1) ? 4 : CL_MINWAVES) void
             if (n_full && lane < n_keep) list[lane] = carry;
             sumq += sq32; sq32 = 0;
         }
-    } else
-    for (uint32_t base = 0; base < (CL_ABL(2u) ? 0u : n_cand); base += kBlock) {
-        const uint32_t v = base + 4u * lane + wv;   // candidate number; consecutive candidates alternate counter sets
-        uint32_t r = lo + (v - wn);
-        if (v < wn) r = a.wide_idx[wlo + v];
-        __builtin_assume(r < (1u << 29));           // the host refuses contigs with >= 2^29 reads
-        bool live = false;
-        uint32_t x = 0, y = 0, k = 0, k1 = 0, qrel = 0, qlen = 0;
-        unsigned long long own_len = 0, own_mq = 0;  // separable sums of the reads this window owns (this pass)
-        if (v < n_cand) {
-            uint32_t e, mq;
-            x = (uint32_t)a.R.pos[r];
-            e = a.end[r]; mq = a.R.mapq[r];
-            if (x >= W) {                                    // the window that holds the read's start owns its sums
-                own_len = e - x;
-                own_mq = mq >= a.o.min_mapq ? (unsigned long long)mq * (e - x) : 0ull;
-            }
-            k = a.R.cigar_off[r];
-            k1 = a.R.cigar_off[r + 1];
-            const unsigned long long q0 = a.R.qual_off[r], q1 = a.R.qual_off[r + 1];
-            qrel = (uint32_t)(q0 - qwin);
-            qlen = (q1 - q0) > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(q1 - q0);
-            if (e > W) {
-                const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
-                uint32_t ib, vb, ie, ve2;            // word index and addend of the +1 and of the -1
-                if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
-                else {
-                    ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
-                    ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
-                }
-                atomicAdd(&s_raw[ib], vb);
-                if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
-                if (mq <= a.o.max_low_mapq) {
-                    atomicAdd(&s_low[ib], vb);
-                    if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
-                }
-                live = mq >= a.o.min_mapq && k < k1;
-            }
-            if (live && k1 - k > kLongOps && x < W) {
-                // long read that starts before the window: jump to the last checkpoint at or before W
-                const uint32_t jlo = (k + 63u) >> 6, jhi = (k1 - 1u) >> 6;
-                if (jlo <= jhi && a.ck_x[jlo] <= W) {
-                    uint32_t lo_j = jlo, hi_j = jhi;                 // invariant: ck_x[lo_j] <= W
-                    while (lo_j < hi_j) {
-                        const uint32_t mid = lo_j + ((hi_j - lo_j + 1u) >> 1);
-                        if (a.ck_x[mid] <= W) lo_j = mid; else hi_j = mid - 1u;
-                    }
-                    k = lo_j << 6; x = a.ck_x[lo_j]; y = a.ck_y[lo_j];
-                }
-            }
-        }
-        win_len += wave_sum_u64(own_len); win_mq += wave_sum_u64(own_mq);
-        {
-            // ---- long-read shape: CIGAR operations in parallel.  The live reads of the pass are
-            //      compacted into s_live; a wave takes a read and 64 of its operations at a time (one
-            //      coalesced load), two wave scans give every operation its reference / query start,
-            //      and each lane consumes its own M/=/X run (runs longer than 64 bases go through
-            //      the wave's list and the quad loop above).  No lane-serial CIGAR walk. ----
-            if (tid == 0) s_nlive = 0;
-            __syncthreads();
-            {
-                const unsigned long long lm = __ballot(live);
-                uint32_t wb = 0;
-                if (lane == 0 && lm) wb = atomicAdd(&s_nlive, (uint32_t)__popcll(lm));
-                wb = __shfl(wb, 0, 64);
-                if (live) {
-                    const uint32_t idx = wb + __builtin_amdgcn_mbcnt_hi((uint32_t)(lm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)lm, 0u));
-                    s_live[2u * idx] = make_uint4(v, k, x, y);
-                    s_live[2u * idx + 1u] = make_uint4(k1, qrel, qlen, 0u);
-                }
-            }
-            __syncthreads();
-            const uint32_t nl = s_nlive;
-            for (uint32_t it = wv; it < nl; it += (uint32_t)kWaves) {
-                const uint4 A = s_live[2u * it], B = s_live[2u * it + 1u];
-                uint32_t rk = A.y, rx = A.z, ry = A.w;
-                const uint32_t rk1 = B.x, rqrel = B.y, rqlen = B.z;
-                const uint32_t rset = (A.x & 1u) << 30;
-                // LONG = 1 (long match runs, HiFi): a wave takes a read and 64 of its operations at a time, one per
-                // lane; every run goes through the list anyway, and the four-operation form above costs a wave of
-                // occupancy.  (The loop is written for kOpl operations per lane; only kOpl = 1 is instantiated.)
-                constexpr uint32_t kOpl = 1u;
-                auto load_ops = [&](uint32_t kb, uint32_t (&wd)[kOpl]) {
-                    const uint32_t kl = kb + kOpl * lane;
-                    if constexpr (kOpl == 1u) {
-                        wd[0] = kl < rk1 ? a.R.cigar[kl] : 5u;               // beyond the read: H, advances nothing
-                    } else {
-                        Q16 t;
-                        t.w[0] = 5u; t.w[1] = 5u; t.w[2] = 5u; t.w[3] = 5u;
-                        if (kl < rk1) __builtin_memcpy(&t, a.R.cigar + kl, 16);  // at most 12 bytes past the read's words
-#pragma unroll
-                        for (uint32_t j = 0; j < kOpl; ++j) wd[j] = (kl + j) < rk1 ? t.w[j] : 5u;
-                    }
-                };
-                auto unit = [&](const Q16 &v, uint32_t u, uint32_t srel, uint32_t trel) {
-                    const uint32_t ps = u << 4;
-                    const uint32_t vs = srel > ps ? srel - ps : 0u;
-                    const uint32_t ve = (trel - ps) < 16u ? (trel - ps) : 16u;
-                    const uint4 ms = s_mstart[vs], me = s_mend[ve];
-                    const uint4 vm = make_uint4(ms.x & me.x, ms.y & me.y, ms.z & me.z, ms.w & me.w);
-                    if (DEEP) sq32 += apply_unit32<ORF>(v, vm, u, s_qcw, a.o);
-                    else if (mode8) sq32 += apply_unit8<ORF>(v, vm, u, (rset >> 30) * (uint32_t)(T / 8), reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                    else sq32 += apply_unit16<ORF>(v, vm, u, reinterpret_cast<unsigned long long *>(s_qcw), a.o);
-                };
-                uint32_t cw_next[kOpl];
-                load_ops(rk, cw_next);
-                while (rk < rk1 && rx < Wend) {                      // wave-uniform
-                    uint32_t cwl[kOpl];
-#pragma unroll
-                    for (uint32_t j = 0; j < kOpl; ++j) cwl[j] = cw_next[j];
-                    load_ops(rk + 64u * kOpl, cw_next);              // the next block is requested before this one is scanned
-                    uint32_t ax[kOpl], ay[kOpl], tx = 0, ty = 0;
-#pragma unroll
-                    for (uint32_t j = 0; j < kOpl; ++j) {
-                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
-                        ax[j] = ((0x18Du >> op) & 1u) ? l : 0u;
-                        ay[j] = ((0x193u >> op) & 1u) ? l : 0u;
-                        tx += ax[j]; ty += ay[j];
-                    }
-                    const uint32_t ix = dpp_incl_scan_u32(tx), iy = dpp_incl_scan_u32(ty);
-                    uint32_t xs = rx + (ix - tx), ys = ry + (iy - ty);
-                    // the lane's first two short runs (A, B) are consumed together below; a third or fourth
-                    // (rare: two indels in a row are rarer than M-indel-M) and runs > 64 bases at once
-                    uint32_t a_st = 0, a_q = 0, b_st = 0, b_q = 0, ns = 0;
-                    auto run_direct = [&](uint32_t sr, uint32_t tr, uint32_t q) {
-                        const uint32_t qb = q + (uint32_t)kQualPad - sr;
-                        for (uint32_t u = sr >> 4; u <= (tr - 1u) >> 4; ++u) {
-                            Q16 v;
-                            __builtin_memcpy(&v, qbase + (qb + (u << 4)), 16);
-                            unit(v, u, sr, tr);
-                        }
-                    };
-#pragma unroll
-                    for (uint32_t j = 0; j < kOpl; ++j) {
-                        const uint32_t op = cwl[j] & 15u, l = cwl[j] >> 4;
-                        const bool ism = ((0x181u >> op) & 1u) != 0u;
-                        const uint32_t xe = xs + ax[j];
-                        const uint32_t sp = xs > W ? xs : W;
-                        const uint32_t lq = ys < rqlen ? ((rqlen - ys) < l ? (rqlen - ys) : l) : 0u;
-                        uint32_t tp = xe < Wend ? xe : Wend;
-                        tp = (xs + lq) < tp ? (xs + lq) : tp;
-                        const bool valid = ism && sp < tp && !(CL_ABL(1u));
-                        const uint32_t sr = sp - W, tr = tp - W;
-                        const uint32_t q = rqrel + ys + (sp - xs);    // quality offset of the run's first counted base
-                        const bool big = valid && (tr - sr) > 64u;
-                        xs = xe; ys += ay[j];
-                        if (valid && !big) {
-                            if (ns == 0u) { a_st = sr | (tr << 16); a_q = q; }
-                            else if (ns == 1u) { b_st = sr | (tr << 16); b_q = q; }
-                            else run_direct(sr, tr, q);
-                            ns += 1u;
-                        }
-                        const unsigned long long bm = __ballot(big);
-                        if (bm) {                                    // wave-uniform: long runs go through the list
-                            if (big) {
-                                const uint32_t idx = n_keep + __builtin_amdgcn_mbcnt_hi((uint32_t)(bm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bm, 0u));
-                                list[idx] = make_uint2(q, sr | ((tr - sr - 1u) << 16) | rset | 0x80000000u);
-                            }
-                            const uint32_t n_list = n_keep + (uint32_t)__popcll(bm);
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            const uint32_t n_full = n_list & ~15u;
-                            if (n_full) consume_list(n_full);
-                            n_keep = n_list - n_full;
-                            uint2 carry = make_uint2(0u, 0u);
-                            if (n_full && lane < n_keep) carry = list[n_full + lane];
-                            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                            __builtin_amdgcn_wave_barrier();
-                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                            if (n_full && lane < n_keep) list[lane] = carry;
-                        }
-                    }
-                    // the first two units of A and of B are requested together (a ~15-base run covers one or two)
-                    {
-                        const uint32_t a_sr = a_st & 0xFFFFu, a_tr = a_st >> 16, b_sr = b_st & 0xFFFFu, b_tr = b_st >> 16;
-                        const uint32_t a_qb = a_q + (uint32_t)kQualPad - a_sr, b_qb = b_q + (uint32_t)kQualPad - b_sr;
-                        const uint32_t a_u0 = a_sr >> 4, a_u1 = ns >= 1u ? (a_tr - 1u) >> 4 : 0u;
-                        const uint32_t b_u0 = b_sr >> 4, b_u1 = ns >= 2u ? (b_tr - 1u) >> 4 : 0u;
-                        Q16 va0, va1, vb0, vb1;
-                        if (ns >= 1u) {
-                            __builtin_memcpy(&va0, qbase + (a_qb + (a_u0 << 4)), 16);
-                            __builtin_memcpy(&va1, qbase + (a_qb + ((a_u0 + 1u <= a_u1 ? a_u0 + 1u : a_u0) << 4)), 16);
-                        }
-                        if (ns >= 2u) {
-                            __builtin_memcpy(&vb0, qbase + (b_qb + (b_u0 << 4)), 16);
-                            __builtin_memcpy(&vb1, qbase + (b_qb + ((b_u0 + 1u <= b_u1 ? b_u0 + 1u : b_u0) << 4)), 16);
-                        }
-                        if (ns >= 1u) {
-                            unit(va0, a_u0, a_sr, a_tr);
-                            if (a_u0 + 1u <= a_u1) unit(va1, a_u0 + 1u, a_sr, a_tr);
-                        }
-                        if (ns >= 2u) {
-                            unit(vb0, b_u0, b_sr, b_tr);
-                            if (b_u0 + 1u <= b_u1) unit(vb1, b_u0 + 1u, b_sr, b_tr);
-                        }
-                        if (ns >= 1u)
-                            for (uint32_t u = a_u0 + 2u; u <= a_u1; ++u) {
-                                Q16 v;
-                                __builtin_memcpy(&v, qbase + (a_qb + (u << 4)), 16);
-                                unit(v, u, a_sr, a_tr);
-                            }
-                        if (ns >= 2u)
-                            for (uint32_t u = b_u0 + 2u; u <= b_u1; ++u) {
-                                Q16 v;
-                                __builtin_memcpy(&v, qbase + (b_qb + (u << 4)), 16);
-                                unit(v, u, b_sr, b_tr);
-                            }
-                    }
-                    rx += (uint32_t)__builtin_amdgcn_readlane((int)ix, 63);
-                    ry += (uint32_t)__builtin_amdgcn_readlane((int)iy, 63);
-                    rk += 64u * kOpl;
-                }
-            }
-            __syncthreads();                                         // s_live is rewritten by the next pass
-        }
-        sumq += sq32; sq32 = 0;
     }
     if (n_keep) {                                   // flush what the last round left over
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

@@ -625,7 +625,8 @@ def test_hifi_like_long_match_runs_and_truncated_qualities(tmp_path):
     """Reads of 8-20 kb with few, kilobase-long M runs (segments that span whole windows and need
     several trips), plus reads whose quality array is shorter than the CIGAR's query length (the
     reference's `qual().get(qpos)` is None beyond it) and reads with exactly 64 / 65 CIGAR ops
-    (either side of the checkpointing threshold)."""
+    (either side of the checkpointing threshold).  The shape that used to select the operation-parallel form; every
+    long-read shape gets the run-table form now."""
     L = 120_000
     rng = np.random.default_rng(77)
     reads = []
@@ -820,8 +821,8 @@ def _stacked_multi_op_reads(n, start_lo, start_hi, seed, long_every=0):
 
 
 def test_operation_parallel_variant_with_16bit_and_32bit_counters(tmp_path):
-    """The long-read shaped kernel variant on windows with more than 510 candidates (16-bit counter
-    fields) and with more than 32 767 (32-bit re-run)."""
+    """A long-read shaped contig (the run-table form; until round 3 the operation-parallel one, hence the name) on
+    windows deeper than 255 (16-bit counter fields) and with more than 32 767 candidates (32-bit re-run)."""
     L = 12_000
     ref = synth.make_reference(L, 41)
     rec = _stacked_multi_op_reads(2500, 3000, 3900, 42, long_every=7)     # deeper than 255: the 16-bit fields are needed

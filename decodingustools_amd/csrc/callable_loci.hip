@@ -346,7 +346,6 @@ struct cl_ctx {
     DevBuf<unsigned long long> d_rec_base;   // per 64 records: a 64-bit quality offset at or below theirs (upload only)
     DevBuf<uint32_t> d_win_off, d_wide_idx;
     DevBuf<WinMeta> d_win;
-    DevBuf<int32_t> d_wide_pos;
     DevBuf<uint8_t> d_state;         // per-position states: allocated and written for debug dumps only
     DevBuf<uint16_t> d_runs;         // per window kT entries: run starts inside the window
     DevBuf<uint8_t> d_first_state, d_last_state;
@@ -1194,7 +1193,7 @@ void cl_destroy(cl_ctx *c)
     c->d_pos.release(); c->d_mapq.release();
     c->d_qual.release(); c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
-    c->d_wide_idx.release(); c->d_wide_pos.release();
+    c->d_wide_idx.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
     c->d_winpart.release(); c->d_lut.release(); c->d_summary.release();
     c->d_iv.release(); c->d_dbg.release(); c->d_fin.release(); c->d_errflag.release(); c->d_runtab.release(); c->site.release();
@@ -1532,7 +1531,6 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, c->d_end.reserve(n + 1));
     HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
-    HIP_TRY(c, c->d_wide_pos.reserve(c->n_wide + 1));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     tmr0.lap("upload: device buffers");
     StageTimer tmr;
@@ -1646,7 +1644,6 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
             HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, wide_rec.data(), wide_rec.size() * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     } else if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipMemcpyAsync(c->d_wide_pos.p, c->h_wide_pos.data(), c->n_wide * sizeof(int32_t), hipMemcpyHostToDevice, c->stream));
     }
     if (c->d_qual.p) {                                   // (given back already when the aligned copy replaced it)
         HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));

@@ -115,6 +115,8 @@ SYMBOLS = [
     ("cl_reset_kernel_ms", C.c_int, [C.c_void_p]),
     ("cl_contig_bytes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cl_debug_depths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
+    ("cl_debug_read_records", C.c_int, [C.c_int32, C.c_void_p, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint64, C.c_uint64,
+                                        C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     ("cl_site_pileup", C.c_int, [C.c_void_p, C.c_uint8, C.c_uint32, C.c_uint64, C.POINTER(cl_site_tile),
                                  C.c_void_p, C.c_size_t, C.c_void_p]),
     ("cl_site_upload", C.c_int, [C.c_void_p, C.c_uint32, C.c_uint64, C.POINTER(cl_site_tile)]),

@@ -1681,6 +1681,26 @@ cl_status cl_contig_upload(cl_ctx *c)
 }
 
 
+cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_ops, uint8_t mapq, uint8_t min_mapping_quality,
+                                uint64_t qual_off, uint64_t qual_len, uint32_t *out, uint32_t cap,
+                                uint32_t *n_records, uint32_t *phase)
+{
+    if ((n_ops && !cigar) || (cap && !out) || !n_records) return CL_ERR_INVALID;
+    // the read's end as cl_push_reads' walk takes it: pos + bam_cigar2rlen, the read spanning nothing beyond the range
+    unsigned long long l = 0;
+    for (uint32_t q = 0; q < n_ops; ++q) if ((0x18Du >> (cigar[q] & 15u)) & 1u) l += cigar[q] >> 4;
+    if (pos < 0) return CL_ERR_INVALID;
+    const uint32_t end = l <= 0xFFFF0000ull - (uint64_t)pos ? (uint32_t)((uint64_t)pos + l) : (uint32_t)pos;
+    uint32_t ph = 0;
+    const uint32_t n = gen_read_recs(pos, end, mapq, min_mapping_quality, cigar, n_ops, qual_off, qual_len,
+                                     [&](uint32_t k, const ReadRec &r) {
+                                         if (k < cap) { out[4 * k] = (uint32_t)r.pos; out[4 * k + 1] = r.span; out[4 * k + 2] = r.qual_lo; out[4 * k + 3] = r.meta; }
+                                     }, &ph);
+    *n_records = n;
+    if (phase) *phase = ph;
+    return CL_OK;
+}
+
 cl_status cl_contig_run(cl_ctx *c)
 {
     Range rg("cl_contig_run");

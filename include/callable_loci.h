@@ -176,6 +176,18 @@ cl_status cl_contig_bytes(cl_ctx *ctx, uint64_t *input_bytes, uint64_t *output_b
 cl_status cl_debug_depths(cl_ctx *ctx, uint32_t *raw, uint32_t *qc, uint32_t *low,
                           uint8_t *state, uint64_t cap);
 
+/* The records the short-read form of the pileup kernel reads for ONE read (host code only, no device needed): what the
+ * upload walk makes of a read at `pos` with the given CIGAR, mapping quality and quality-string length, the quality
+ * bytes starting at offset `qual_off` -- a head {pos, span, qual offset of its run, mapq | 0x100 | run length << 16}
+ * and a piece {pos of the run, 0, qual offset, mapq | run length << 16} per further M/=/X run (mod.rs:22-37: the read is
+ * in every column of its span, the bases of its match operations that have a quality byte are tested).  Writes up to
+ * `cap` records of four 32-bit words each to `out`, the count to *n_records (also when it exceeds cap) and the
+ * phase (reference position - query offset of the first run, mod 16) to *phase.  Reads below min_mapping_quality get
+ * the head alone; a read without a reference span gets no record. */
+cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_ops, uint8_t mapq, uint8_t min_mapping_quality,
+                                uint64_t qual_off, uint64_t qual_len, uint32_t *out, uint32_t cap,
+                                uint32_t *n_records, uint32_t *phase);
+
 /* ---- config 5: site-list pileup (haplogroup::caller::process_region,
  *      src/haplogroup/caller.rs:62-152) ---------------------------------------------------- */
 typedef struct cl_site_tile {

@@ -37,6 +37,12 @@ class cl_interval(C.Structure):
     _fields_ = [("start", C.c_uint32), ("end", C.c_uint32), ("state", C.c_uint32)]
 
 
+class cl_layout_info(C.Structure):
+    _fields_ = [("form", C.c_int32), ("counter_planes", C.c_uint32), ("n_reads", C.c_uint64), ("n_records", C.c_uint64),
+                ("n_windows", C.c_uint64), ("n_qual", C.c_uint64), ("n_cigar", C.c_uint64), ("row_groups", C.c_uint64),
+                ("max_groups", C.c_uint64), ("run_table_entries", C.c_uint64), ("device_bytes", C.c_uint64)]
+
+
 class cl_site_tile(C.Structure):
     _fields_ = [("n_reads", C.c_uint64), ("pos", C.c_void_p), ("mapq", C.c_void_p),
                 ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
@@ -114,6 +120,11 @@ SYMBOLS = [
     ("cl_get_kernel_ms", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     ("cl_reset_kernel_ms", C.c_int, [C.c_void_p]),
     ("cl_contig_bytes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("cl_contig_layout", C.c_int, [C.c_void_p, C.POINTER(cl_layout_info)]),
+    ("cl_debug_qual_pack", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint8, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),
+    ("cl_debug_host_create", C.c_int, [C.POINTER(cl_options), C.POINTER(C.c_void_p)]),
+    ("cl_debug_pass_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
+                                     C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
     ("cl_debug_depths", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64]),
     ("cl_debug_read_records", C.c_int, [C.c_int32, C.c_void_p, C.c_uint32, C.c_uint8, C.c_uint8, C.c_uint64, C.c_uint64,
                                         C.c_void_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

@@ -12,12 +12,13 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libcallable_hip.so")
-SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "host_coverage.cpp"),
+SOURCES = [os.path.join(CSRC, "callable_loci.hip"), os.path.join(CSRC, "qual_pack.cpp"), os.path.join(CSRC, "host_coverage.cpp"),
            os.path.join(CSRC, "bam_io.cpp"), os.path.join(CSRC, "report.cpp"),
            os.path.join(CSRC, "haplogroup.cpp")]
 CLI = os.path.join(LIBDIR, "dut-coverage")
 CLI_SRC = os.path.join(CSRC, "coverage_main.cpp")
 HEADERS = [os.path.join(CSRC, "kernels.hip.h"), os.path.join(CSRC, "host_parallel.h"),
+           os.path.join(CSRC, "qual_pack.h"), os.path.join(CSRC, "pass_rows.h"),
            os.path.join(HERE, "..", "include", "callable_loci.h"),
            os.path.join(HERE, "..", "include", "dut_coverage.h"),
            os.path.join(HERE, "..", "include", "dut_bam.h"),

@@ -179,6 +179,12 @@ class Engine:
         self._check(self._lib.cl_contig_bytes(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def contig_layout(self):
+        """What is resident for the uploaded contig (cl_layout_info as a dict)."""
+        li = _lib.cl_layout_info()
+        self._check(self._lib.cl_contig_layout(self._h, C.byref(li)))
+        return {k: int(getattr(li, k)) for k, _ in li._fields_}
+
     def debug_depths(self, extent):
         raw = np.zeros(extent, np.uint32); qc = np.zeros(extent, np.uint32)
         low = np.zeros(extent, np.uint32); st = np.zeros(extent, np.uint8)
@@ -219,6 +225,34 @@ class Engine:
         ms = C.c_double(); b = C.c_uint64()
         self._check(self._lib.cl_site_pileup_stats(self._h, C.byref(ms), C.byref(b)))
         return ms.value, b.value
+
+
+class HostStage(Engine):
+    """A context WITHOUT a device (cl_debug_host_create), for the CPU test suite: contig_begin / push_reads stage a
+    contig exactly as a device context does, `pass_rows` runs the upload's row builder over it.  Everything that needs a
+    device raises: there is no CPU pileup."""
+
+    def __init__(self, options: CallableOptions):
+        self._lib = _lib.load()
+        self.options = options
+        self._opt_c = options.to_c()
+        h = C.c_void_p()
+        st = self._lib.cl_debug_host_create(C.byref(self._opt_c), C.byref(h))
+        if st != 0:
+            raise EngineError(st, "cl_debug_host_create failed")
+        self._h = h
+        self.device_id = -1
+        self._keep = []
+
+    def pass_rows(self):
+        """(n_groups per window, rows as uint32 array of 256-word groups window after window, summed_baseq)."""
+        nwords = C.c_uint64(); nwin = C.c_uint32(); sq = C.c_uint64()
+        self._check(self._lib.cl_debug_pass_rows(self._h, None, 0, None, 0, C.byref(nwords), C.byref(nwin), C.byref(sq)))
+        ng = np.zeros(max(nwin.value, 1), np.uint32)
+        rows = np.zeros(max(nwords.value, 1), np.uint32)
+        self._check(self._lib.cl_debug_pass_rows(self._h, _ptr(ng), nwin.value, _ptr(rows), nwords.value, C.byref(nwords),
+                                                 C.byref(nwin), C.byref(sq)))
+        return ng[:nwin.value], rows[:nwords.value], int(sq.value)
 
 
 @dataclass

@@ -5,6 +5,8 @@
 #include "../../include/callable_loci.h"
 #include "kernels.hip.h"
 #include "host_parallel.h"
+#include "qual_pack.h"
+#include "pass_rows.h"
 
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
@@ -295,6 +297,8 @@ struct cl_ctx {
     // host staging of the current contig
     bool in_contig = false, uploaded = false, ran = false;
     bool deep = false;               // this contig needs the 32-bit counter variant of k_pileup
+    bool bits = true;                // the pass-bit form (default); DUT_QUAL_FORM=bytes at cl_create: the byte forms
+    bool host_only = false;          // cl_debug_host_create: staging and the row builder only, for the CPU test suite
     int form = 0;                    // the form of k_pileup the resident contig gets (pick_form, at upload)
     uint32_t tune_ablate = 0;        // CL_TUNING builds: CL_ABLATE, read once at cl_create
     bool has_long = false;           // some read has more than kLongOps CIGAR ops (its checkpoints are in h_ck_x / h_ck_y)
@@ -312,10 +316,6 @@ struct cl_ctx {
     std::vector<uint32_t> h_wide_idx;
     // short-read form: read i's records are rec[h_rec_of[i] .. h_rec_of[i + 1]) (built at upload, gen_read_recs)
     std::vector<uint32_t> h_rec_of;
-    // short-read form, aligned quality layout: read i's quality bytes are moved on the device from offset h_qual_off[i]
-    // to h_qual_off[i] + h_shift[i] (n + 1 entries; all zero when the layout is not used), see build_qual_alignment
-    std::vector<uint32_t> h_shift;
-    bool qual_aligned = false;
     std::vector<uint32_t> h_wide_rec_of;   // prefix sums of the wide reads' record counts (n_wide + 1 entries)
     uint32_t n_rec = 0;
     std::vector<int32_t> h_wide_pos;
@@ -323,10 +323,15 @@ struct cl_ctx {
     // and for reads with more than kLongOps operations the (reference, query) position before every 64th operation
     // of the contig's CIGAR array
     RawVec<uint32_t> h_end, h_ck_x, h_ck_y;
-    // per read, from the same walk: how many records the short-read form gets for it and the phase of its first run
-    // (gen_read_recs); their prefix sums are taken at upload
+    // per read, from the same walk: how many records the record forms get for it (gen_read_recs); their prefix sums
+    // are taken at upload
     RawVec<uint32_t> h_rec_cnt;
-    RawVec<uint8_t> h_phase;
+    // pass-bit form (the default): bit g = quality byte g of the contig passes min_base_quality (mod.rs:33), taken in
+    // cl_push_reads' walk; and, from the same walk, the sum of the passing qualities over the M/=/X bases of the reads
+    // with mapq >= min_mapping_quality (contig_profiler.rs:65-70: summed_baseq is per-read separable)
+    RawVec<uint64_t> h_qbits;
+    uint64_t host_sum_q = 0;         // of the contig being pushed
+    uint64_t dev_sum_q = 0;          // of the resident contig (handed to the summary workgroup of every run)
     bool rec_counted = true;           // false: a tile of long-read shape skipped the count (cl_contig_upload makes up for it if the contig gets the short-read form after all)
     uint32_t n_long = 0;                 // reads with more than kLongOps operations
     uint32_t host_err = 0;               // kErrCigar / kErrRange found by that walk (reported by cl_contig_collect)
@@ -341,9 +346,9 @@ struct cl_ctx {
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
     DevBuf<ReadRec> d_rec;           // the records of the short-read form of k_pileup
-    DevBuf<uint8_t> d_qual_al;       // short-read form: the quality bytes in the aligned layout (k_repack_qual)
-    DevBuf<uint32_t> d_rec_shift;    // per record: how far its read's quality bytes move (upload only)
-    DevBuf<unsigned long long> d_rec_base;   // per 64 records: a 64-bit quality offset at or below theirs (upload only)
+    DevBuf<uint4> d_rows;            // pass-bit form: the windows' rows, groups of 4 rows x 64 blocks (1 KB each)
+    uint64_t n_row_groups = 0;
+    uint32_t max_groups = 0;         // most groups of any window: picks the number of counter planes of k_pileup_rows
     DevBuf<uint32_t> d_win_off, d_wide_idx;
     DevBuf<WinMeta> d_win;
     DevBuf<uint8_t> d_state;         // per-position states: allocated and written for debug dumps only
@@ -559,6 +564,7 @@ cl_status harvest_events(cl_ctx *c)
 // (kernels.hip.h: LONG = 0 records (short reads), 2 the run table (long reads))
 int pick_form(const cl_ctx *c)
 {
+    if (c->bits) return 3;           // the pass-bit form: head records + rows, whatever the reads' shape
     int form = 0;
     // long-read shape (8 or more CIGAR operations per read on average): the host's walk leaves a table of match pieces
     // per window (the run-table form).  It also wins where the operation-parallel form of rounds 1-2 was used -- long
@@ -624,6 +630,31 @@ inline uint32_t gen_read_recs(int32_t pos, uint32_t end, uint32_t mq, uint32_t m
     return k;
 }
 
+// A read's share of summed_baseq (contig_profiler.rs:65-70): the sum of the quality bytes that pass min_base_quality
+// over the bases of its M/=/X operations that have a quality byte (q[0, ql): the read's quality string).  Reads of few
+// operations: run by run; reads of many (long reads, a run every ~15 bases): the whole string minus the inserted and
+// clipped bases, so that the vector loop sees long stretches.
+inline uint64_t read_pass_sum(const uint8_t *q, unsigned long long ql, const uint32_t *cig, uint32_t nops, uint8_t thr, int level)
+{
+    unsigned long long y = 0;
+    uint64_t sum = 0;
+    if (nops <= 8u) {
+        for (uint32_t j = 0; j < nops; ++j) {
+            const uint32_t cw = cig[j], op = cw & 15u, l = cw >> 4;
+            if ((0x181u >> op) & 1u) { if (y < ql) sum += dut::qual_pass_sum(q + y, std::min<unsigned long long>(ql - y, l), thr, level); y += l; }
+            else if ((0x193u >> op) & 1u) y += l;
+        }
+        return sum;
+    }
+    uint64_t minus = 0;
+    for (uint32_t j = 0; j < nops; ++j) {
+        const uint32_t cw = cig[j], op = cw & 15u, l = cw >> 4;
+        if ((0x181u >> op) & 1u) y += l;
+        else if ((0x193u >> op) & 1u) { if (y < ql) minus += dut::qual_pass_sum(q + y, std::min<unsigned long long>(ql - y, l), thr, 0); y += l; }
+    }
+    return dut::qual_pass_sum(q, std::min<unsigned long long>(ql, y), thr, level) - minus;
+}
+
 // bytes of read records per pinned buffer (DUT_REC_CHUNK: a test hook that puts the buffer seams inside the records of
 // one read with small inputs; a multiple of the record size; read once)
 uint64_t rec_chunk_bytes()
@@ -649,11 +680,9 @@ cl_status build_rec_index(cl_ctx *c)
         const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
         const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
         const uint32_t min_mapq = c->opt.min_mapping_quality;
-        uint32_t *cw = c->h_rec_cnt.data(); uint8_t *pw = c->h_phase.data();
+        uint32_t *cw = c->h_rec_cnt.data();
         dut::parallel_for(n, dut::grain_for(n, 65536), [&](size_t i) {
-            uint32_t ph = 0;
-            cw[i] = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], 0ull, hq[i + 1] - hq[i], [](uint32_t, const ReadRec &) {}, &ph);
-            pw[i] = (uint8_t)ph;
+            cw[i] = gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], 0ull, hq[i + 1] - hq[i], [](uint32_t, const ReadRec &) {});
         });
         c->rec_counted = true;
     }
@@ -677,57 +706,13 @@ cl_status build_rec_index(cl_ctx *c)
     return CL_OK;
 }
 
-// The aligned quality layout of the short-read form.  k_pileup applies units of 16 reference positions = 16 quality
-// bytes per lane; as the reads lie in the pushed array those 16 bytes start at any byte address, and a wave's
-// byte-unaligned 16-byte loads cost the vector memory pipe 66 cycles where 16-byte aligned ones cost 38-51
-// (profiles/r03_ubench_memory_pipe.txt; the kernel is 7 % faster with aligned addresses).  So the bytes are moved once,
-// on the device at upload (k_repack_qual), each read's string to an offset congruent mod 16 to the phase of its first
-// run: read i goes from h_qual_off[i] to h_qual_off[i] + h_shift[i], h_shift = the running sum of the pads (0..15 bytes
-// per read, 7.5 on average: +5 % of HBM for the qualities).  pad_i = (phase_i - phase_(i-1) - len_(i-1)) mod 16 needs
-// the neighbours only, so the sum is two parallel sweeps.  Not used (all shifts zero) when the pads would pass 2^32.
-void build_qual_alignment(cl_ctx *c)
-{
-    const size_t n = c->h_pos.size();
-    c->h_shift.assign(n + 1, 0u);
-    c->qual_aligned = false;
-    if (n == 0) return;
-    static const bool off = [] { const char *e = getenv("DUT_QUAL_ALIGN"); return e && *e == '0'; }();   // (A/B switch)
-    if (off) return;
-    const uint8_t *ph = c->h_phase.data(); const unsigned long long *hq = c->h_qual_off.data();
-    uint32_t *sh = c->h_shift.data();
-    const size_t grain = dut::grain_for(n, 65536), nchunk = (n + grain - 1) / grain;
-    std::vector<uint64_t> tot(nchunk + 1, 0);
-    auto pad_of = [&](size_t i) -> uint32_t {
-        if (i == 0) return (uint32_t)((ph[0] - hq[0]) & 15ull);
-        return (uint32_t)(((unsigned long long)ph[i] - ph[i - 1] - (hq[i] - hq[i - 1])) & 15ull);
-    };
-    dut::parallel_for(nchunk, 1, [&](size_t k) {
-        const size_t a = k * grain, b = std::min(n, a + grain);
-        uint64_t t = 0;
-        for (size_t i = a; i < b; ++i) t += pad_of(i);
-        tot[k + 1] = t;
-    });
-    for (size_t k = 0; k < nchunk; ++k) tot[k + 1] += tot[k];
-    if (tot[nchunk] >= 0xFFFFFF00ull) return;
-    dut::parallel_for(nchunk, 1, [&](size_t k) {
-        const size_t a = k * grain, b = std::min(n, a + grain);
-        uint32_t run = (uint32_t)tot[k];
-        for (size_t i = a; i < b; ++i) { run += pad_of(i); sh[i] = run; }
-    });
-    sh[n] = (uint32_t)tot[nchunk];
-    c->qual_aligned = true;
-}
-
 // The windows' candidate ranges: an index of the resident reads (binary searches over the sorted positions), built on
 // the host at upload -- where the positions still are -- instead of in every run (round 1 ran the same rules as a
 // device function in front of every pileup launch; the parity tests hold the results of this one against the oracle).
-void host_window_bounds(const cl_ctx *c, const std::vector<uint32_t> &wro_v, std::vector<WinMeta> &win, uint32_t &flags)
+void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &flags)
 {
     const uint32_t n = (uint32_t)c->h_pos.size(), n_wide = (uint32_t)c->h_wide_pos.size();
     const int32_t *pos = c->h_pos.data(), *wpos = c->h_wide_pos.data();
-    static const uint32_t kZero[1] = {0u};
-    const uint32_t *wro = wro_v.empty() ? kZero : wro_v.data();      // (no wide read: wlo = wn = 0 everywhere)
-    const uint32_t *sh = (c->form == 0 && c->h_shift.size() == (size_t)n + 1) ? c->h_shift.data() : nullptr;
     auto lb = [](const int32_t *p, uint32_t cnt, long long key) {
         return (uint32_t)(std::lower_bound(p, p + cnt, key, [](int32_t v, long long k) { return (long long)v < k; }) - p);
     };
@@ -744,24 +729,35 @@ void host_window_bounds(const cl_ctx *c, const std::vector<uint32_t> &wro_v, std
             m.wn = lb(wpos, n_wide, W - (long long)c->span_n + 1) - m.wlo;
         }
         const uint32_t first = m.wn ? c->h_wide_idx[m.wlo] : m.lo;      // lo <= n: the offsets array has n + 1 entries
-        // (short-read form: the offsets of the aligned layout, build_qual_alignment; zero shifts when it is not used)
-        const unsigned long long qf = c->h_qual_off[first] + (sh ? sh[first] : 0u), qh = c->h_qual_off[m.hi] + (sh ? sh[m.hi] : 0u);
+        const unsigned long long qf = c->h_qual_off[first], qh = c->h_qual_off[m.hi];
         m.q0 = qf; m.rlo = 0; m.rn = 0;
-        // k_pileup addresses the quality bytes of a window with 32-bit offsets
-        if (m.hi > first && qh - qf > 0xFFFF0000ull) fl.fetch_or(kErrRange);
-        if (c->form == 0) {
-            // the short-read form's candidates are records: those of the reads [lo, hi) lie side by side, the wide reads'
-            // are listed in wide_rec (wro: the prefix sums of the wide reads' record counts)
+        // the byte forms of k_pileup address the quality bytes of a window with 32-bit offsets
+        if (!c->bits && m.hi > first && qh - qf > 0xFFFF0000ull) fl.fetch_or(kErrRange);
+        win[w] = m;
+    });
+    flags = fl.load();
+}
+
+// ... and, once the host's walks over the reads of the windows are done (run table, rows: they index reads), the ranges as
+// the kernel wants them: the record forms' candidates are records -- those of the reads [lo, hi) lie side by side, the
+// wide reads' are listed in wide_rec (wro: the prefix sums of the wide reads' record counts).
+void finish_windows(const cl_ctx *c, const std::vector<uint32_t> &wro_v, std::vector<WinMeta> &win, uint32_t &flags)
+{
+    static const uint32_t kZero[1] = {0u};
+    const uint32_t *wro = wro_v.empty() ? kZero : wro_v.data();      // (no wide read: wlo = wn = 0 everywhere)
+    std::atomic<uint32_t> fl{0};
+    dut::parallel_for(c->n_win, 4096, [&](size_t w) {
+        WinMeta &m = win[w];
+        if (c->form != 2) {
             const uint32_t *ro = c->h_rec_of.data();
             m.lo = ro[m.lo]; m.hi = ro[m.hi];
             const uint32_t w1 = wro[m.wlo + m.wn];
             m.wlo = wro[m.wlo]; m.wn = w1 - m.wlo;
         }
-        // more candidates than the 16-bit counters / differences of k_pileup can hold: the 32-bit variant is needed
+        // more candidates than the 16-bit differences of the pileup kernels can hold: the 32-bit variant is needed
         if ((m.hi - m.lo) + m.wn > 32767u) fl.fetch_or(kNeedDeep);
-        win[w] = m;
     });
-    flags = fl.load();
+    flags |= fl.load();
 }
 
 
@@ -969,6 +965,153 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
     return fail(c, CL_ERR_DEVICE, "run table: the second sizing pass did not fit");
 }
 
+// groups of rows per pinned buffer (DUT_ROW_CHUNK: a test hook that makes the buffer-full and oversized-window paths
+// reachable with small inputs; read once)
+size_t row_chunk_groups()
+{
+    static const size_t n = [] {
+        const char *e = getenv("DUT_ROW_CHUNK");
+        const size_t full = PinRing::kPinBytes / (dut::kRowGroupWords * sizeof(uint32_t));
+        const size_t v = e ? (size_t)strtoull(e, nullptr, 0) : full;
+        return v < 1 ? 1 : (v > full ? full : v);
+    }();
+    return n;
+}
+
+dut::RowReads row_reads(const cl_ctx *c)
+{
+    dut::RowReads H;
+    H.pos = c->h_pos.data(); H.end = c->h_end.data(); H.mapq = c->h_mapq.data();
+    H.cigar_off = c->h_cigar_off.data(); H.cigar = c->h_cigar.data(); H.qual_off = c->h_qual_off.data();
+    H.bits = c->h_qbits.data(); H.ck_x = c->h_ck_x.data(); H.ck_y = c->h_ck_y.data();
+    H.min_mapq = c->opt.min_mapping_quality;
+    return H;
+}
+
+// The pass-bit rows of the resident contig (pass_rows.h), built by one more walk over the staged CIGARs at upload and
+// streamed to HBM the way the run table is: a thread takes a range of windows and sweeps it with a list of read cursors;
+// the groups of a window are written straight into the pinned buffers of the staging ring, a buffer leaves when the
+// next window no longer fits, buffers are placed in the device array in the order they fill (a window only needs its
+// own groups contiguous: its record holds their index).  win[w].rlo / rn = first group / number of groups.
+cl_status stream_rows(cl_ctx *c, std::vector<WinMeta> &win)
+{
+    const uint32_t n_win = c->n_win;
+    const dut::RowReads H = row_reads(c);
+    const uint32_t *wide_idx = c->h_wide_idx.data();
+    c->n_row_groups = 0; c->max_groups = 0;
+    if (n_win == 0) return CL_OK;
+    cl_status s = ensure_pins(c);
+    if (s != CL_OK) return s;
+    const int nt = std::max(1, std::min<int>(PinRing::kCopyThreads, dut::worker_threads()));
+    const size_t per = std::max<size_t>(16, (size_t)n_win / (8 * (size_t)nt) + 1);
+    const size_t ntasks = ((size_t)n_win + per - 1) / per;
+    const size_t capG = row_chunk_groups();
+    constexpr size_t GW = dut::kRowGroupWords;
+    // the device array: an estimate first (rows ~ 1.7 x the mean depth, a quarter of that in groups, one group of
+    // rounding per window); a contig that needs more tells how much
+    uint64_t want = (c->n_qual / kT) * 17 / 40 + (uint64_t)n_win + 1024;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(c, hipSetDevice(c->device));
+        HIP_TRY(c, c->d_rows.reserve(want * (GW / 4)));
+        uint32_t *const d_tab = reinterpret_cast<uint32_t *>(c->d_rows.p);
+        const uint64_t dev_cap = c->d_rows.cap / (GW / 4);              // groups
+        std::atomic<uint64_t> dev_next{0};
+        std::atomic<size_t> next_task{0};
+        std::atomic<uint32_t> max_groups{0};
+        PinRing *R = c->ring.get();
+        R->acquire(c);
+        c->ring_held = true;
+        if (!R->ensure_slots(nt)) { (void)ring_finish(c); return fail(c, CL_ERR_DEVICE, "cannot extend the pinned staging ring (hipHostMalloc)"); }
+        for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
+        for (int t = 0; t < nt; ++t) {
+            c->copiers.push_back(dut::spawn_or_run([&, t]() {
+                hipError_t err = hipSetDevice(c->device);
+                int kb = 0;                                                  // buffers this thread has sent
+                auto cur_buf = [&]() { return reinterpret_cast<uint32_t *>(R->pin[t][kb & 1]); };
+                auto send = [&](uint32_t *dst, size_t groups) {              // the current buffer leaves; on to the other one
+                    if (err != hipSuccess) return;
+                    err = hipMemcpyAsync(dst, cur_buf(), groups * GW * sizeof(uint32_t), hipMemcpyHostToDevice, R->copy_stream[t]);
+                    if (err == hipSuccess) err = hipEventRecord(R->pin_ev[t][kb & 1], R->copy_stream[t]);
+                    ++kb;
+                    if (kb >= 2 && err == hipSuccess) err = hipEventSynchronize(R->pin_ev[t][kb & 1]);   // its previous transfer is done
+                };
+                std::vector<dut::RowCur> act, save;
+                std::vector<uint32_t> in_buf;                                // windows whose groups lie in the current buffer
+                dut::RowScratch sc;
+                RawVec<uint32_t> big;
+                size_t used = 0;
+                uint32_t my_max = 0;
+                auto flush = [&]() {
+                    if (!used) return;
+                    const uint64_t off = dev_next.fetch_add(used);
+                    if (off + used <= dev_cap) send(d_tab + off * GW, used);  // else: the array is too small, only the total counts now
+                    for (uint32_t w : in_buf) win[w].rlo += (uint32_t)off;
+                    in_buf.clear(); used = 0;
+                };
+                try {
+                    size_t task;
+                    while ((task = next_task.fetch_add(1)) < ntasks) {
+                        const size_t w0 = task * per, w1 = std::min<size_t>(n_win, w0 + per);
+                        act.clear();
+                        for (size_t w = w0; w < w1; ++w) {
+                            const uint32_t W = (uint32_t)(w * kT);
+                            WinMeta &m = win[w];
+                            if (w == w0) {
+                                // what covers the range's first window: the wide reads in front of read lo, then [lo, hi)
+                                for (uint32_t i = 0; i < m.wn; ++i) dut::rows_enter(act, H, wide_idx[m.wlo + i], W);
+                                for (uint32_t r = m.lo; r < m.hi; ++r) dut::rows_enter(act, H, r, W);
+                            } else {
+                                for (uint32_t r = win[w - 1].hi; r < m.hi; ++r) dut::rows_enter(act, H, r, W);   // the reads that start in this window
+                            }
+                            if (act.empty()) { m.rlo = 0; m.rn = 0; continue; }
+                            save = act;
+                            size_t cnt = dut::rows_window<kT>(act, H, W, cur_buf() + used * GW, capG - used, sc);
+                            if (cnt == SIZE_MAX) {                           // the buffer is full: it leaves, the window starts over
+                                flush();
+                                act = save;
+                                cnt = dut::rows_window<kT>(act, H, W, cur_buf(), capG, sc);
+                            }
+                            if (cnt == SIZE_MAX) {
+                                // a window that no buffer holds (depth in the ten thousands): through a block of its own
+                                size_t bc = capG * 4;
+                                for (;;) {
+                                    big.clear(); big.resize(bc * GW);
+                                    act = save;
+                                    cnt = dut::rows_window<kT>(act, H, W, big.data(), bc, sc);
+                                    if (cnt != SIZE_MAX) break;
+                                    bc *= 4;
+                                }
+                                const uint64_t off = dev_next.fetch_add(cnt);
+                                if (off + cnt <= dev_cap && err == hipSuccess)
+                                    err = hipMemcpy(d_tab + off * GW, big.data(), cnt * GW * sizeof(uint32_t), hipMemcpyHostToDevice);
+                                m.rlo = (uint32_t)off; m.rn = (uint32_t)std::min<size_t>(cnt, 0xFFFFFFFFu);
+                                my_max = std::max(my_max, m.rn);
+                                continue;
+                            }
+                            m.rlo = (uint32_t)used; m.rn = (uint32_t)cnt;
+                            my_max = std::max(my_max, m.rn);
+                            if (cnt) in_buf.push_back((uint32_t)w);
+                            used += cnt;
+                        }
+                    }
+                    flush();
+                } catch (...) { if (err == hipSuccess) err = hipErrorOutOfMemory; }
+                for (int b = 0; b < 2 && b < kb; ++b) { const hipError_t e = hipEventSynchronize(R->pin_ev[t][b]); if (err == hipSuccess) err = e; }
+                uint32_t seen = max_groups.load();
+                while (seen < my_max && !max_groups.compare_exchange_weak(seen, my_max)) {}
+                c->copy_err[t] = err;
+            }));
+        }
+        s = ring_finish(c);
+        if (s != CL_OK) return s;
+        const uint64_t total = dev_next.load();
+        if (total >= 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 groups of pass-bit rows in one contig");
+        if (total <= dev_cap) { c->n_row_groups = total; c->max_groups = max_groups.load(); return CL_OK; }
+        want = total;                                            // exact now: once more
+    }
+    return fail(c, CL_ERR_DEVICE, "pass-bit rows: the second sizing pass did not fit");
+}
+
 // allocate and lay out everything that depends on the extent (called by cl_contig_upload, the staged arrays still there)
 cl_status size_for_extent(cl_ctx *c, uint32_t extent)
 {
@@ -997,10 +1140,17 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
         // ... beside it, the windows' candidate ranges
         std::vector<WinMeta> win;
         uint32_t flags = 0;
-        host_window_bounds(c, c->h_wide_rec_of, win, flags);
+        host_window_bounds(c, win, flags);
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
-        c->n_runtab = 0;
+        c->n_runtab = 0; c->n_row_groups = 0; c->max_groups = 0;
+        if (c->form == 3) {
+            // the windows' pass-bit rows: one more walk over the staged CIGARs, streamed to HBM through the ring
+            StageTimer tr;
+            rs = stream_rows(c, win);
+            if (rs != CL_OK) return rs;
+            tr.lap("upload: pass-bit rows (walk + H2D)");
+        }
         if (c->form == 2 && !(flags & kErrRange)) {
             // the windows' match pieces: one more walk over the staged CIGARs, streamed to HBM through the ring
             StageTimer tr;
@@ -1011,11 +1161,20 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
         // DUT_VALIDATE=1 (tooling: tools/fuzz_parity.py sets it): what the kernels will index is checked on the host before
         // anything is launched -- candidate ranges against the resident arrays, and every entry of the run table (read
         // back from the device) against the quality array -- so that a bad index is an error message, not a GPU fault
+        finish_windows(c, c->h_wide_rec_of, win, flags);
+        // what k_pileup_rows streams per window must lie inside the resident rows: checked in the product build, once per
+        // contig (an index past the array is an error return, not a device fault)
+        if (c->form == 3) {
+            std::atomic<bool> bad{false};
+            const uint64_t ngr = c->n_row_groups;
+            dut::parallel_for(c->n_win, 8192, [&](size_t w) { if ((uint64_t)win[w].rlo + win[w].rn > ngr) bad.store(true); });
+            if (bad.load()) return fail(c, CL_ERR_RANGE, "a window's pass-bit rows lie outside the resident row array");
+        }
         static const bool validate = [] { const char *e = getenv("DUT_VALIDATE"); return e && *e == '1'; }();
         if (validate && !(flags & kErrRange)) {
-            const uint64_t n_cand = c->form == 0 ? c->n_rec : c->h_pos.size();
+            const uint64_t n_cand = c->form != 2 ? c->n_rec : c->h_pos.size();
             uint64_t n_wide_list = c->h_wide_idx.size();
-            if (c->form == 0 && !c->h_wide_rec_of.empty()) n_wide_list = c->h_wide_rec_of.back();
+            if (c->form != 2) n_wide_list = c->h_wide_rec_of.empty() ? 0 : c->h_wide_rec_of.back();
             std::vector<uint2> tab;
             if (c->form == 2 && c->n_runtab) {
                 tab.resize(c->n_runtab);
@@ -1063,7 +1222,7 @@ void launch_rle(cl_ctx *c)
     hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
                        c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
                        c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
-                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu));
+                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu), c->form == 3 ? (unsigned long long)c->dev_sum_q : 0ull);
 }
 
 template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
@@ -1074,8 +1233,15 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     // serves every threshold now and only ORF = true is instantiated)
 #define CL_LAUNCH(DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
 #define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else CL_LAUNCH(DEEP_, 0); } while (0)
+#define CL_LAUNCH_R(DEEP_, NP_) hipLaunchKernelGGL((k_pileup_rows<(int)kT, DEBUG, DEEP_, NP_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
+#define CL_LAUNCH_RN(DEEP_) do { if (c->max_groups <= 63u) CL_LAUNCH_R(DEEP_, 8); else if (c->max_groups <= 16383u) CL_LAUNCH_R(DEEP_, 16); else CL_LAUNCH_R(DEEP_, 32); } while (0)
     // the 32-bit counter variant is used only when the window bounds asked for it (kNeedDeep)
-    if (!c->deep) CL_LAUNCH_L(false); else CL_LAUNCH_L(true);
+    if (c->form == 3) {
+        // pass-bit form: the counter planes by the deepest window's rows (4 per group): 8 planes count to 255
+        if (!c->deep) CL_LAUNCH_RN(false); else CL_LAUNCH_RN(true);
+    } else if (!c->deep) CL_LAUNCH_L(false); else CL_LAUNCH_L(true);
+#undef CL_LAUNCH_RN
+#undef CL_LAUNCH_R
 #undef CL_LAUNCH_L
 #undef CL_LAUNCH
 }
@@ -1098,7 +1264,6 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     PileupArgs a;
     a.R = R; a.o = c->dopt;
-    if (c->form == 0 && c->qual_aligned) a.R.qual = c->d_qual_al.p + kQualPad;     // the aligned layout (k_repack_qual)
  a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
     a.wide_idx = c->d_wide_idx.p;
     a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
@@ -1109,7 +1274,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     a.win_wide = c->d_win_wide.p; a.err_flag = c->d_errflag.p;
     a.upl = (c->n_reads && c->n_qual <= 128ull * c->n_reads) ? 2u : 3u;   // by the mean read length
     a.ablate = c->tune_ablate;        // 0 outside tuning builds
-    a.runtab = c->d_runtab.p;
+    a.runtab = c->d_runtab.p; a.rows = c->d_rows.p;
     if (debug) launch_pileup<true>(c, a); else launch_pileup<false>(c, a);
     if (prof) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
@@ -1149,6 +1314,10 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     if (!c) return CL_ERR_NOMEM;
     c->device = device_id;
     c->opt = *opt;
+    // DUT_QUAL_FORM=bytes: the quality bytes themselves go to the device and k_pileup tests them there (the byte forms:
+    // records for short reads, the run table for long ones) -- the forms of rounds 1-3, kept selectable so that their
+    // measurements stay reproducible.  Default: the pass-bit form (k_pileup_rows).  Read per context.
+    { const char *qf = getenv("DUT_QUAL_FORM"); c->bits = !(qf && strcmp(qf, "bytes") == 0); }
     if (hipSetDevice(device_id) != hipSuccess) { delete c; return CL_ERR_DEVICE; }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -1185,13 +1354,14 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
 void cl_destroy(cl_ctx *c)
 {
     if (!c) return;
+    if (c->host_only) { delete c; return; }
     (void)hipSetDevice(c->device);
     StageTimer tmr;
     drop_prefetch(c);                                     // its copiers write into d_qual: joined before anything is released
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     tmr.lap("destroy: sync");
     c->d_pos.release(); c->d_mapq.release();
-    c->d_qual.release(); c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
+    c->d_qual.release(); c->d_rows.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
     c->d_wide_idx.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
@@ -1217,7 +1387,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     if (!c) return CL_ERR_INVALID;
     if (contig_len > 0xFFF00000u) return fail(c, CL_ERR_RANGE, "contig length beyond the engine's 32-bit range");
     if (ref_len && !ref_bases) return fail(c, CL_ERR_INVALID, "ref_bases is null");
-    drop_prefetch(c);
+    if (!c->host_only) drop_prefetch(c);
     take_staging(c);
     c->tid = tid; c->contig_len = contig_len;
     const uint64_t nref = std::min<uint64_t>(ref_len, contig_len);
@@ -1228,7 +1398,8 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->q_dev = 0;
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->n_long = 0; c->host_err = 0; c->bounds_err = 0;
-    c->h_rec_cnt.clear(); c->h_phase.clear(); c->rec_counted = true;
+    c->h_rec_cnt.clear(); c->rec_counted = true;
+    c->h_qbits.clear(); c->host_sum_q = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -1262,6 +1433,7 @@ constexpr uint64_t kDirectQual = 4u << 20;   // tiles with at least this many qu
 cl_status cl_contig_prefetch_qual(cl_ctx *c, const uint8_t *qual, uint64_t n_bytes)
 {
     if (!c || !c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_prefetch_qual outside cl_contig_begin .. upload");
+    if (c->bits) return CL_OK;                                  // pass-bit form: no quality byte goes to the device
     if (!qual || n_bytes < kDirectQual) return CL_OK;            // small tiles are staged on the host anyway
     try {
         drop_prefetch(c);
@@ -1288,9 +1460,11 @@ cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, u
         c->h_pos.reserve(n_reads); c->h_mapq.reserve(n_reads);
         c->h_cigar_off.reserve(n_reads + 1); c->h_qual_off.reserve(n_reads + 1);
         c->h_cigar.reserve(n_cigar_ops);
+        if (c->bits) c->h_qbits.reserve(((n_qual_bytes + 63) >> 6) + 2);
     } catch (const std::bad_alloc &) {
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
+    if (c->bits) return CL_OK;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->d_qual.grow_keep(n_qual_bytes + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
     return CL_OK;
@@ -1322,7 +1496,8 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     //      the small arrays.  All are joined before the call returns (the caller's buffer is free again then);
     //      nothing of the context changes if the tile turns out to be invalid. ----
     struct RingGuard { cl_ctx *c; bool active = false; ~RingGuard() { if (active) (void)ring_finish(c); } } ring{c};
-    const bool direct = nq >= kDirectQual;
+    const bool bits = c->bits;                                // the pass-bit form: no quality byte goes to the device
+    const bool direct = !bits && nq >= kDirectQual;
     if (direct) {
         const uint8_t *src = t->qual + q0;
         const bool prefetched = c->pf_active && c->pf_src == src && c->pf_n == nq && c->h_qual.empty() && c->pf_off == c->q_dev;
@@ -1358,11 +1533,12 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     // that every thread has some)
     const size_t grain = dut::grain_for(n, 65536);
     const size_t nchunk = (n + grain - 1) / grain;
-    struct Chunk { int bad = 0; uint32_t n_long = 0, err = 0; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide; };
+    struct Chunk { int bad = 0; uint32_t n_long = 0, err = 0; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0, sum_q = 0; std::vector<uint32_t> wide; };
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
     try {
-        c->h_rec_cnt.reserve(rbase + n); c->h_phase.reserve(rbase + n + 1);
+        c->h_rec_cnt.reserve(rbase + n);
+        if (bits) c->h_qbits.reserve(((qbase + nq + 63) >> 6) + 2);
         c->h_end.reserve(rbase + n);                           // entries [rbase, rbase + n) are written below; the
         c->h_ck_x.reserve(((cbase + ncig) >> 6) + 2);          // sizes follow when the tile is accepted (a refused
         c->h_ck_y.reserve(((cbase + ncig) >> 6) + 2);          // tile leaves only unused capacity behind)
@@ -1371,8 +1547,24 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     }
     uint32_t *const h_end = c->h_end.data() + rbase, *const h_ck_x = c->h_ck_x.data(), *const h_ck_y = c->h_ck_y.data();
     uint32_t *const h_rec_cnt = c->h_rec_cnt.data() + rbase;
-    uint8_t *const h_phase = c->h_phase.data() + rbase;
     const uint32_t min_mapq = c->opt.min_mapping_quality;
+    // pass-bit form: the bits of this tile's quality bytes [qbase, qbase + nq) of the contig.  A word of the bit array
+    // belongs to the chunk (below: to the block of reads) that holds its FIRST byte, so no two threads write one word;
+    // the word that holds byte qbase itself, when earlier tiles left it partly filled, is completed after the walk.
+    uint64_t *const qbits = c->h_qbits.data();
+    const uint8_t *const qsrc = t->qual ? t->qual + q0 : nullptr;
+    const uint8_t min_bq = c->opt.min_base_quality;
+    const int plevel = dut::qual_pack_level();
+    auto pack_range = [&](uint64_t ga, uint64_t gb) {          // the words whose first byte lies in tile bytes [ga, gb)
+        if (ga >= gb) return;
+        uint64_t w0 = (qbase + ga + 63) >> 6;
+        const uint64_t w1 = (qbase + gb + 63) >> 6;            // first word NOT of this range
+        if (w0 >= w1) return;
+        // whole words, then the tile's last, partial one (its upper bits stay zero)
+        const uint64_t wfull = std::min<uint64_t>(w1, (qbase + nq) >> 6);
+        if (wfull > w0) { dut::qual_pass_words(qsrc + ((w0 << 6) - qbase), wfull - w0, min_bq, qbits + w0, plevel); w0 = wfull; }
+        if (w0 < w1) qbits[w0] = dut::qual_pass_partial(qsrc + ((w0 << 6) - qbase), (uint32_t)(qbase + nq - (w0 << 6)), min_bq);
+    };
     // (a tile of long-read shape -- 8 or more operations per read -- will not get the short-read form: its reads'
     // records are not counted here, that would be a second pass over every operation)
     const bool count_recs = ncig < 8ull * n;
@@ -1380,14 +1572,23 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         Chunk &o = ch[k];
         const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
         int32_t last = a ? t->pos[a - 1] : last0;
-        for (size_t i = a; i < b; ++i) {
+        // blocks of 256 reads: their quality bytes (about 40 KB of short reads) are turned into pass bits first and are
+        // still in the cache when the reads' sums are taken
+        for (size_t ib = a; ib < b; ib += 256) {
+        const size_t ie = std::min(b, ib + 256);
+        if (bits) {
+            const uint64_t ga = t->qual_off[ib] - q0, gb = t->qual_off[ie] - q0;
+            if (t->qual_off[ib] >= q0 && ga <= gb && gb <= nq) pack_range(ga, gb);      // (else: flagged bad = 3 below)
+        }
+        for (size_t i = ib; i < ie; ++i) {
             const int32_t p = t->pos[i];
             if (p < 0 || (uint32_t)p >= c->contig_len) { if (!o.bad) o.bad = 1; }
             else if (p < last) { if (!o.bad) o.bad = 2; }
             last = p;
-            h_end[i] = (uint32_t)p; h_rec_cnt[i] = 0u; h_phase[i] = 0;
+            h_end[i] = (uint32_t)p; h_rec_cnt[i] = 0u;
             if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i]) { if (!o.bad) o.bad = 3; continue; }
             if (t->cigar_off[i] < cig0 || t->cigar_off[i + 1] > cig0 + ncig) { if (!o.bad) o.bad = 3; continue; }
+            if (t->qual_off[i] < q0 || t->qual_off[i + 1] > q0 + nq) { if (!o.bad) o.bad = 3; continue; }
             const uint32_t q0i = t->cigar_off[i], q1i = t->cigar_off[i + 1], nops = q1i - q0i;
             unsigned long long l = 0;
             if (nops <= kLongOps) {
@@ -1423,17 +1624,27 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             else o.err |= kErrRange;
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
-            // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
-            if (count_recs) {
+            if (bits) {
+                // pass-bit form: a head record per read with a reference span (k_pileup_rows), and the read's share of
+                // summed_baseq (contig_profiler.rs:65-70): the passing qualities of its M/=/X bases that have a quality
+                // byte, for reads with mapq >= min_mapping_quality -- the bytes are in the cache from pack_range above
+                const bool in_pileup = h_end[i] != (uint32_t)p;
+                h_rec_cnt[i] = in_pileup ? 1u : 0u;
+                const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
+                if (in_pileup && ql && t->mapq[i] >= min_mapq)
+                    o.sum_q += read_pass_sum(qsrc + (t->qual_off[i] - q0), ql, t->cigar + q0i, nops, min_bq, plevel);
+            } else if (count_recs) {
+                // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
                 const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
                 const uint32_t mq = t->mapq[i];
-                uint32_t cnt, ph = 0;
+                uint32_t cnt;
                 // one M/=/X operation as long as the qualities (96 reads in 100 of aligner output): one record, no walk
-                if (nops == 1u && h_end[i] != (uint32_t)p && ql < 0x10000ull && ((0x181u >> (t->cigar[q0i] & 15u)) & 1u) && (t->cigar[q0i] >> 4) == ql) {
-                    cnt = 1u; ph = mq >= min_mapq ? ((uint32_t)p & 15u) : 0u;
-                } else cnt = gen_read_recs(p, h_end[i], mq, min_mapq, t->cigar + q0i, nops, 0ull, ql, [](uint32_t, const ReadRec &) {}, &ph);
-                h_rec_cnt[i] = cnt; h_phase[i] = (uint8_t)ph;
+                if (nops == 1u && h_end[i] != (uint32_t)p && ql < 0x10000ull && ((0x181u >> (t->cigar[q0i] & 15u)) & 1u) && (t->cigar[q0i] >> 4) == ql)
+                    cnt = 1u;
+                else cnt = gen_read_recs(p, h_end[i], mq, min_mapq, t->cigar + q0i, nops, 0ull, ql, [](uint32_t, const ReadRec &) {});
+                h_rec_cnt[i] = cnt;
             }
+        }
         }
     });
     tmr.lap("push: validate + spans");
@@ -1446,7 +1657,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     // ---- staging of the small arrays (offsets rebased onto the contig's); undone if anything below fails, so that
     //      a refused tile leaves the context as it was ----
     struct Undo {
-        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; uint32_t n_long, host_err; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
+        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; uint32_t n_long, host_err; bool has_long; uint32_t span_n, span_w; uint64_t max_end, sum_q; bool armed = true;
         ~Undo()
         {
             if (!armed) return;
@@ -1454,25 +1665,27 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             c->h_cigar_off.resize(n_pos + 1); c->h_qual_off.resize(n_pos + 1);
             c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide); c->n_long = n_long; c->host_err = host_err;
             c->h_end.resize(n_pos); c->h_ck_x.resize((n_cig >> 6) + 2); c->h_ck_y.resize((n_cig >> 6) + 2);
-            c->h_rec_cnt.resize(n_pos); c->h_phase.resize(n_pos);
-            c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end;
+            c->h_rec_cnt.resize(n_pos);
+            c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end; c->host_sum_q = sum_q;
         }
-    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->n_long, c->host_err, c->has_long, c->span_n, c->span_w, c->host_max_end};
+    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->n_long, c->host_err, c->has_long, c->span_n, c->span_w, c->host_max_end, c->host_sum_q};
     try {
         for (const Chunk &o : ch) {
             if (o.n_long) c->has_long = true;
             c->n_long += o.n_long; c->host_err |= o.err;
             c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
             c->host_max_end = std::max(c->host_max_end, o.max_end);
+            c->host_sum_q += o.sum_q;
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
         }
         c->h_end.resize(rbase + n); c->h_ck_x.resize(((cbase + ncig) >> 6) + 2); c->h_ck_y.resize(((cbase + ncig) >> 6) + 2);
-        c->h_rec_cnt.resize(rbase + n); c->h_phase.resize(rbase + n);
-        if (!count_recs) c->rec_counted = false;
+        c->h_rec_cnt.resize(rbase + n);
+        if (!bits && !count_recs) c->rec_counted = false;
+
         c->h_pos.append(t->pos, n);
         c->h_mapq.append(t->mapq, n);
         c->h_cigar.append(t->cigar + cig0, ncig);
-        if (!direct) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
+        if (!direct && !bits) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
         const size_t o0 = c->h_cigar_off.size();               // == rbase + 1: entry r+1 closes read r
         c->h_cigar_off.resize(o0 + n);
         c->h_qual_off.resize(o0 + n);
@@ -1492,7 +1705,16 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         if (rs != CL_OK) return rs;
     }
     tmr.lap("push: wait for the qualities");
-    if (direct) c->q_dev += nq;
+    if (bits && nq) {
+        // (last: nothing fails from here on.)  The word that holds the tile's first byte, when that is not the word's
+        // first, belongs to no block of the walk -- its first byte is an earlier tile's --: completed here; the bits
+        // above the contig's bytes so far are zero (a tile's last word is written whole, zeros above its bytes)
+        const uint64_t head = (qbase & 63ull) ? std::min<uint64_t>(nq, 64ull - (qbase & 63ull)) : 0ull;
+        if (head) qbits[qbase >> 6] |= dut::qual_pass_partial(qsrc, (uint32_t)head, min_bq) << (qbase & 63ull);
+        c->h_qbits.resize(((qbase + nq + 63) >> 6) + 1);       // (capacity reserved above: the data stay where they are)
+        c->h_qbits[c->h_qbits.size() - 1] = 0ull;              // the pad word deposit_bits may read
+    }
+    if (direct || bits) c->q_dev += nq;                      // (pass-bit form: the contig's quality bytes so far, none on the device)
     undo.armed = false;
     return CL_OK;
 }
@@ -1510,26 +1732,28 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
 {
     Range rg("cl_contig_upload");
     if (!c || !c->in_contig) return fail(c, CL_ERR_INVALID, "cl_contig_upload without cl_contig_begin");
+    if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context (cl_debug_host_create) has no device to upload to");
     HIP_TRY(c, hipSetDevice(c->device));
     drop_prefetch(c);
     c->n_reads = (uint32_t)c->h_pos.size();
     c->n_cigar = c->h_cigar.size();
-    {
+    if (!c->bits) {
         cl_status fs = flush_staged_qual(c);
         if (fs != CL_OK) return fs;
     }
     c->n_qual = c->q_dev;
+    c->dev_sum_q = c->host_sum_q;
     c->n_wide = (uint32_t)c->h_wide_idx.size();
     const size_t n = c->n_reads;
     c->form = pick_form(c);
     const int form = c->form;
     StageTimer tmr0;
-    // What the device needs of the per-read fields depends on the form of k_pileup the contig gets: the short-read form
-    // reads records (built below) and nothing else per read; the run-table form pos, mapq and end of the windows'
-    // candidates, and the table that the walk in size_for_extent() builds from the staged CIGARs.  No form reads a CIGAR
-    // or an offset array: neither is uploaded.
+    // What the device needs of the per-read fields depends on the form of the pileup kernel the contig gets: the record
+    // forms (pass bits: always; bytes: short reads) read records (built below) and nothing else per read; the run-table
+    // form pos, mapq and end of the windows' candidates, and the table that the walk in size_for_extent() builds from the
+    // staged CIGARs.  No form reads a CIGAR or an offset array: neither is uploaded.
     HIP_TRY(c, c->d_end.reserve(n + 1));
-    HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
+    if (!c->bits) HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     tmr0.lap("upload: device buffers");
@@ -1537,44 +1761,31 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // everything goes through the pinned staging ring (pageable vectors -> pinned buffers -> HBM, the fills overlapping
     // the transfers)
     cl_status rs = CL_OK;
-    if (form != 0) {
+    if (form == 2) {
         HIP_TRY(c, c->d_pos.reserve(n + 1));
         HIP_TRY(c, c->d_mapq.reserve(n + 1));
         if ((rs = ring_copy(c, c->d_pos.p, c->h_pos.data(), n * sizeof(int32_t))) != CL_OK) return rs;
         if ((rs = ring_copy(c, c->d_mapq.p, c->h_mapq.data(), n)) != CL_OK) return rs;
-    }
-    if (form != 0)
         if ((rs = ring_copy(c, c->d_end.p, c->h_end.data(), n * sizeof(uint32_t))) != CL_OK) return rs;
+    }
     c->h_rec_of.clear(); c->h_wide_rec_of.clear(); c->n_rec = 0;
-    if (form == 0) {
-        // the records of the short-read form (kernels.hip.h: ReadRec): the host's walk over the CIGARs, so that the
-        // device decodes none -- north_star's "CIGAR-expanded ref spans" on the host side of the boundary.  Counted
-        // first (the reads' record ranges are what the windows' candidate ranges index), then built straight into the
-        // pinned buffers: a buffer covers a range of record numbers, the reads it belongs to are found by binary search.
+    if (form != 2) {
+        // the records (kernels.hip.h: ReadRec): the host's walk over the CIGARs, so that the device decodes none --
+        // north_star's "CIGAR-expanded ref spans" on the host side of the boundary.  Counted first (the reads' record
+        // ranges are what the windows' candidate ranges index), then built straight into the pinned buffers: a buffer
+        // covers a range of record numbers, the reads it belongs to are found by binary search.  Pass-bit form: a head
+        // record per read and nothing else (its M/=/X runs are in the rows).
         if ((rs = build_rec_index(c)) != CL_OK) return rs;
         tmr.lap("upload: record index");
         const uint32_t n_rec = c->n_rec;
         HIP_TRY(c, c->d_rec.reserve((size_t)n_rec + 1));
-        // the aligned quality layout (build_qual_alignment): its buffer first -- without it the shifts stay zero and
-        // k_pileup reads the bytes where they were pushed
-        build_qual_alignment(c);
-        if (c->qual_aligned) {
-            const size_t need = (size_t)c->n_qual + c->h_shift[n] + 2 * kQualPad + 64;
-            if (c->d_qual_al.reserve(need) != hipSuccess || c->d_rec_shift.reserve((size_t)n_rec + 1) != hipSuccess ||
-                c->d_rec_base.reserve((size_t)n_rec / 64 + 2) != hipSuccess) {
-                (void)hipGetLastError();
-                c->d_qual_al.release(); c->d_rec_shift.release(); c->d_rec_base.release();
-                std::fill(c->h_shift.begin(), c->h_shift.end(), 0u);
-                c->qual_aligned = false;
-            }
-        }
-        tmr.lap("upload: alignment index + buffers");
         const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
         const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
-        const uint32_t *ro = c->h_rec_of.data(), *sh = c->h_shift.data();
+        const uint32_t *ro = c->h_rec_of.data();
         const uint32_t min_mapq = c->opt.min_mapping_quality;
+        const bool heads_only = c->bits;
         rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), ((uint64_t)n_rec + 1) * sizeof(ReadRec),
-                        [hp, hm, he, hc, hcig, hq, ro, sh, n, n_rec, min_mapq](uint64_t off, uint64_t len, uint8_t *out) {
+                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq, heads_only](uint64_t off, uint64_t len, uint8_t *out) {
             ReadRec *o = reinterpret_cast<ReadRec *>(out);
             const uint64_t j0 = off / sizeof(ReadRec), j1 = (off + len) / sizeof(ReadRec);
             if (j1 > n_rec) memset(static_cast<void *>(o + (std::max<uint64_t>(n_rec, j0) - j0)), 0, (j1 - std::max<uint64_t>(n_rec, j0)) * sizeof(ReadRec));   // the padding record
@@ -1583,56 +1794,24 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
             size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
             for (; i < n && ro[i] < j1; ++i) {
                 const uint64_t jb = ro[i];
-                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i] + sh[i], hq[i + 1] - hq[i],
+                if (heads_only) {
+                    // the read as the pileup holds it, [pos, end) (mod.rs:22-28)
+                    if (ro[i + 1] == jb || jb < j0) continue;
+                    ReadRec r;
+                    r.pos = hp[i]; r.span = he[i] - (uint32_t)hp[i]; r.qual_lo = 0u; r.meta = (uint32_t)hm[i] | 0x100u;
+                    o[jb - j0] = r;
+                    continue;
+                }
+                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i], hq[i + 1] - hq[i],
                               [&](uint32_t k, const ReadRec &r) { const uint64_t j = jb + k; if (j >= j0 && j < j1) o[j - j0] = r; });
             }
         }, rec_chunk_bytes());
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
         tmr.lap("upload: records built + sent");
-        if (c->qual_aligned && n_rec) {
-            // what k_repack_qual needs beside the records: per record how far its read's bytes move, per 64 records a
-            // 64-bit offset at or below theirs (the records hold the low halves)
-            rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec_shift.p), (uint64_t)n_rec * sizeof(uint32_t),
-                            [ro, sh, n](uint64_t off, uint64_t len, uint8_t *out) {
-                uint32_t *o = reinterpret_cast<uint32_t *>(out);
-                const uint64_t j0 = off / sizeof(uint32_t), j1 = (off + len) / sizeof(uint32_t);
-                size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
-                for (; i < n && ro[i] < j1; ++i)
-                    for (uint64_t j = std::max<uint64_t>(ro[i], j0), je = std::min<uint64_t>(ro[i + 1], j1); j < je; ++j) o[j - j0] = sh[i];
-            });
-            if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
-            if (rs != CL_OK) return rs;
-            const size_t nb = ((size_t)n_rec + 63) / 64;
-            std::vector<unsigned long long> base(nb);
-            std::atomic<bool> far{false};
-            dut::parallel_for(nb, 4096, [&](size_t b) {
-                const size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)(b * 64)) - ro) - 1;
-                base[b] = hq[i] + sh[i];
-                // the block's last record belongs to read ie: its bytes end within 2^32 of the base
-                const size_t je = std::min<size_t>(b * 64 + 63, (size_t)n_rec - 1);
-                const size_t ie = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)je) - ro) - 1;
-                if (hq[ie + 1] + sh[ie + 1] - base[b] > 0xFFFF0000ull) far.store(true);
-            });
-            if (far.load()) return fail(c, CL_ERR_RANGE, "the quality bytes of 64 consecutive read records span more than 2^32 bytes");
-            HIP_TRY(c, hipMemcpyAsync(c->d_rec_base.p, base.data(), nb * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            hipLaunchKernelGGL(k_repack_qual, dim3((unsigned)nb), dim3(kBlock), 0, c->stream, c->d_rec.p, c->d_rec_shift.p, c->d_rec_base.p,
-                               n_rec, c->d_qual.p + kQualPad, c->d_qual_al.p + kQualPad);
-            HIP_TRY(c, hipGetLastError());
-            // The bytes as pushed and the two upload-only arrays are not read again while this contig is resident.  When
-            // the device is filling up (many resident contexts: a whole genome on one GPU) they are given back now; else
-            // they stay for the next contig (a free + malloc of gigabytes per contig costs more than it saves).
-            size_t fr = 0, tot = 0;
-            if (hipMemGetInfo(&fr, &tot) == hipSuccess && fr < tot / 3) {
-                HIP_TRY(c, hipStreamSynchronize(c->stream));
-                c->d_qual.release(); c->d_rec_shift.release(); c->d_rec_base.release();
-            }
-        }
     }
-    tmr.lap("upload: records");
-    std::vector<uint32_t> wide_rec;                      // short-read form: the wide reads' records, read by read
-    if (c->n_wide && form == 0) {
+    std::vector<uint32_t> wide_rec;                      // record forms: the wide reads' records, read by read
+    if (c->n_wide && form != 2) {
         c->h_wide_rec_of.assign(c->n_wide + 1, 0u);
         for (uint32_t j = 0; j < c->n_wide; ++j) {
             const uint32_t i = c->h_wide_idx[j];
@@ -1645,7 +1824,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     } else if (c->n_wide) {
         HIP_TRY(c, hipMemcpyAsync(c->d_wide_idx.p, c->h_wide_idx.data(), c->n_wide * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
     }
-    if (c->d_qual.p) {                                   // (given back already when the aligned copy replaced it)
+    if (!c->bits && c->d_qual.p) {
         HIP_TRY(c, hipMemsetAsync(c->d_qual.p, 0, kQualPad, c->stream));
         HIP_TRY(c, hipMemsetAsync(c->d_qual.p + kQualPad + c->n_qual, 0, kQualPad, c->stream));
     }
@@ -1662,9 +1841,9 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // context's or another's (giving back and re-faulting a few hundred megabytes per contig was a fifth of a contig's
     // host time).
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
-    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear();
+    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qbits.clear();
     std::vector<uint32_t>().swap(c->h_rec_of); c->h_wide_rec_of.clear();
-    std::vector<uint32_t>().swap(c->h_shift); c->h_phase.clear(); c->h_rec_cnt.clear();
+    c->h_rec_cnt.clear();
     give_staging(c);
     std::vector<uint8_t>().swap(c->h_qual);
     tmr.lap("upload: done");
@@ -1701,6 +1880,85 @@ cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_o
     return CL_OK;
 }
 
+cl_status cl_debug_qual_pack(const uint8_t *qual, uint64_t n, uint8_t min_base_quality, int level, uint64_t *words_out, uint64_t *sum_out)
+{
+    if ((n && !qual) || level < 0 || level > 2) return CL_ERR_INVALID;
+    if (words_out) {
+        dut::qual_pass_words(qual, n >> 6, min_base_quality, words_out, level);
+        if (n & 63ull) words_out[n >> 6] = dut::qual_pass_partial(qual + (n & ~63ull), (uint32_t)(n & 63ull), min_base_quality);
+    }
+    if (sum_out) *sum_out = dut::qual_pass_sum(qual, n, min_base_quality, level);
+    return CL_OK;
+}
+
+cl_status cl_debug_host_create(const cl_options *opt, cl_ctx **out)
+{
+    if (!opt || !out) return CL_ERR_INVALID;
+    *out = nullptr;
+    cl_ctx *c = new (std::nothrow) cl_ctx();
+    if (!c) return CL_ERR_NOMEM;
+    c->device = -1; c->opt = *opt; c->host_only = true; c->bits = true;
+    *out = c;
+    return CL_OK;
+}
+
+static cl_status cl_debug_pass_rows_impl(cl_ctx *c, uint32_t *n_groups, uint32_t n_win_cap, uint32_t *rows, uint64_t cap_words,
+                                         uint64_t *n_words, uint32_t *n_windows, uint64_t *summed_baseq)
+{
+    if (!c || !c->in_contig || !c->bits) return fail(c, CL_ERR_INVALID, "cl_debug_pass_rows: no staged contig in the pass-bit form");
+    const uint32_t extent = (uint32_t)std::max<uint64_t>(c->contig_len, c->host_max_end);
+    const uint32_t n_win = (uint32_t)(((uint64_t)extent + kT - 1) / kT);
+    c->n_win = n_win;
+    if (n_windows) *n_windows = n_win;
+    if (summed_baseq) *summed_baseq = c->host_sum_q;
+    std::vector<WinMeta> win;
+    uint32_t flags = 0;
+    host_window_bounds(c, win, flags);
+    const dut::RowReads H = row_reads(c);
+    std::vector<dut::RowCur> act, save;
+    dut::RowScratch sc;
+    std::vector<uint32_t> buf;
+    uint64_t used = 0;
+    for (uint32_t w = 0; w < n_win; ++w) {
+        const uint32_t W = w * kT;
+        const WinMeta &m = win[w];
+        // (every third window entered afresh, as the first window of a thread's range is -- through the checkpoints of the
+        // long reads --, the others carried over from the window before, as inside a range)
+        act.clear();
+        if (w % 3u == 0u) {
+            for (uint32_t i = 0; i < m.wn; ++i) dut::rows_enter(act, H, c->h_wide_idx[m.wlo + i], W);
+            for (uint32_t r = m.lo; r < m.hi; ++r) dut::rows_enter(act, H, r, W);
+        } else {
+            act = save;
+            for (uint32_t r = win[w - 1].hi; r < m.hi; ++r) dut::rows_enter(act, H, r, W);
+        }
+        size_t cap = 16, cnt;
+        std::vector<dut::RowCur> start = act;
+        for (;;) {
+            buf.assign(cap * dut::kRowGroupWords, 0xDEADBEEFu);         // groups must be zeroed by the builder itself
+            act = start;
+            cnt = dut::rows_window<kT>(act, H, W, buf.data(), cap, sc);
+            if (cnt != SIZE_MAX) break;
+            cap *= 4;
+        }
+        save = act;
+        if (w < n_win_cap && n_groups) n_groups[w] = (uint32_t)cnt;
+        const uint64_t nw = (uint64_t)cnt * dut::kRowGroupWords;
+        if (rows && used + nw <= cap_words) memcpy(rows + used, buf.data(), nw * sizeof(uint32_t));
+        used += nw;
+    }
+    if (n_words) *n_words = used;
+    return CL_OK;
+}
+
+cl_status cl_debug_pass_rows(cl_ctx *c, uint32_t *n_groups, uint32_t n_win_cap, uint32_t *rows, uint64_t cap_words,
+                             uint64_t *n_words, uint32_t *n_windows, uint64_t *summed_baseq)
+{
+    try { return cl_debug_pass_rows_impl(c, n_groups, n_win_cap, rows, cap_words, n_words, n_windows, summed_baseq); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
 cl_status cl_contig_run(cl_ctx *c)
 {
     Range rg("cl_contig_run");
@@ -1714,6 +1972,7 @@ cl_status cl_contig_run(cl_ctx *c)
 cl_status cl_sync(cl_ctx *c)
 {
     if (!c) return CL_ERR_INVALID;
+    if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context has no device");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return harvest_events(c);
 }
@@ -1812,12 +2071,14 @@ cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *out, const cl_interval 
 cl_status cl_contig_abort(cl_ctx *c)
 {
     if (!c) return CL_ERR_INVALID;
-    (void)hipSetDevice(c->device);
-    drop_prefetch(c);                                     // joins the copiers: nothing reads the caller's buffer any more
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (!c->host_only) {
+        (void)hipSetDevice(c->device);
+        drop_prefetch(c);                                 // joins the copiers: nothing reads the caller's buffer any more
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+    }
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
-    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qual.clear();
-    c->q_dev = 0;
+    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qual.clear(); c->h_qbits.clear(); c->h_rec_cnt.clear();
+    c->q_dev = 0; c->host_sum_q = 0;
     c->in_contig = false; c->uploaded = false; c->ran = false;
     return CL_OK;
 }
@@ -1860,16 +2121,40 @@ cl_status cl_reset_kernel_ms(cl_ctx *c)
 cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_bytes)
 {
     if (!c || !c->uploaded) return fail(c, CL_ERR_INVALID, "no resident contig");
-    // what one run must read at least once: quality bytes, per-read pos/mapq/offsets, CIGAR
-    // words, reference bytes; what it must write: the intervals (12 bytes each; the per-position
-    // counters and states never reach HBM)
-    // per read: one packed 16-byte record in the short-read form; pos 4 + mapq 1 + CIGAR offset 4 + quality offset 8 in
-    // the long-read forms
-    const uint64_t n = c->n_reads;
-    const uint64_t per_read = c->form ? (4 + 1 + 4 + 8) : sizeof(ReadRec);
-    if (input_bytes)
-        *input_bytes = c->n_qual + n * per_read + c->n_cigar * 4 + (uint64_t)c->extent;
+    // What one run of the resident form must read at least once, counted strictly: the array elements the form's kernel
+    // addresses, nothing it does not (no CIGAR word: none is resident in any form), and what it must write: the intervals
+    // (12 bytes each; the per-position counters and states never reach HBM).
+    //   every form   reference bytes (extent) + one 32-byte window record per window
+    //   pass bits    the rows (1 KB per group of 4 rows) + a 16-byte head record per read with a span + the wide list
+    //   bytes, 0     the quality bytes + the 16-byte records (heads and pieces) + the wide list
+    //   bytes, 2     the quality bytes + 8 bytes per piece of the run table + pos 4, end 4, mapq 1 per read + the wide list
+    uint64_t in = (uint64_t)c->extent + (uint64_t)c->n_win * sizeof(WinMeta);
+    if (c->form == 3) in += c->n_row_groups * (uint64_t)(dut::kRowGroupWords * sizeof(uint32_t)) + (uint64_t)c->n_rec * sizeof(ReadRec) + (uint64_t)c->n_wide * 4;
+    else if (c->form == 0) in += c->n_qual + (uint64_t)c->n_rec * sizeof(ReadRec) + (uint64_t)c->n_wide * 4;
+    else in += c->n_qual + c->n_runtab * 8 + (uint64_t)c->n_reads * 9 + (uint64_t)c->n_wide * 4;
+    if (input_bytes) *input_bytes = in;
     if (output_bytes) *output_bytes = 12ull * c->h_sum.n_intervals;
+    return CL_OK;
+}
+
+cl_status cl_contig_layout(cl_ctx *c, cl_layout_info *out)
+{
+    if (!c || !out || !c->uploaded) return fail(c, CL_ERR_INVALID, "no resident contig");
+    memset(out, 0, sizeof(*out));
+    out->form = c->form;
+    out->n_reads = c->n_reads; out->n_records = c->n_rec; out->n_windows = c->n_win;
+    out->n_qual = c->n_qual; out->n_cigar = c->n_cigar;
+    out->row_groups = c->n_row_groups; out->max_groups = c->max_groups;
+    out->run_table_entries = c->n_runtab;
+    out->counter_planes = c->form == 3 ? (c->max_groups <= 63u ? 8u : c->max_groups <= 16383u ? 16u : 32u) : 0u;
+    // HBM this context holds (the capacity of every device buffer: what cl_destroy gives back)
+    uint64_t b = 0;
+    b += c->d_pos.cap * 4 + c->d_mapq.cap + c->d_qual.cap + c->d_ref.cap + c->d_end.cap * 4 + c->d_rec.cap * sizeof(ReadRec);
+    b += c->d_rows.cap * sizeof(uint4) + c->d_win_off.cap * 4 + c->d_wide_idx.cap * 4 + c->d_win.cap * sizeof(WinMeta);
+    b += c->d_state.cap + c->d_runs.cap * 2 + c->d_first_state.cap + c->d_last_state.cap + c->d_win_wide.cap;
+    b += c->d_winpart.cap * sizeof(WinPartial) + c->d_fin.cap * sizeof(FinPartial) + c->d_errflag.cap * 4 + c->d_runtab.cap * 8;
+    b += c->d_lut.cap * 4 + c->d_summary.cap * sizeof(DevSummary) + c->d_iv.cap * sizeof(Interval) + c->d_dbg.cap * 4;
+    out->device_bytes = b;
     return CL_OK;
 }
 
@@ -1906,6 +2191,7 @@ cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low,
 static cl_status cl_site_upload_impl(cl_ctx *c, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *t)
 {
     if (!c || !t) return CL_ERR_INVALID;
+    if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context has no device");
     HIP_TRY(c, hipSetDevice(c->device));
     drop_prefetch(c);                                        // the ring is needed below
     SiteResident &S = c->site;
@@ -1992,6 +2278,7 @@ static void site_prepare(const uint32_t *sites, size_t n_sites, SitePrep &P)
 static cl_status cl_site_run_impl(cl_ctx *c, uint8_t min_quality, const uint32_t *sites, size_t n_sites, uint32_t *hist, const SitePrep *ready)
 {
     if (!c || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
+    if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context has no device");
     SiteResident &S = c->site;
     if (!S.resident) return fail(c, CL_ERR_INVALID, "cl_site_run without cl_site_upload");
     HIP_TRY(c, hipSetDevice(c->device));

@@ -216,6 +216,7 @@ struct PileupArgs {
     const uint8_t  *ref;          // padded with 'N' up to n_win*T
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     const uint2    *runtab;       // run-table form (LONG = 2): per window, the M/=/X pieces of its reads (host, at upload)
+    const uint4    *rows;         // pass-bit form (k_pileup_rows): per window, groups of 4 rows x 64 blocks (host, at upload)
     uint8_t        *state;        // n_win*T bytes; written by the DEBUG instantiation only (test dumps)
     uint16_t       *runs;         // per window T entries: the run starts strictly inside the window, rel. position | state << 12
     uint8_t        *first_state, *last_state;   // per window: state of its first / last position (run seams)
@@ -940,6 +941,401 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
 }
 
 // ---------------------------------------------------------------------------------------------
+// k_pileup_rows: the pass-bit form of k_pileup (the default; DUT_QUAL_FORM=bytes selects the byte forms above).
+//
+// "qual >= min_base_quality" (mod.rs:33) is decided once on the host, where the quality bytes are touched anyway
+// (cl_push_reads: one bit per base, qual_pack.cpp), and the bits reach the device as ROWS (pass_rows.h): per window a
+// stack of T-bit rows, bit p of a row <-> reference position W + p, every read of the window (mapq >= min) alone in its
+// stretch of a row.  qc_depth[p] (mod.rs:30-37) is then the column sum of the window's rows -- taken BIT-SLICED: a lane
+// owns a block of 32 positions, a wave streams whole groups of 4 rows (one 16-byte load per lane, 1 KB per wave
+// instruction, no address arithmetic, no masks, no shifts), and adds them into NP counter planes (plane k = bit k of
+// the 32 counts) with carry-save adders: three-input boolean operations (v_bitop3), about 4.5 instructions per row
+// for 32 positions.  No LDS atomics, no CIGAR, no offsets.  The four waves' planes are added by wave 0 and compared --
+// still bit-sliced -- with min_depth and max_depth (callable_profiler.rs:108-113): two 32-bit masks per block, which
+// the final phase expands to the bytes of its byte-parallel classification.  quality_bases is the number of set bits
+// (contig_profiler.rs:71); summed_baseq comes with the bits from the host's walk (contig_profiler.rs:70, per-read
+// separable: SURVEY 8a-7).
+//
+// The window's candidates are head records (ReadRec, one per read with a reference span): the +-1 scatter of raw_depth
+// and low_mapq_count (mod.rs:22-28) and the owner sums, exactly as in the record form of k_pileup.
+//
+// NP: counter planes -- 8 while no window has more than 255 rows (63 groups), 16 up to 65 535, else 32.
+// DEEP: 32-bit difference words (a window with more than 32 767 candidates), as in k_pileup.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bs_maj(uint32_t a, uint32_t b, uint32_t c) { return (a & b) | (c & (a | b)); }
+
+// 4 rows (one group) into the counter planes: two carry-save adders on plane 0, one on plane 1, a half-adder ripple above
+template <int NP>
+__device__ __forceinline__ void bs_add4(uint32_t (&c)[NP], const uint4 x)
+{
+    const uint32_t t0 = c[0] ^ x.x ^ x.y, k0 = bs_maj(c[0], x.x, x.y);
+    c[0] = t0 ^ x.z ^ x.w;
+    const uint32_t k1 = bs_maj(t0, x.z, x.w);
+    uint32_t k = bs_maj(c[1], k0, k1);
+    c[1] = c[1] ^ k0 ^ k1;
+#pragma unroll
+    for (int p = 2; p < NP; ++p) { const uint32_t t = c[p] & k; c[p] ^= k; k = t; }
+}
+
+// bit i = (the count of position i < K), for the NP planes of a block
+template <int NP>
+__device__ __forceinline__ uint32_t bs_less_than(const uint32_t (&c)[NP], unsigned long long K)
+{
+    if (NP < 64 && (K >> NP) != 0ull) return 0xFFFFFFFFu;       // K beyond what NP planes can count to
+    uint32_t lt = 0u, eq = 0xFFFFFFFFu;
+#pragma unroll
+    for (int p = NP - 1; p >= 0; --p) {
+        if ((K >> p) & 1ull) { lt |= eq & ~c[p]; eq &= c[p]; }
+        else eq &= ~c[p];
+    }
+    return lt;
+}
+
+template <int T, bool DEBUG, bool DEEP, int NP>
+__global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_rows(PileupArgs a)
+{
+    constexpr int PER = T / kBlock;
+    static_assert(PER == 8 && T == 2048, "a lane owns a block of 32 positions: T = 64 x 32");
+    constexpr int kWaves = kBlock / 64;
+    constexpr uint32_t kLutLds = 256;
+    constexpr int kDiffWords = DEEP ? T : T / 2;
+    constexpr int G = 4;                                   // groups a wave keeps in flight
+    __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];
+    __shared__ __attribute__((aligned(16))) uint32_t s_low[kDiffWords];
+    __shared__ uint32_t s_pl[kWaves][NP][64];              // the waves' counter planes
+    __shared__ uint32_t s_lt[64], s_gt[64];                // per block: qc < min_depth, qc > max_depth
+    __shared__ uint16_t s_lut[kLutLds];
+    __shared__ uint32_t s_wraw[kWaves], s_wlow[kWaves], s_wmax[kWaves];
+    __shared__ uint8_t s_last[kBlock];
+    __shared__ unsigned long long s_wtot[kWaves][12];
+
+    const uint32_t w = (blockIdx.x & 7u) * a.n_win8 + (blockIdx.x >> 3);   // XCD-contiguous window ranges
+    if (w >= a.n_win) return;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t W = w * (uint32_t)T;
+    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    const uint32_t p0 = W + tid * PER;
+
+    const WinMeta wm = a.win[w];
+    const uint32_t lo = wm.lo, hi = wm.hi, wlo = wm.wlo, wn = wm.wn;
+    const uint32_t n_cand = wn + (hi - lo);
+    const uint32_t ng = wm.rn;                             // groups of 4 rows
+    const uint4 *rows = a.rows + (size_t)wm.rlo * 64u;
+
+    // requested first, needed last: the window's rows (this wave's first G groups), the reference bytes
+    // (every load unconditional: a group past the end is clamped onto the last one and zeroed)
+    uint4 rv[G];
+    if (ng) {
+#pragma unroll
+        for (int j = 0; j < G; ++j) {
+            const uint32_t g = wv + (uint32_t)kWaves * j;
+            rv[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
+        }
+    }
+    uint32_t refw[PER / 4];
+#pragma unroll
+    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
+
+    // ---- clear ----
+    {
+        const uint4 z = make_uint4(0, 0, 0, 0);
+        uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low);
+        const uint4 zb = DEEP ? z : make_uint4(0x8000u, 0x8000u, 0x8000u, 0x8000u);
+        for (int i = tid; i < kDiffWords / 4; i += kBlock) { r4[i] = zb; l4[i] = zb; }
+        if (tid < kLutLds) {
+            const uint32_t v = (tid >= a.o.min_depth_for_low_mapq && tid > 0) ? a.lut[tid] : 0xFFFFFFFFu;
+            s_lut[tid] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v;
+        }
+    }
+    __syncthreads();
+
+    // ---- the window's candidates: head records.  +-1 at the clipped span ends (mod.rs:22-28: every read covering a
+    //      position counts, D/N included); the window that holds a read's start owns its separable sums
+    //      (contig_profiler.rs:74, 79-82) ----
+    unsigned long long win_len = 0, win_mq = 0;
+    for (uint32_t base = 0; base < n_cand; base += kBlock) {
+        const uint32_t v = base + tid;
+        uint32_t r = lo + (v - wn);
+        if (v < wn) r = a.wide_idx[wlo + v];
+        __builtin_assume(r < (1u << 29));
+        uint32_t own_l = 0, own_m = 0;
+        bool big = false;
+        uint32_t big_span = 0, big_mq = 0;
+        if (v < n_cand) {
+            uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
+            asm volatile("" : "+v"(rr.x), "+v"(rr.y), "+v"(rr.z), "+v"(rr.w));
+            const uint32_t x = rr.x, span = rr.y, mq = rr.w & 255u;
+            if ((rr.w & 0x100u) && span) {
+                const uint32_t e = x + span;
+                if (x >= W) {
+                    const bool hq = mq >= a.o.min_mapq;
+                    if (span < 0x10000u) { own_l = span; own_m = hq ? mq * span : 0u; }
+                    else { big = true; big_span = span; big_mq = hq ? mq : 0u; }
+                }
+                if (e > W) {
+                    const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
+                    uint32_t ib, vb, ie, ve2;
+                    if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
+                    else {
+                        ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
+                        ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                    }
+                    atomicAdd(&s_raw[ib], vb);
+                    if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
+                    if (mq <= a.o.max_low_mapq) {
+                        atomicAdd(&s_low[ib], vb);
+                        if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
+                    }
+                }
+            }
+        }
+        win_len += dpp_wave_sum_u32(own_l); win_mq += dpp_wave_sum_u32(own_m);
+        if (__any(big)) {
+            win_len += wave_sum_u64(big ? (unsigned long long)big_span : 0ull);
+            win_mq += wave_sum_u64(big ? (unsigned long long)big_mq * big_span : 0ull);
+        }
+    }
+
+    // ---- the window's rows: this wave's groups wv, wv + 4, ... into its counter planes ----
+    uint32_t c[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) c[p] = 0u;
+    unsigned long long nbits = 0;                          // set bits seen by this lane (-> quality_bases)
+    if (ng) {
+        for (uint32_t g0 = wv; g0 < ng; g0 += (uint32_t)kWaves * G) {      // wave-uniform
+            uint4 nx[G];
+#pragma unroll
+            for (int j = 0; j < G; ++j) {                  // the next trip's groups are requested first
+                const uint32_t g = g0 + (uint32_t)kWaves * (G + j);
+                nx[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
+            }
+            uint32_t pc = 0;
+#pragma unroll
+            for (int j = 0; j < G; ++j) {
+                const bool in = g0 + (uint32_t)kWaves * j < ng;
+                const uint4 x = in ? rv[j] : make_uint4(0u, 0u, 0u, 0u);
+                bs_add4<NP>(c, x);
+                pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+            }
+            nbits += pc;
+#pragma unroll
+            for (int j = 0; j < G; ++j) rv[j] = nx[j];
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < NP; ++p) s_pl[wv][p][lane] = c[p];
+    __syncthreads();
+
+    // ---- final phase: depths, low-MAPQ rule, state, counts (8 positions per thread) ----
+    {
+        // wave 0: the four waves' planes added (a bit-sliced ripple adder per wave) and compared with the two depth
+        // thresholds (callable_profiler.rs:108-113); the other waves go on with their prefix sums meanwhile
+        if (wv == 0) {
+#pragma unroll
+            for (int v = 1; v < kWaves; ++v) {
+                uint32_t carry = 0u;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) {
+                    const uint32_t d = s_pl[v][p][lane];
+                    const uint32_t s = c[p] ^ d ^ carry;
+                    carry = bs_maj(c[p], d, carry);
+                    c[p] = s;
+                }
+            }
+            s_lt[lane] = bs_less_than<NP>(c, (unsigned long long)a.o.min_depth);
+            // qc > max_depth  <=>  !(qc < max_depth + 1); the rule is off for max_depth == 0
+            s_gt[lane] = a.o.max_depth > 0u ? ~bs_less_than<NP>(c, (unsigned long long)a.o.max_depth + 1ull) : 0u;
+            if (DEBUG) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) s_pl[0][p][lane] = c[p];
+            }
+        }
+        uint32_t vr[PER], vl[PER];
+        uint32_t sr = 0, sl = 0;
+        if (DEEP) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                sr += s_raw[tid * PER + i]; vr[i] = sr;
+                sl += s_low[tid * PER + i]; vl[i] = sl;
+            }
+        } else {
+#pragma unroll
+            for (int h = 0; h < PER / 2; ++h) {
+                const uint32_t wr = s_raw[tid * (PER / 2) + h], wl = s_low[tid * (PER / 2) + h];
+                sr += (wr & 0xFFFFu) - 0x8000u; vr[2 * h] = sr;
+                sr += (uint32_t)((int32_t)wr >> 16); vr[2 * h + 1] = sr;
+                sl += (wl & 0xFFFFu) - 0x8000u; vl[2 * h] = sl;
+                sl += (uint32_t)((int32_t)wl >> 16); vl[2 * h + 1] = sl;
+            }
+        }
+        const uint32_t ir = dpp_incl_scan_u32(sr), il = dpp_incl_scan_u32(sl);
+        if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
+        __syncthreads();
+        uint32_t offr = ir - sr, offl = il - sl;
+        for (uint32_t i = 0; i < wv; ++i) { offr += s_wraw[i]; offl += s_wlow[i]; }
+        uint32_t mx = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) { vr[i] += offr; vl[i] += offl; mx = vr[i] > mx ? vr[i] : mx; }
+        const uint32_t n_ok = p0 >= a.extent ? 0u : (a.extent - p0 < (uint32_t)PER ? a.extent - p0 : (uint32_t)PER);
+        // this thread's 8 positions are byte (tid & 3) of block tid >> 2
+        const uint32_t lt8 = (s_lt[tid >> 2] >> (8u * (tid & 3u))) & 0xFFu;
+        const uint32_t gt8 = (s_gt[tid >> 2] >> (8u * (tid & 3u))) & 0xFFu;
+
+        uint32_t S[PER / 4];
+        uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, ncov = 0;
+        if (!DEEP && mx < kLutLds && n_ok == (uint32_t)PER) {
+            // ---- byte-parallel path: four positions per 32-bit word ----
+            const uint32_t ONES = 0x01010101u;
+#pragma unroll
+            for (int h = 0; h < PER / 4; ++h) {
+                uint32_t cov = 0, low = 0;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t raw = vr[4 * h + i];
+                    cov |= (raw < 1u ? raw : 1u) << (8 * i);
+                    low |= (vl[4 * h + i] >= (uint32_t)s_lut[raw] ? 1u : 0u) << (8 * i);   // callable_profiler.rs:100-101
+                }
+                const uint32_t x = (refw[h] | 0x20202020u) ^ 0x6e6e6e6eu;   // zero byte <=> 'N' or 'n'
+                const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7;
+                const uint32_t N = ~nz & ONES;
+                const uint32_t lt = __umul24((lt8 >> (4 * h)) & 15u, 0x204081u) & ONES;    // 4 mask bits -> 4 bytes
+                const uint32_t gt = __umul24((gt8 >> (4 * h)) & 15u, 0x204081u) & ONES;
+                // priorities of callable_profiler.rs:104-116, resolved into disjoint flags
+                const uint32_t t0 = ~N & cov;
+                const uint32_t rLow = t0 & low, t1 = t0 & ~low;
+                const uint32_t rLT = t1 & lt, t2 = t1 & ~lt;
+                const uint32_t rGT = t2 & gt, rC = t2 & ~gt;
+                const uint32_t rNC = ~N & ~cov & ONES;
+                S[h] = rC + (rNC << 1) + rLT + (rLT << 1) + (rGT << 2) + rLow + (rLow << 2);
+                cnt[0] += __popc(N); cnt[1] += __popc(rC); cnt[2] += __popc(rNC);
+                cnt[3] += __popc(rLT); cnt[4] += __popc(rGT); cnt[5] += __popc(rLow);
+                ncov += __popc(cov);
+            }
+        } else {
+            // ---- general path, one position at a time ----
+            uint32_t st[PER];
+            for (int i = 0; i < PER; ++i) {
+                const uint32_t raw = vr[i], low = vl[i];
+                bool is_low = false;                                                  // callable_profiler.rs:100-101
+                if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
+                    if (raw < kLutSize) is_low = low >= a.lut[raw];
+                    else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
+                }
+                const uint32_t rb = (refw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
+                uint32_t sx = 1u;                                                     // CALLABLE
+                sx = ((gt8 >> i) & 1u) ? 4u : sx;                                     // EXCESSIVE_COVERAGE
+                sx = ((lt8 >> i) & 1u) ? 3u : sx;                                     // LOW_COVERAGE
+                sx = is_low ? 5u : sx;                                                // POOR_MAPPING_QUALITY
+                sx = raw == 0 ? 2u : sx;                                              // NO_COVERAGE
+                sx = ((rb | 0x20u) == 'n') ? 0u : sx;                                 // REF_N
+                const bool ok = (uint32_t)i < n_ok;
+                if (ok) { cnt[sx] += 1; ncov += raw > 0 ? 1u : 0u; }
+                st[i] = ok ? sx : 0xFFu;
+            }
+#pragma unroll
+            for (int h = 0; h < PER / 4; ++h)
+                S[h] = st[4 * h] | (st[4 * h + 1] << 8) | (st[4 * h + 2] << 16) | (st[4 * h + 3] << 24);
+        }
+        if (DEBUG) {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                uint32_t qc = 0;
+                const uint32_t bit = 8u * (tid & 3u) + (uint32_t)i;
+#pragma unroll
+                for (int p = 0; p < NP; ++p) qc |= ((s_pl[0][p][tid >> 2] >> bit) & 1u) << p;
+                if (a.dbg_raw) a.dbg_raw[p0 + i] = vr[i];
+                if (a.dbg_low) a.dbg_low[p0 + i] = vl[i];
+                if (a.dbg_qc) a.dbg_qc[p0 + i] = qc;
+            }
+        }
+        // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
+        s_last[tid] = (uint8_t)(S[PER / 4 - 1] >> 24);
+        mx = dpp_wave_max_u32(mx);
+        if (lane == 0) s_wmax[wv] = mx;
+        __syncthreads();
+        uint32_t nb = 0;
+        uint32_t bmk[PER / 4];
+        {
+            uint32_t prevb = tid > 0 ? (uint32_t)s_last[tid - 1] : (S[0] & 0xFFu);
+            // 0x01 for the positions < extent
+            const uint32_t okb = (1u << n_ok) - 1u;
+            const uint32_t okw[2] = {__umul24(okb & 15u, 0x204081u) & 0x01010101u, __umul24((okb >> 4) & 15u, 0x204081u) & 0x01010101u};
+#pragma unroll
+            for (int h = 0; h < PER / 4; ++h) {
+                const uint32_t P = (S[h] << 8) | prevb;
+                const uint32_t d = S[h] ^ P;
+                bmk[h] = ((((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) >> 7) & okw[h];
+                nb += __popc(bmk[h]);
+                prevb = S[h] >> 24;
+            }
+        }
+        if (DEBUG) {
+#pragma unroll
+            for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
+        }
+        if (!DEEP && NP == 8) {
+            // a thread's counts are <= 8, every wave total <= 512: packed words, one butterfly reduction each; the
+            // wave's set bits are < 2^18 (16 groups of 4 rows x 2048 bits)
+            uint32_t pk[4];
+            pk[0] = cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
+            pk[1] = cnt[3] | (cnt[4] << 10) | (cnt[5] << 20);
+            pk[2] = ncov | (nb << 10);
+            pk[3] = (uint32_t)nbits;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) pk[q] = dpp_wave_sum_u32(pk[q]);
+            if (lane == 0) {
+                unsigned long long *t = s_wtot[wv];
+                t[0] = pk[0] & 1023u; t[1] = (pk[0] >> 10) & 1023u; t[2] = pk[0] >> 20;
+                t[3] = pk[1] & 1023u; t[4] = (pk[1] >> 10) & 1023u; t[5] = pk[1] >> 20;
+                t[6] = pk[2] & 1023u; t[9] = pk[2] >> 10;
+                t[7] = pk[3]; t[8] = 0;
+                t[10] = win_len; t[11] = win_mq;
+            }
+        } else {
+            unsigned long long v[10];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) v[q] = cnt[q];
+            v[6] = ncov; v[7] = nbits; v[8] = 0; v[9] = nb;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) {
+                const unsigned long long r = wave_sum_u64(v[q]);
+                if (lane == 0) s_wtot[wv][q] = r;
+            }
+            if (lane == 0) { s_wtot[wv][10] = win_len; s_wtot[wv][11] = win_mq; }
+        }
+        __syncthreads();
+        {
+            const uint32_t inc = dpp_incl_scan_u32(nb);
+            if (nb) {
+                uint32_t off = inc - nb;
+                for (uint32_t i = 0; i < wv; ++i) off += (uint32_t)s_wtot[i][9];
+                uint16_t *dst = a.runs + (size_t)w * T + off;
+#pragma unroll
+                for (int h = 0; h < PER / 4; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if ((bmk[h] >> (8 * j)) & 1u) *dst++ = (uint16_t)((tid * PER + 4 * h + j) | (((S[h] >> (8 * j)) & 7u) << 12));
+            }
+            if (tid == 0) a.first_state[w] = (uint8_t)(S[0] & 0xFFu);
+            if (tid == kBlock - 1) a.last_state[w] = (uint8_t)(S[PER / 4 - 1] >> 24);
+        }
+    }
+    if (tid == 0) {
+        WinPartial wp;
+        unsigned long long tot[12];
+        for (int q = 0; q < 12; ++q) { tot[q] = 0; for (int i = 0; i < kWaves; ++i) tot[q] += s_wtot[i][q]; }
+        for (int q = 0; q < 6; ++q) wp.cnt[q] = tot[q];
+        wp.n_cov = tot[6]; wp.sum_qc = tot[7]; wp.sum_q = tot[8];
+        wp.sum_reflen = tot[10]; wp.sum_mapq_reflen = tot[11];
+        wp.n_inner = (uint32_t)tot[9];
+        uint32_t m = 0;
+        for (int i = 0; i < kWaves; ++i) m = s_wmax[i] > m ? s_wmax[i] : m;
+        wp.max_raw = m;
+        a.winpart[w] = wp;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // k_fin_windows / fin_summary: exclusive scan of the run starts per window inside blocks of kFinBlock
 // windows (inner boundaries + the seam with the previous window) and reduction of the window
 // partials to the contig summary (fin_summary runs as the last workgroup of k_rle_write).
@@ -1001,7 +1397,7 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
 // one workgroup of kBlock threads (the extra, last workgroup of k_rle_write).
 __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
                                             uint32_t extent, uint32_t *__restrict__ err_flag,
-                                            DevSummary *__restrict__ out)
+                                            DevSummary *__restrict__ out, unsigned long long host_sum_q)
 {
     __shared__ unsigned long long s_red[12][kBlock / 64];
     __shared__ uint32_t s_u[kBlock / 64];
@@ -1030,7 +1426,8 @@ __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, 
         for (int i = 0; i < 6; ++i) out->state_counts[i] = tot[i];
         out->n_covered_bases = tot[6];
         out->quality_bases = tot[7];
-        out->summed_baseq = tot[8];
+        // (pass-bit form: the kernels see bits, the sum of the passing qualities comes from the host's walk over the bytes)
+        out->summed_baseq = tot[8] + host_sum_q;
         out->summed_coverage = tot[9];
         out->summed_mapq = tot[10];
         out->extent = extent;
@@ -1057,10 +1454,11 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
                                                        uint32_t *__restrict__ err_flag,
                                                        DevSummary *__restrict__ summary,
                                                        uint32_t n_win, uint32_t extent,
-                                                       Interval *__restrict__ iv, uint32_t iv_cap)
+                                                       Interval *__restrict__ iv, uint32_t iv_cap,
+                                                       unsigned long long host_sum_q)
 {
     if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: the contig summary
-        fin_summary(fin, n_fin, extent, err_flag, summary);
+        fin_summary(fin, n_fin, extent, err_flag, summary, host_sum_q);
         return;
     }
     // one wave per window: its seam run (if the first state differs from the previous window's last)
@@ -1090,38 +1488,6 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
     if (w == n_win - 1 && lane == 0) {                     // the last run ends where classification ends
         const uint32_t last = idx0 + seam + n_inner;
         if (last > 0 && last - 1 < iv_cap) iv[last - 1].end = extent;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// k_repack_qual (short-read form, once per upload): the quality bytes of every record's run move from where the tile
-// put them to the aligned layout -- each read's string shifted by its running pad so that the first run's bytes for
-// reference positions 16u .. 16u + 15 are one 16-byte aligned block (callable_loci.hip: build_qual_alignment).  A lane
-// quad per record; a record's bytes are written by it alone (runs never overlap in the array), 16 at a time and the tail
-// byte by byte.  rec.qual_lo is the low half of the run's new offset; base[b] <= the offsets of the block's records,
-// within 2^32 of them.
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_repack_qual(const ReadRec *__restrict__ rec, const uint32_t *__restrict__ shift,
-                                                         const unsigned long long *__restrict__ base, uint32_t n_rec,
-                                                         const uint8_t *__restrict__ raw, uint8_t *__restrict__ al)
-{
-    const uint32_t j = blockIdx.x * 64u + (threadIdx.x >> 2), ql = threadIdx.x & 3u;
-    if (j >= n_rec) return;
-    const uint4 rr = *reinterpret_cast<const uint4 *>(rec + j);
-    const uint32_t len = rr.w >> 16;
-    if (len == 0u) return;
-    const unsigned long long b = base[blockIdx.x];
-    const unsigned long long dst = b + (uint32_t)(rr.z - (uint32_t)b), src = dst - shift[j];
-    if (len < 16u) {
-        if (ql == 0u) for (uint32_t i = 0; i < len; ++i) al[dst + i] = raw[src + i];
-        return;
-    }
-    // 16 bytes at a time; the last block of a run is moved back to end with the run (bytes written twice get the same value)
-    for (uint32_t k = ql * 16u; k < len; k += 64u) {
-        const uint32_t kk = k + 16u <= len ? k : len - 16u;
-        Q16 v;
-        __builtin_memcpy(&v, raw + src + kk, 16);
-        __builtin_memcpy(al + dst + kk, &v, 16);
     }
 }
 

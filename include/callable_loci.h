@@ -125,15 +125,19 @@ cl_status cl_contig_begin(cl_ctx *ctx, int32_t tid, uint32_t contig_len,
 /* Optional size hint for the contig that was just begun: totals over all tiles that will be pushed.
  * Saves regrowing the staging / device buffers; never required. */
 cl_status cl_contig_reserve(cl_ctx *ctx, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes);
-/* Optional: starts sending quality bytes to the device before their tile is pushed, so that the transfer runs
+/* Optional, byte forms only (DUT_QUAL_FORM=bytes; a no-op in the default pass-bit form, where no quality byte goes to
+ * the device): starts sending quality bytes to the device before their tile is pushed, so that the transfer runs
  * beside the caller's own work on the records (the host driver's read admission, say).  `qual` must be exactly
  * the bytes the NEXT cl_push_reads will present (tile.qual + tile.qual_off[0], tile.qual_off[n] - tile.qual_off[0]
  * of them) and must stay valid until that call returns; a push that presents anything else simply sends its own
  * bytes (the prefetch is dropped).  Blocks of less than 4 MiB are ignored.  Never required. */
 cl_status cl_contig_prefetch_qual(cl_ctx *ctx, const uint8_t *qual, uint64_t n_bytes);
-/* Appends a tile (coordinate order across tiles).  The caller's buffers are free again on return:
- * small tiles are copied to host staging, the quality bytes of tiles of >= 4 MiB go to HBM through a pinned staging
- * ring (the fills of the pinned buffers overlap the transfers). */
+/* Appends a tile (coordinate order across tiles).  The caller's buffers are free again on return.  The base-quality
+ * test of mod.rs:33 is taken here, where the quality bytes are read once ("or a packed pass-bitmask
+ * variant"; 8d: q = 1/8): one bit per base stays in host staging, together with the tile's share of summed_baseq
+ * (contig_profiler.rs:65-70, a per-read separable sum); cl_contig_upload lays the bits out as the rows the pileup
+ * kernel counts.  With DUT_QUAL_FORM=bytes in the environment of cl_create the quality bytes themselves go to HBM
+ * (small tiles via host staging, tiles of >= 4 MiB through a pinned staging ring) and are tested on the device. */
 cl_status cl_push_reads(cl_ctx *ctx, const cl_read_tile *tile);
 /* upload + run + collect in one call.  *intervals points at context-owned memory, valid until
  * the next cl_contig_begin / cl_destroy. */
@@ -165,10 +169,26 @@ cl_status cl_set_profiling(cl_ctx *ctx, int on);
  * and CL_K_BOUNDS read 0 (the slots are kept so that the table's layout does not change). */
 cl_status cl_get_kernel_ms(cl_ctx *ctx, double ms[CL_K_COUNT], uint64_t *n_runs);
 cl_status cl_reset_kernel_ms(cl_ctx *ctx);
-/* Bytes of the resident inputs the pileup kernel must read at least once (quality bytes, per-read fields, CIGAR
- * words, reference bases) and of the intervals it leaves behind (12 bytes each; the per-position counters and
- * states never reach HBM): the algorithmic traffic of one cl_contig_run. */
+/* Bytes of the resident inputs the pileup kernel of the contig's form must read at least once, counted strictly --
+ * the array elements that kernel addresses: pass-bit rows or quality bytes, read records or run-table entries and
+ * per-read fields, reference bases, window records; no CIGAR word (none is resident) -- and of the intervals it leaves
+ * behind (12 bytes each; the per-position counters and states never reach HBM): the traffic one cl_contig_run cannot
+ * do without. */
 cl_status cl_contig_bytes(cl_ctx *ctx, uint64_t *input_bytes, uint64_t *output_bytes);
+/* What is resident for the uploaded contig: the form of the pileup kernel (3 pass-bit rows; 0 records + quality bytes,
+ * 2 run table + quality bytes: DUT_QUAL_FORM=bytes), element counts, and the HBM the context holds. */
+typedef struct cl_layout_info {
+    int32_t  form;
+    uint32_t counter_planes;      /* pass-bit form: 8, 16 or 32 bit-sliced counter planes                        */
+    uint64_t n_reads, n_records, n_windows;
+    uint64_t n_qual;              /* quality bytes of the contig (on the device only in the byte forms)          */
+    uint64_t n_cigar;             /* CIGAR operations of the contig (never on the device)                        */
+    uint64_t row_groups;          /* pass-bit form: 1 KB groups of 4 rows                                        */
+    uint64_t max_groups;          /* ... most groups of any window                                               */
+    uint64_t run_table_entries;   /* byte form 2                                                                 */
+    uint64_t device_bytes;        /* capacity of every device buffer of the context                              */
+} cl_layout_info;
+cl_status cl_contig_layout(cl_ctx *ctx, cl_layout_info *out);
 
 /* ---- test hooks ------------------------------------------------------------------------- */
 /* Re-runs the resident contig with per-position dumps: raw_depth, qc_depth, low_mapq_count
@@ -187,6 +207,22 @@ cl_status cl_debug_depths(cl_ctx *ctx, uint32_t *raw, uint32_t *qc, uint32_t *lo
 cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_ops, uint8_t mapq, uint8_t min_mapping_quality,
                                 uint64_t qual_off, uint64_t qual_len, uint32_t *out, uint32_t cap,
                                 uint32_t *n_records, uint32_t *phase);
+
+/* Host only: the pass bits of n quality bytes (words_out: ceil(n / 64) 64-bit words, bit i of word i / 64 <-> byte i,
+ * zeros above byte n) and the sum of the passing bytes, as cl_push_reads takes them -- at `level` 0 scalar, 1 SSE2,
+ * 2 AVX2 where the CPU has it (else SSE2). */
+cl_status cl_debug_qual_pack(const uint8_t *qual, uint64_t n, uint8_t min_base_quality, int level, uint64_t *words_out,
+                             uint64_t *sum_out);
+/* A context WITHOUT a device, for the CPU test suite only: cl_contig_begin / cl_push_reads (pass-bit form) stage a
+ * contig on the host exactly as a device context does, and cl_debug_pass_rows runs the upload's row builder over it.
+ * Every call that needs a device fails with CL_ERR_DEVICE: there is no CPU pileup. */
+cl_status cl_debug_host_create(const cl_options *opt, cl_ctx **out);
+/* The pass-bit rows of the staged contig as cl_contig_upload would build them (pass_rows.h): n_groups[w] groups of 4 rows
+ * per window of 2048 positions (n_win_cap entries at most; *n_windows = how many there are), the groups themselves window
+ * after window in rows[0, cap_words) (256 words each: word (block << 2) | (row & 3) of group row >> 2; *n_words = how
+ * many words there are, also when that exceeds cap_words), and the contig's share of summed_baseq from the push walk. */
+cl_status cl_debug_pass_rows(cl_ctx *ctx, uint32_t *n_groups, uint32_t n_win_cap, uint32_t *rows, uint64_t cap_words,
+                             uint64_t *n_words, uint32_t *n_windows, uint64_t *summed_baseq);
 
 /* ---- config 5: site-list pileup (haplogroup::caller::process_region,
  *      src/haplogroup/caller.rs:62-152) ---------------------------------------------------- */

@@ -15,6 +15,41 @@ from decodingustools_amd.records import ContigRecords
 
 pytestmark = pytest.mark.gpu
 KATS = load_kats()
+
+# The engine has two kinds of pileup kernel: the pass-bit form (default: the base-quality test is taken on the host, the
+# device counts rows of bits) and the byte forms of rounds 1-3 (DUT_QUAL_FORM=bytes at cl_create: the quality bytes go to
+# the device; records for short reads, the run table for long ones).  Every test runs in the default form; the tests
+# named here run in the byte forms too (or only there: what they exercise exists only in those).
+BYTES_TOO = {
+    "test_kats_on_gpu", "test_adversarial_contigs", "test_short_reads_2mb_30x", "test_long_reads_indel_rich",
+    "test_deep_pileup_uses_32bit_counters", "test_record_form_covers_every_read_shape",
+    "test_run_table_with_one_base_runs_needs_the_second_sizing_pass", "test_run_table_with_truncated_qualities_and_long_runs",
+    "test_hifi_like_long_match_runs_and_truncated_qualities", "test_quality_prefetch_is_claimed_by_the_matching_tile_and_harmless_otherwise",
+    "test_tiles_of_mixed_sizes_small_staged_large_direct", "test_a_long_read_shaped_tile_in_a_short_read_contig",
+    "test_long_reads_with_eqx_cigars", "test_records_through_small_pinned_buffers", "test_tiled_pushes_on_a_long_lived_engine",
+    "test_operation_parallel_variant_with_16bit_and_32bit_counters", "test_deeper_short_read_data_keeps_the_8bit_counters",
+    "test_a_refused_tile_leaves_the_contig_as_it_was", "test_long_reads_in_tiles_with_a_refused_tile_between",
+    "test_an_error_behind_a_quality_prefetch_leaves_nothing_in_flight", "test_outlier_spans_do_not_widen_every_window",
+}
+BYTES_ONLY = {"test_run_table_through_small_pinned_buffers", "test_run_table_window_whose_last_piece_belongs_to_the_first_read"}
+
+
+def pytest_generate_tests(metafunc):
+    if "qual_form" in metafunc.fixturenames:
+        name = metafunc.function.__name__
+        forms = ["bytes"] if name in BYTES_ONLY else (["bits", "bytes"] if name in BYTES_TOO else ["bits"])
+        metafunc.parametrize("qual_form", forms)
+
+
+@pytest.fixture(autouse=True)
+def qual_form(request, monkeypatch):
+    """DUT_QUAL_FORM for the contexts (and child processes) of this test."""
+    form = getattr(request, "param", "bits")
+    if form == "bytes":
+        monkeypatch.setenv("DUT_QUAL_FORM", "bytes")
+    else:
+        monkeypatch.delenv("DUT_QUAL_FORM", raising=False)
+    return form
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 
 
@@ -1190,33 +1225,11 @@ def test_records_through_small_pinned_buffers(chunk):
     assert r.returncode == 0 and "REC_CHUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
-_NO_ALIGN_CASE = r"""
-import os, sys, tempfile, pathlib
-sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
-import test_gpu_parity as T
-from decodingustools_amd import synth
-L, rec, ref = T.record_shapes_contig(L=120_000, n_plain=1500)
-T.compare([("chrS", 4, L, ref, rec)], dict(min_mapping_quality=0), pathlib.Path(tempfile.mkdtemp()), "noalign")
-L = 300_000
-T.compare([("chr21", 20, L, synth.make_reference(L, 7), synth.short_read_contig(L, 30, 8))], dict(), pathlib.Path(tempfile.mkdtemp()), "noalign_s")
-print("NO_ALIGN_OK")
-"""
-
-
-def test_short_read_form_without_the_aligned_quality_layout():
-    """DUT_QUAL_ALIGN=0: the records point at the quality bytes where the tile put them (what the engine also falls back
-    to when the second quality buffer cannot be had) -- same results.  (The switch is read once per process.)"""
-    import subprocess
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, DUT_QUAL_ALIGN="0")
-    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _NO_ALIGN_CASE], env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0 and "NO_ALIGN_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
-
-
-def test_aligned_layout_over_several_tiles_and_contigs(tmp_path):
-    """The pads of the aligned layout depend on the previous read, across tile seams too; a context that keeps its
-    buffers from one contig to the next (larger, then smaller, then larger) must not read stale bytes: tiled pushes on a
-    long-lived engine give what a single push on a fresh engine gives (which the other tests hold against the oracle)."""
+def test_tiled_pushes_on_a_long_lived_engine(tmp_path):
+    """The pass bits of a tile start and end inside words of the contig's bit array (byte forms: small tiles are staged,
+    large ones go directly); a context that keeps its buffers from one contig to the next (larger, then smaller, then
+    larger) must not read stale data: tiled pushes on a long-lived engine give what a single push on a fresh engine gives
+    (which the other tests hold against the oracle)."""
     opt = CallableOptions()
     contigs = []
     for k, (L, depth, seed) in enumerate([(400_000, 30, 11), (90_000, 45, 12), (250_000, 12, 13)]):
@@ -1232,12 +1245,14 @@ def test_aligned_layout_over_several_tiles_and_contigs(tmp_path):
     with Engine(opt, 0) as eng:
         for (tid, L, ref, rec), w in zip(contigs, want):
             eng.contig_begin(tid, L, ref)
-            cuts = [0, 1, 2, 1000, 1001, rec.n // 3, rec.n // 3 + 7, rec.n]      # small tiles are staged, large ones go directly
+            cuts = [0, 1, 2, 1000, 1001, rec.n // 3, rec.n // 3 + 7, rec.n]
             for a, b in zip(cuts[:-1], cuts[1:]):
                 if b > a:
                     push(eng, rec.slice(a, b))
             got = eng.contig_finish()
             assert got.as_dict() == w.as_dict() and np.array_equal(got.intervals, w.intervals), tid
+            lay = eng.contig_layout()
+            assert lay["form"] == (3 if os.environ.get("DUT_QUAL_FORM") != "bytes" else 0) and lay["n_reads"] == rec.n
             eng.contig_run()
             again = eng.contig_collect()
             assert again.as_dict() == w.as_dict() and np.array_equal(again.intervals, w.intervals), tid
@@ -1280,3 +1295,59 @@ def test_run_table_window_whose_last_piece_belongs_to_the_first_read(tmp_path):
     compare([("chrF", 1, L, ref, rec)], dict(min_depth=4, max_depth=0, min_mapping_quality=1, min_base_quality=255, min_depth_for_low_mapq=5,
                                              max_low_mapq=1, max_low_mapq_fraction=0.5), tmp_path, "fuzz300026")
     compare([("chrF", 1, L, ref, rec)], dict(), tmp_path, "fuzz300026b")
+
+
+# ---- the pass-bit form: rows of bits built on the host at upload (pass_rows.h), counted bit-sliced by k_pileup_rows ----
+_ROW_CHUNK_CASE = r"""
+import os, sys, tempfile, pathlib
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import test_gpu_parity as T
+from decodingustools_amd import synth
+L = 150_000
+rec = synth.long_read_contig(L, 50, synth.seed_for(3, 31))
+T.compare([("chrR", 5, L, synth.make_reference(L, synth.seed_for(3, 31)), rec)], dict(), pathlib.Path(tempfile.mkdtemp()), "rows_long_" + os.environ["DUT_ROW_CHUNK"])
+L = 200_000
+T.compare([("chr21", 20, L, synth.make_reference(L, 7), synth.short_read_contig(L, 30, 8))], dict(), pathlib.Path(tempfile.mkdtemp()), "rows_short_" + os.environ["DUT_ROW_CHUNK"])
+print("ROW_CHUNK_OK")
+"""
+
+
+@pytest.mark.parametrize("chunk", ["1", "9", "64"])
+def test_rows_through_small_pinned_buffers(chunk):
+    """The groups of a window go to HBM through pinned buffers of DUT_ROW_CHUNK groups (1 KB each): 1 -- every window is
+    larger than a buffer and travels as a block of its own; 9 -- a buffer holds about one ordinary window, the buffer-full
+    path with the window started over; 64 -- a few windows per buffer.  (The knob is read once per process.)"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DUT_ROW_CHUNK=chunk)
+    r = subprocess.run([sys.executable, "-c", f"ROOT = {root!r}\n" + _ROW_CHUNK_CASE], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ROW_CHUNK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+@pytest.mark.parametrize("depth,planes", [(200, 8), (300, 16), (66_000, 32)])
+def test_counter_planes_follow_the_deepest_window(depth, planes, tmp_path):
+    """k_pileup_rows counts in 8 bit planes while no window has more than 255 rows (63 groups of 4), in 16 beyond; the
+    depth thresholds are compared bit-sliced, so thresholds beyond what the planes can count to must also work."""
+    L = 7000
+    rng = np.random.default_rng(depth)
+    reads = [[int(p), "120M" if depth < 1000 else "20M", int(rng.choice([10, 20, 60, 60])), int(rng.choice([10, 20, 40])), 0, f"d{i}"]
+             for i, p in enumerate(np.sort(rng.integers(2000, 2060 if depth < 1000 else 2004, depth)))]
+    reads += [[int(p), "100M", 60, 30, 0, f"e{i}"] for i, p in enumerate(np.sort(rng.integers(0, L - 100, 300)))]
+    reads.sort(key=lambda r: r[0])
+    rec = ContigRecords.from_reads(reads)
+    ref = synth.make_reference(L, 5)
+    if depth < 1000:
+        trials = (dict(), dict(min_depth=150, max_depth=450), dict(min_depth=256, max_depth=499), dict(min_depth=70000, max_depth=100000),
+                  dict(min_depth=0, max_depth=255, min_base_quality=0, min_mapping_quality=0))
+    else:          # (the depth cap of the admission rule is max_depth: lifted so that all 66 000 reads are in the pileup)
+        trials = (dict(max_depth=1_000_000), dict(min_depth=65_536, max_depth=1_000_000))
+    for o in trials:
+        compare([("chrD", 3, L, ref, rec)], o, tmp_path, f"planes{depth}")
+    opt = _opts(trials[0])
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(3, L, ref)
+        eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        eng.contig_finish()
+        lay = eng.contig_layout()
+    assert lay["form"] == 3 and lay["counter_planes"] == planes, lay
+    assert lay["n_qual"] == rec.qual.shape[0] and lay["row_groups"] >= lay["max_groups"] > 0

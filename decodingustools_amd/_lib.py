@@ -40,7 +40,8 @@ class cl_interval(C.Structure):
 class cl_layout_info(C.Structure):
     _fields_ = [("form", C.c_int32), ("counter_planes", C.c_uint32), ("n_reads", C.c_uint64), ("n_records", C.c_uint64),
                 ("n_windows", C.c_uint64), ("n_qual", C.c_uint64), ("n_cigar", C.c_uint64), ("row_groups", C.c_uint64),
-                ("max_groups", C.c_uint64), ("run_table_entries", C.c_uint64), ("device_bytes", C.c_uint64)]
+                ("max_groups", C.c_uint64), ("run_table_entries", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("upload_h2d_bytes", C.c_uint64)]
 
 
 class cl_site_tile(C.Structure):

@@ -261,8 +261,9 @@ static std::shared_ptr<PinRing> acquire_ring(int device)
 struct StagingSet {
     RawVec<uint8_t> ref, mapq;
     RawVec<int32_t> pos;
-    RawVec<uint32_t> cigar_off, cigar, end, ck_x, ck_y;
+    RawVec<uint32_t> cigar_off, cigar, end, ck_x, ck_y, rec_cnt;
     RawVec<unsigned long long> qual_off;
+    RawVec<uint64_t> qbits;
 };
 constexpr size_t kStagingSets = 2;
 static std::mutex g_staging_mu;
@@ -391,6 +392,7 @@ static void swap_staging(cl_ctx *c, StagingSet &o)
 {
     c->h_ref.swap(o.ref); c->h_mapq.swap(o.mapq); c->h_pos.swap(o.pos); c->h_cigar_off.swap(o.cigar_off);
     c->h_cigar.swap(o.cigar); c->h_end.swap(o.end); c->h_ck_x.swap(o.ck_x); c->h_ck_y.swap(o.ck_y); c->h_qual_off.swap(o.qual_off);
+    c->h_qbits.swap(o.qbits); c->h_rec_cnt.swap(o.rec_cnt);
 }
 // a context without staging memory of its own takes a pooled set (cl_contig_begin) ...
 static void take_staging(cl_ctx *c)
@@ -411,7 +413,7 @@ static void give_staging(cl_ctx *c)
     if (!s) return;
     swap_staging(c, *s);
     s->ref.clear(); s->mapq.clear(); s->pos.clear(); s->cigar_off.clear(); s->cigar.clear(); s->end.clear();
-    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear();
+    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear(); s->qbits.clear(); s->rec_cnt.clear();
     std::lock_guard<std::mutex> g(g_staging_mu);
     if (g_staging.size() < kStagingSets) { g_staging.push_back(std::move(s)); return; }
     size_t small = 0;
@@ -1591,6 +1593,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             if (t->qual_off[i] < q0 || t->qual_off[i + 1] > q0 + nq) { if (!o.bad) o.bad = 3; continue; }
             const uint32_t q0i = t->cigar_off[i], q1i = t->cigar_off[i + 1], nops = q1i - q0i;
             unsigned long long l = 0;
+            uint64_t long_sum = 0;
             if (nops <= kLongOps) {
                 for (uint32_t q = q0i; q < q1i; ++q) {
                     const uint32_t cw = t->cigar[q], len = cw >> 4;
@@ -1604,6 +1607,12 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
                 o.n_long += 1;
                 uint32_t yq = 0;                                               // query advance (M I S = X), modulo 2^32
                 const uint32_t shift = cbase - cig0;                           // tile op index -> contig op index (mod 2^32)
+                // (pass-bit form: the read's share of summed_baseq is its whole quality string's passing bytes minus
+                // those of its inserted and clipped bases -- taken here, in the one loop over its operations)
+                const unsigned long long qli = t->qual_off[i + 1] - t->qual_off[i];
+                const uint8_t *qi = (bits && qli && t->mapq[i] >= min_mapq) ? qsrc + (t->qual_off[i] - q0) : nullptr;
+                unsigned long long y64 = 0;
+                uint64_t minus = 0;
                 for (uint32_t q = q0i; q < q1i; ++q) {
                     const uint32_t kc = q + shift;
                     if ((kc & 63u) == 0u) {
@@ -1616,7 +1625,13 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
                     l += radv ? len : 0u;
                     yq += qadv ? len : 0u;
                     if (radv && len == 0u) o.err |= kErrCigar;
+                    if (qadv) {
+                        if (qi && !radv)                                       // I S
+                            for (unsigned long long b2 = y64, e2 = std::min<unsigned long long>(qli, y64 + len); b2 < e2; ++b2) minus += qi[b2] >= min_bq ? qi[b2] : 0u;
+                        y64 += len;
+                    }
                 }
+                if (qi) long_sum = dut::qual_pass_sum(qi, std::min<unsigned long long>(qli, y64), min_bq, plevel) - minus;
             }
             const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
             // an end beyond the engine's 32-bit coordinate range: flagged; the read then spans nothing
@@ -1632,7 +1647,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
                 h_rec_cnt[i] = in_pileup ? 1u : 0u;
                 const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
                 if (in_pileup && ql && t->mapq[i] >= min_mapq)
-                    o.sum_q += read_pass_sum(qsrc + (t->qual_off[i] - q0), ql, t->cigar + q0i, nops, min_bq, plevel);
+                    o.sum_q += nops > kLongOps ? long_sum : read_pass_sum(qsrc + (t->qual_off[i] - q0), ql, t->cigar + q0i, nops, min_bq, plevel);
             } else if (count_recs) {
                 // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
                 const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
@@ -1842,7 +1857,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // host time).
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qbits.clear();
-    std::vector<uint32_t>().swap(c->h_rec_of); c->h_wide_rec_of.clear();
+    c->h_rec_of.clear(); c->h_wide_rec_of.clear();       // (capacity kept for the context's next contig)
     c->h_rec_cnt.clear();
     give_staging(c);
     std::vector<uint8_t>().swap(c->h_qual);
@@ -2155,6 +2170,13 @@ cl_status cl_contig_layout(cl_ctx *c, cl_layout_info *out)
     b += c->d_winpart.cap * sizeof(WinPartial) + c->d_fin.cap * sizeof(FinPartial) + c->d_errflag.cap * 4 + c->d_runtab.cap * 8;
     b += c->d_lut.cap * 4 + c->d_summary.cap * sizeof(DevSummary) + c->d_iv.cap * sizeof(Interval) + c->d_dbg.cap * 4;
     out->device_bytes = b;
+    // what cl_contig_upload sent over the link for this contig (every transfer goes through the pinned staging ring)
+    const uint64_t padded = (uint64_t)c->n_win * kT + 16;
+    uint64_t h = padded + (uint64_t)c->n_win * sizeof(WinMeta) + (uint64_t)c->n_wide * 4;
+    if (c->form == 3) h += c->n_row_groups * (uint64_t)(dut::kRowGroupWords * sizeof(uint32_t)) + ((uint64_t)c->n_rec + 1) * sizeof(ReadRec);
+    else if (c->form == 0) h += c->n_qual + ((uint64_t)c->n_rec + 1) * sizeof(ReadRec);
+    else h += c->n_qual + c->n_runtab * 8 + (uint64_t)c->n_reads * 9;
+    out->upload_h2d_bytes = h;
     return CL_OK;
 }
 

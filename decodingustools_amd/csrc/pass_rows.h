@@ -41,18 +41,21 @@ struct RowCur { uint32_t k, k1, x, y, qlen, pos, end; unsigned long long q0; };
 
 struct RowScratch { std::vector<uint32_t> rend; };
 
-// n bits of `src` from bit offset o, OR-ed into row r of the window's groups at window-relative position d
+// n bits of `src` from bit offset o, OR-ed into row r of the window's groups at window-relative position d: up to 64
+// bits a step (two destination words: the words of a row are 16 bytes apart, one per block of 32 positions)
 inline void deposit_bits(const uint64_t *src, unsigned long long o, uint32_t n, uint32_t *grp, uint32_t r, uint32_t d)
 {
     uint32_t *dst = grp + (size_t)(r >> 2) * kRowGroupWords + (r & 3u);
     while (n) {
-        const uint32_t b = d >> 5, lo = d & 31u, take = std::min(32u - lo, n);
+        const uint32_t b = d >> 5, lo = d & 31u, take = std::min(64u - lo, n);
         const unsigned long long w = o >> 6;
         const uint32_t s = (uint32_t)(o & 63ull);
         uint64_t v = src[w] >> s;
         if (s + take > 64u) v |= src[w + 1] << (64u - s);
-        const uint32_t bits = (uint32_t)v & (take == 32u ? 0xFFFFFFFFu : ((1u << take) - 1u));
-        dst[(size_t)b << 2] |= bits << lo;
+        if (take < 64u) v &= (1ull << take) - 1ull;
+        v <<= lo;                                                   // lo + take <= 64
+        dst[(size_t)b << 2] |= (uint32_t)v;
+        if (lo + take > 32u) dst[((size_t)b + 1) << 2] |= (uint32_t)(v >> 32);
         o += take; d += take; n -= take;
     }
 }

@@ -187,6 +187,7 @@ typedef struct cl_layout_info {
     uint64_t max_groups;          /* ... most groups of any window                                               */
     uint64_t run_table_entries;   /* byte form 2                                                                 */
     uint64_t device_bytes;        /* capacity of every device buffer of the context                              */
+    uint64_t upload_h2d_bytes;    /* what cl_contig_upload (byte forms: and cl_push_reads) sent over the link    */
 } cl_layout_info;
 cl_status cl_contig_layout(cl_ctx *ctx, cl_layout_info *out);
 

@@ -175,6 +175,9 @@ SYMBOLS = [
     ("dut_coverage_files", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
                                      C.POINTER(cl_options), C.POINTER(C.c_char_p), C.c_size_t, C.c_int,
                                      C.c_char_p, C.c_size_t]),
+    ("dut_coverage_files_multi", C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p,
+                                           C.POINTER(cl_options), C.POINTER(C.c_char_p), C.c_size_t, C.POINTER(C.c_int), C.c_size_t,
+                                           C.c_uint, C.c_char_p, C.c_size_t]),
     ("dut_bam_sample", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     # include/dut_report.h
     ("dut_detect_aligner", C.c_char_p, [C.c_char_p, C.c_size_t]),

@@ -90,11 +90,13 @@ class FastaReader:
 
 def coverage_files(bam_file: str, reference_file: str, output_bed: str = "callable_regions.bed",
                    summary_json: str = None, options: CallableOptions = None, contigs=None, device_id: int = 0,
-                   output_summary: str = None):
+                   output_summary: str = None, devices=None):
     """CoverageAnalyzer::analyze on files (CoverageInput of api/coverage.rs:124-132); summary_json
     receives the CoverageOutput JSON of main.rs:68-69; output_summary, when given, the HTML report
     (api/coverage.rs:104; None: not written, the JSON then names "summary.html").  The per-contig coverage
-    figures `<contig>_coverage.svg` go beside the BED file (callable_profiler.rs:80-84)."""
+    figures `<contig>_coverage.svg` go beside the BED file (callable_profiler.rs:80-84).
+    devices: a list of HIP ordinals (one may repeat) -- the contigs are dealt to them inside the library
+    (dut_coverage_files_multi: one host thread and one engine context per entry, no torch, no collective)."""
     lib = _lib.load()
     options = options or CallableOptions()
     oc = options.to_c()
@@ -104,8 +106,14 @@ def coverage_files(bam_file: str, reference_file: str, output_bed: str = "callab
         n = len(contigs)
         arr = (C.c_char_p * max(n, 1))(*[c.encode() for c in contigs])
     err = C.create_string_buffer(1024)
-    st = lib.dut_coverage_files(bam_file.encode(), reference_file.encode(), output_bed.encode(),
-                                summary_json.encode() if summary_json else None, output_summary.encode() if output_summary else None,
-                                C.byref(oc), arr, n, device_id, err, 1024)
+    if devices is not None:
+        dv = (C.c_int * len(devices))(*[int(d) for d in devices])
+        st = lib.dut_coverage_files_multi(bam_file.encode(), reference_file.encode(), output_bed.encode(),
+                                          summary_json.encode() if summary_json else None, output_summary.encode() if output_summary else None,
+                                          C.byref(oc), arr, n, dv, len(devices), 0, err, 1024)
+    else:
+        st = lib.dut_coverage_files(bam_file.encode(), reference_file.encode(), output_bed.encode(),
+                                    summary_json.encode() if summary_json else None, output_summary.encode() if output_summary else None,
+                                    C.byref(oc), arr, n, device_id, err, 1024)
     if st != 0:
         raise EngineError(st, err.value.decode())

@@ -961,11 +961,31 @@ static void io_stage_time(const char *what, double &t0)
     t0 = t1;
 }
 
+// Contigs dealt to devices by longest-processing-time-first: the heaviest contig next, to the device with the least
+// load so far (weights: the index's mapped-read counts when it records them, the contig lengths otherwise).
+static std::vector<int> lpt_deal(const std::vector<uint64_t> &weight, size_t n_dev)
+{
+    std::vector<size_t> order(weight.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return weight[a] > weight[b]; });
+    std::vector<uint64_t> load(n_dev, 0);
+    std::vector<int> owner(weight.size(), 0);
+    for (size_t i : order) {
+        size_t best = 0;
+        for (size_t d = 1; d < n_dev; ++d) if (load[d] < load[best]) best = d;
+        owner[i] = (int)best; load[best] += weight[i] + 1;
+    }
+    return owner;
+}
+
 static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path, const char *bed_path,
                                   const char *summary_json, const char *summary_html, const cl_options *opt,
-                                  const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len)
+                                  const char *const *contigs, size_t n_contigs, const int *devices, size_t n_devices,
+                                  unsigned flags, char *err, size_t err_len)
 {
-    if (!bam_path || !fasta_path || !bed_path || !opt) { set_err(err, err_len, "null argument"); return CL_ERR_INVALID; }
+    if (!bam_path || !fasta_path || !bed_path || !opt || !devices || n_devices == 0) { set_err(err, err_len, "null argument"); return CL_ERR_INVALID; }
+    const int device_id = devices[0];
+    const bool leave = (flags & DUT_FILES_LEAVE_TO_EXIT) != 0;
     char e[512] = {0};
     double tm = io_now();
     dut_bam_stats *bstats = dut_bam_stats_new(10000);                  // api/coverage.rs:56-59
@@ -997,7 +1017,109 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
         set_err(err, err_len, "None of the specified contigs (" + list + ") were found in the BAM file");
         rc = CL_ERR_INVALID; goto out;
     }
-    {
+    if (n_devices > 1 && !tids.empty()) {
+        // ---- several devices: one host thread, one reader pair and one engine context per device; the contigs dealt by
+        //      LPT; every contig's runs, counts and statistics come back through host memory and the BED is written here,
+        //      in tid order (api/coverage.rs:229-234 is a serial loop with no cross-contig state but the BED writer's
+        //      pending line, callable_profiler.rs:64-66).  No collective: one process holds every result. ----
+        io_stage_time("(before contigs)", tm);
+        struct Result { int rc = CL_OK; std::string msg; dut_contig_stats st; uint64_t counts[6]; std::vector<cl_interval> iv; bool done = false; };
+        std::vector<Result> res(tids.size());
+        std::mutex mu;
+        std::condition_variable cv;
+        std::atomic<bool> stop{false};
+        std::vector<uint64_t> weight(tids.size());
+        for (size_t i = 0; i < tids.size(); ++i) {
+            const int64_t m = dut_bam_ref_mapped(bam, tids[i]);
+            weight[i] = m >= 0 ? (uint64_t)m : (uint64_t)dut_bam_ref_len(bam, tids[i]);
+        }
+        const std::vector<int> owner = lpt_deal(weight, n_devices);
+        prof = dut_profiler_new(bed_path);
+        if (!prof) { set_err(err, err_len, std::string("Failed to create CallableProfiler: cannot create ") + bed_path); rc = CL_ERR_INVALID; goto out; }
+        {
+            uint32_t largest = 0;
+            for (int t : tids) if (strcmp(dut_bam_ref_name(bam, t), "chrM") != 0) largest = std::max(largest, dut_bam_ref_len(bam, t));
+            dut_profiler_enable_plots(prof, largest);
+        }
+        {
+            std::vector<dut::Thread> workers;
+            for (size_t d = 0; d < n_devices; ++d) {
+                workers.push_back(dut::spawn_or_run([&, d]() {
+                    auto fail_rest = [&](size_t from, int code, const std::string &m) {
+                        std::lock_guard<std::mutex> g(mu);
+                        for (size_t i = from; i < tids.size(); ++i)
+                            if (owner[i] == (int)d && !res[i].done) { res[i].rc = code; res[i].msg = m; res[i].done = true; }
+                        cv.notify_all();
+                    };
+                    char e2[512] = {0};
+                    cl_ctx *dctx = nullptr;
+                    dut_bam *db = nullptr; dut_fasta *df = nullptr;
+                    try {
+                        int drc = cl_create(opt, devices[d], nullptr, &dctx);
+                        if (drc != CL_OK) { fail_rest(0, drc, "no usable HIP device (the engine has no CPU fallback)"); return; }
+                        db = dut_bam_open(bam_path, e2, sizeof(e2));
+                        if (!db) { fail_rest(0, CL_ERR_INVALID, std::string("Failed to open BAM file: ") + e2); cl_destroy(dctx); return; }
+                        df = dut_fasta_open(fasta_path, e2, sizeof(e2));
+                        if (!df) { fail_rest(0, CL_ERR_INVALID, std::string("Failed to open reference: ") + e2); dut_bam_close(db); cl_destroy(dctx); return; }
+                        for (size_t i = 0; i < tids.size(); ++i) {
+                            if (owner[i] != (int)d) continue;
+                            if (stop.load()) { fail_rest(i, CL_ERR_INVALID, "abandoned"); break; }
+                            const int t = tids[i];
+                            dut_records rec;
+                            const uint8_t *bases = nullptr; uint64_t blen = 0;
+                            int frc = CL_OK;
+                            dut::Thread fb;
+                            if (dut_bam_ref_len(db, t) > 0)
+                                fb = dut::spawn_or_run([&]() { frc = dut_fasta_fetch(df, dut_bam_ref_name(db, t), &bases, &blen); });
+                            drc = dut_bam_read_contig(db, t, &rec, nullptr, nullptr);
+                            if (fb.joinable()) fb.join();
+                            if (drc != CL_OK) { fail_rest(i, drc, std::string("Error processing contig: ") + dut_bam_error(db)); break; }
+                            if (frc != CL_OK) { fail_rest(i, frc, std::string("Error processing contig: ") + dut_fasta_error(df)); break; }
+                            Result r;
+                            memset(&r.st, 0, sizeof(r.st));
+                            const cl_interval *iv = nullptr; size_t niv = 0;
+                            drc = dut_process_single_contig_runs(dctx, &r.st, opt, t, dut_bam_ref_len(db, t), bases, blen, &rec, r.counts, &iv, &niv);
+                            if (drc != CL_OK) {
+                                const char *m = cl_last_error(dctx);
+                                fail_rest(i, drc, std::string("Error processing contig: ") + ((m && *m) ? m : (drc == CL_ERR_UNSORTED ? "the input is not sorted" : "failed")));
+                                break;
+                            }
+                            r.iv.assign(iv, iv + niv);
+                            r.done = true;
+                            { std::lock_guard<std::mutex> g(mu); res[i] = std::move(r); }
+                            cv.notify_all();
+                        }
+                    } catch (...) { fail_rest(0, CL_ERR_NOMEM, "out of memory or internal error"); }
+                    if (!leave) {
+                        if (df) dut_fasta_close(df);
+                        if (db) dut_bam_close(db);
+                        if (dctx) cl_destroy(dctx);
+                    }
+                }));
+            }
+            // the BED, in tid order, as each contig's result arrives
+            for (size_t i = 0; i < tids.size(); ++i) {
+                Result r;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return res[i].done; });
+                    r = std::move(res[i]);
+                }
+                if (rc != CL_OK) continue;                       // (after the first error the rest is only waited for)
+                if (r.rc != CL_OK) { rc = r.rc; set_err(err, err_len, r.msg); stop.store(true); continue; }
+                const char *nm = dut_bam_ref_name(bam, tids[i]);
+                double tb = io_now();
+                int frc = dut_profiler_feed_contig(prof, nm, r.iv.data(), r.iv.size(), r.counts);
+                if (frc == CL_OK && dut_profiler_finish_plot(prof, nm, dut_bam_ref_len(bam, tids[i])) < 0) frc = CL_ERR_INVALID;
+                if (frc != CL_OK) { rc = frc; set_err(err, err_len, std::string("cannot write ") + bed_path); stop.store(true); continue; }
+                io_stage_time("BED lines", tb);
+                stats.push_back(r.st); names.push_back(nm); counts.push_back(std::vector<uint64_t>(r.counts, r.counts + 6));
+            }
+            workers.clear();                                     // joins
+        }
+        io_stage_time("contigs over the devices", tm);
+        if (rc != CL_OK) goto out;
+    } else {
         // the HIP runtime and the engine context come up on their own thread while the first contig is decoded
         dut::Thread init = dut::spawn_or_run([&]() { rc = cl_create(opt, device_id, nullptr, &ctx); });
         // Contigs are processed in ascending tid order (api/coverage.rs:229-234).  With an index and more
@@ -1110,19 +1232,20 @@ out:
     io_stage_time("(since the last decode) + summary", tm);
     dut_bam_stats_free(bstats);
     if (prof) dut_profiler_free(prof);
+    if (leave) {
+        // the caller is about to leave the process (DUT_FILES_LEAVE_TO_EXIT: the command line tool): every result is on
+        // disk; the device context, the readers and their decode buffers are left to the exit -- giving them back one by
+        // one costs a few hundred milliseconds of page-table and driver work that the exit does once, in one sweep
+        if (bam && bam->z.fp) { bam->st.drop_ahead(); fclose(bam->z.fp); bam->z.fp = nullptr; }
+        io_stage_time("left to the exit", tm);
+        return rc;
+    }
     {
-        // giving the device memory back and unmapping the decode buffers take a few hundred ms at chr21 size: side by side
+        // giving the device memory back and unmapping the decode buffers take a few hundred ms at chr21 size: side by
+        // side, and both joined -- a library call leaves no thread behind
         dut::Thread td = dut::spawn_or_run([&]() { if (ctx) cl_destroy(ctx); });
         dut_fasta_close(fa);
-        // The reader's descriptor is closed here; its decode buffers (gigabytes at chr21 size: 0.15 s of munmap) are
-        // given back on a thread of their own that nobody waits for -- every result is on disk by now.
-        if (bam) {
-            bam->st.drop_ahead();
-            if (bam->z.fp) { fclose(bam->z.fp); bam->z.fp = nullptr; }
-            dut_bam *gone = bam;
-            bam = nullptr;
-            try { std::thread([gone]() { delete gone; }).detach(); } catch (const std::system_error &) { delete gone; }
-        }
+        if (bam) dut_bam_close(bam);
         io_stage_time("readers closed", tm);
         if (td.joinable()) td.join();
     }
@@ -1135,7 +1258,17 @@ extern "C" int dut_coverage_files(const char *bam_path, const char *fasta_path, 
                                   const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len)
 {
     // no exception leaves the library through the C ABI
-    try { return dut_coverage_files_impl(bam_path, fasta_path, bed_path, summary_json, summary_html, opt, contigs, n_contigs, device_id, err, err_len); }
+    try { return dut_coverage_files_impl(bam_path, fasta_path, bed_path, summary_json, summary_html, opt, contigs, n_contigs, &device_id, 1, 0u, err, err_len); }
+    catch (const std::bad_alloc &) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_NOMEM; }
+    catch (...) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_INVALID; }
+}
+
+extern "C" int dut_coverage_files_multi(const char *bam_path, const char *fasta_path, const char *bed_path,
+                                        const char *summary_json, const char *summary_html, const cl_options *opt,
+                                        const char *const *contigs, size_t n_contigs, const int *devices, size_t n_devices,
+                                        unsigned flags, char *err, size_t err_len)
+{
+    try { return dut_coverage_files_impl(bam_path, fasta_path, bed_path, summary_json, summary_html, opt, contigs, n_contigs, devices, n_devices, flags, err, err_len); }
     catch (const std::bad_alloc &) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_NOMEM; }
     catch (...) { set_err(err, err_len, "out of memory or internal error"); return CL_ERR_INVALID; }
 }

@@ -845,7 +845,9 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
     if (n_win == 0) return CL_OK;
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
-    const int nt = std::max(1, std::min<int>(PinRing::kCopyThreads, dut::worker_threads()));
+    // (as many walkers as the staging ring has buffer pairs -- DUT_COPY_THREADS, 8 by default --: pinning 16 MB more per
+    // further walker costs more than the walker saves: 73 ms with 16 walkers against 23 ms with 8 at chr21 30x)
+    const int nt = std::max(1, std::min<int>(std::max(1, c->ring->slots), dut::worker_threads()));
     // tasks: several per thread so that uneven depth evens out, not so short that the range-start walks show
     const size_t per = std::max<size_t>(16, (size_t)n_win / (8 * (size_t)nt) + 1);
     const size_t ntasks = ((size_t)n_win + per - 1) / per;
@@ -1004,7 +1006,9 @@ cl_status stream_rows(cl_ctx *c, std::vector<WinMeta> &win)
     if (n_win == 0) return CL_OK;
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
-    const int nt = std::max(1, std::min<int>(PinRing::kCopyThreads, dut::worker_threads()));
+    // (as many walkers as the staging ring has buffer pairs -- DUT_COPY_THREADS, 8 by default --: pinning 16 MB more per
+    // further walker costs more than the walker saves: 73 ms with 16 walkers against 23 ms with 8 at chr21 30x)
+    const int nt = std::max(1, std::min<int>(std::max(1, c->ring->slots), dut::worker_threads()));
     const size_t per = std::max<size_t>(16, (size_t)n_win / (8 * (size_t)nt) + 1);
     const size_t ntasks = ((size_t)n_win + per - 1) / per;
     const size_t capG = row_chunk_groups();

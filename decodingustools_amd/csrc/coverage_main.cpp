@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
 #include <unistd.h>
 #include <vector>
@@ -19,7 +20,7 @@ static void usage()
             "Usage: dut-coverage [coverage] <BAM_FILE> -r <REFERENCE_FILE> [-o callable_regions.bed] [-s summary.html]\n"
             "       [-L <CONTIG>]... [--min-depth 4] [--max-depth 500] [--min-mapping-quality 10]\n"
             "       [--min-base-quality 20] [--min-depth-for-low-mapq 10] [--max-low-mapq 1]\n"
-            "       [--max-low-mapq-fraction 0.1] [--device 0]\n");
+            "       [--max-low-mapq-fraction 0.1] [--device 0 | --devices 0,1,...]\n");
 }
 
 // find-y-branch / find-mt-branch (src/cli.rs:62-105, src/commands/find_branch.rs).  The reference
@@ -77,7 +78,7 @@ int main(int argc, char **argv)
     cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};      // src/cli.rs:34-60
     std::string bam, ref, out = "callable_regions.bed", summary = "summary.html";
     std::vector<const char *> contigs;
-    int device = 0;
+    std::vector<int> devices;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         std::string val;
@@ -101,18 +102,34 @@ int main(int argc, char **argv)
         else if (a == "--min-depth-for-low-mapq") opt.min_depth_for_low_mapq = (uint32_t)strtoul(next(), nullptr, 10);
         else if (a == "--max-low-mapq") opt.max_low_mapq = (uint8_t)strtoul(next(), nullptr, 10);
         else if (a == "--max-low-mapq-fraction") opt.max_low_mapq_fraction = strtod(next(), nullptr);
-        else if (a == "--device") device = atoi(next());
+        else if (a == "--device") devices.assign(1, atoi(next()));
+        else if (a == "--devices") {
+            // the contigs are dealt to these devices (HIP ordinals, comma separated; an ordinal may repeat)
+            devices.clear();
+            const std::string list = next();
+            for (size_t b = 0; b <= list.size();) {
+                const size_t e = std::min(list.find(',', b), list.size());
+                if (e > b) devices.push_back(atoi(list.substr(b, e - b).c_str()));
+                b = e + 1;
+            }
+            if (devices.empty()) { fprintf(stderr, "error: invalid value '%s' for '--devices'\n", list.c_str()); return 2; }
+        }
         else if (a == "-h" || a == "--help") { usage(); return 0; }
         else if (!a.empty() && a[0] != '-' && bam.empty()) bam = a;
         else { fprintf(stderr, "error: unexpected argument '%s'\n", argv[i]); usage(); return 2; }
     }
     if (bam.empty() || ref.empty()) { usage(); return 2; }
+    if (devices.empty()) devices.push_back(0);
     char err[1024] = {0};
-    const int rc = dut_coverage_files(bam.c_str(), ref.c_str(), out.c_str(), "summary.json", summary.c_str(), &opt,
-                                      contigs.empty() ? nullptr : contigs.data(), contigs.size(), device, err, sizeof(err));
+    // this process ends with the analysis: what the library holds (device contexts, readers, decode buffers) is left to
+    // the exit (DUT_CLI_TEARDOWN=1: given back piece by piece first, as a library caller's process would)
+    const char *td = getenv("DUT_CLI_TEARDOWN");
+    const unsigned flags = (td && *td == '1') ? 0u : DUT_FILES_LEAVE_TO_EXIT;
+    const int rc = dut_coverage_files_multi(bam.c_str(), ref.c_str(), out.c_str(), "summary.json", summary.c_str(), &opt,
+                                            contigs.empty() ? nullptr : contigs.data(), contigs.size(), devices.data(), devices.size(),
+                                            flags, err, sizeof(err));
     if (rc != CL_OK) { fprintf(stderr, "Error: Analysis error: %s\n", err); return 1; }
-    // every output file is written and closed and the engine is destroyed: leave without the HIP runtime's
-    // exit handlers (tens of milliseconds of teardown that nothing depends on)
+    // every output file is written and closed: leave without the HIP runtime's exit handlers
     fflush(nullptr);
     _exit(0);
 }

@@ -76,6 +76,23 @@ int dut_coverage_files(const char *bam_path, const char *fasta_path, const char 
                        const char *summary_json, const char *summary_html, const cl_options *opt,
                        const char *const *contigs, size_t n_contigs, int device_id, char *err, size_t err_len);
 
+
+/* The same over SEVERAL devices of one node, below any Python or torch.distributed layer -- what a Rust caller of
+ * process_contigs_api (api/coverage.rs:221-252) can bind: one host thread, one BAM / FASTA reader pair and one engine
+ * context per entry of `devices` (HIP ordinals; the same ordinal may appear more than once: several contexts on one
+ * device); the selected contigs are dealt to them by longest-processing-time-first on the index's mapped-read counts
+ * (contig lengths when the index does not record them); every contig's runs, state counts and ContigProfiler numbers
+ * come back through host memory and the BED is written by the calling thread in tid order with the duplicated last line
+ * per contig (callable_profiler.rs:64-66), so the files are byte for byte those of the one-device call.  One process,
+ * no collective.  The first error in tid order aborts the analysis, as the serial loop's `?` does.
+ * flags: DUT_FILES_LEAVE_TO_EXIT -- the caller leaves the process right after the call (the command line tool): the
+ * contexts, readers and decode buffers are not given back one by one.  n_devices == 1, flags == 0: dut_coverage_files. */
+#define DUT_FILES_LEAVE_TO_EXIT 1u
+int dut_coverage_files_multi(const char *bam_path, const char *fasta_path, const char *bed_path,
+                             const char *summary_json, const char *summary_html, const cl_options *opt,
+                             const char *const *contigs, size_t n_contigs, const int *devices, size_t n_devices,
+                             unsigned flags, char *err, size_t err_len);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 // The device engine is not part of this binary: the few cl_* symbols the host sources reference are
 // defined below as failing stubs for the link only (nothing here reaches them).
 #include "../../include/dut_coverage.h"
+#include "../../include/dut_bam.h"
 #include "../../include/dut_haplogroup.h"
 #include "../../include/dut_report.h"
 #include "../../decodingustools_amd/csrc/host_parallel.h"
@@ -14,14 +15,32 @@
 #include <string>
 #include <vector>
 
+// A stand-in for the device engine, for this binary only: a context that remembers the contig it was given and hands back
+// two runs that depend on it (so that a result delivered to the wrong contig, or twice, shows in the BED).  It lets the
+// host's orchestration -- dut_coverage_files_multi: one thread, reader pair and context per "device", results handed to
+// the BED writer in tid order -- run under ThreadSanitizer without a GPU.  Nothing here computes a pileup.
+struct cl_ctx { int device; int32_t tid; uint32_t len; uint64_t n_reads; cl_interval iv[2]; };
 extern "C" {
-cl_status cl_create(const cl_options *, int, void *, cl_ctx **) { return CL_ERR_DEVICE; }
-void cl_destroy(cl_ctx *) {}
+cl_status cl_create(const cl_options *, int device, void *, cl_ctx **out)
+{
+    if (device < 0 || device > 7) return CL_ERR_DEVICE;
+    *out = new cl_ctx(); (*out)->device = device; return CL_OK;
+}
+void cl_destroy(cl_ctx *c) { delete c; }
 const char *cl_last_error(const cl_ctx *) { return "no device in the sanitizer build"; }
-cl_status cl_contig_begin(cl_ctx *, int32_t, uint32_t, const uint8_t *, uint64_t) { return CL_ERR_DEVICE; }
-cl_status cl_push_reads(cl_ctx *, const cl_read_tile *) { return CL_ERR_DEVICE; }
-cl_status cl_contig_prefetch_qual(cl_ctx *, const uint8_t *, uint64_t) { return CL_ERR_DEVICE; }
-cl_status cl_contig_finish(cl_ctx *, cl_contig_summary *, const cl_interval **, size_t *) { return CL_ERR_DEVICE; }
+cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t len, const uint8_t *, uint64_t) { c->tid = tid; c->len = len; c->n_reads = 0; return CL_OK; }
+cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t) { c->n_reads += t->n_reads; return CL_OK; }
+cl_status cl_contig_prefetch_qual(cl_ctx *, const uint8_t *, uint64_t) { return CL_OK; }
+cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *s, const cl_interval **iv, size_t *n)
+{
+    memset(s, 0, sizeof(*s));
+    const uint32_t cut = c->len > 1 ? 1 + (uint32_t)((c->n_reads * 7 + (uint32_t)c->tid) % (c->len - 1)) : c->len;
+    c->iv[0] = {0, cut, CL_NO_COVERAGE}; c->iv[1] = {cut, c->len, CL_CALLABLE};
+    s->state_counts[CL_NO_COVERAGE] = cut; s->state_counts[CL_CALLABLE] = c->len - cut; s->extent = c->len;
+    s->n_intervals = cut < c->len ? 2 : 1;
+    *iv = c->iv; *n = (size_t)s->n_intervals;
+    return c->len ? CL_OK : CL_ERR_INVALID;
+}
 cl_status cl_contig_abort(cl_ctx *) { return CL_OK; }
 cl_status cl_site_pileup(cl_ctx *, uint8_t, uint32_t, uint64_t, const cl_site_tile *, const uint32_t *, size_t, uint32_t *) { return CL_ERR_DEVICE; }
 }
@@ -155,6 +174,27 @@ int main(int argc, char **argv)
             dut_profiler_free(pr);
         }
         printf("html rc %d\n", dut_write_html_report(st, names, counts, 2, &meta, 10000, (dir + "/san.html").c_str()));
+    }
+    // the orchestration of the several-device call (threads, reader pairs, results handed to the BED writer in tid
+    // order) over the stand-in engine above: the BED of 1, 2 and 3 "devices" must be the same text
+    if (argc > 3) {
+        const std::string dir = std::string(argv[3]).substr(0, std::string(argv[3]).find_last_of('/'));
+        unsigned long long first = 0;
+        for (int nd = 1; nd <= 3; ++nd) {
+            const int devs[3] = {0, 1, 1};
+            const std::string bed = dir + "/multi" + std::to_string(nd) + ".bed";
+            char e2[512] = {0};
+            const int rc = dut_coverage_files_multi(argv[1], argv[3], bed.c_str(), nullptr, nullptr, &opt, nullptr, 0, devs, (size_t)nd, 0u, e2, sizeof(e2));
+            std::string text;
+            if (FILE *f = fopen(bed.c_str(), "rb")) { char buf[4096]; size_t g; while ((g = fread(buf, 1, sizeof(buf), f)) > 0) text.append(buf, g); fclose(f); }
+            const unsigned long long h = checksum(text.data(), text.size());
+            if (nd == 1) first = h;
+            printf("multi %d device(s): rc %d%s%s, bed %zu bytes %s\n", nd, rc, rc ? " " : "", rc ? e2 : "", text.size(), h == first ? "same" : "DIFFERENT");
+            if (rc == CL_OK && h != first) return 4;
+        }
+        const int bad[2] = {0, 99};
+        char e3[512] = {0};
+        printf("multi, a device that does not exist: rc %d\n", dut_coverage_files_multi(argv[1], argv[3], (dir + "/multi_bad.bed").c_str(), nullptr, nullptr, &opt, nullptr, 0, bad, 2, 0u, e3, sizeof(e3)));
     }
     return 0;
 }

@@ -1351,3 +1351,61 @@ def test_counter_planes_follow_the_deepest_window(depth, planes, tmp_path):
         lay = eng.contig_layout()
     assert lay["form"] == 3 and lay["counter_planes"] == planes, lay
     assert lay["n_qual"] == rec.qual.shape[0] and lay["row_groups"] >= lay["max_groups"] > 0
+
+
+def test_coverage_files_over_several_contexts_of_one_device(tmp_path):
+    """dut_coverage_files_multi (the multi-device path BELOW Python: one host thread, one reader pair and one engine
+    context per entry of `devices`, contigs dealt by LPT on the index's mapped-read counts, BED written by the caller in
+    tid order): with devices = [0, 0] and [0, 0, 0] -- several contexts on this box's one GPU -- the BED, the summary JSON
+    and the figures are byte for byte those of the one-device call and of the oracle; an error in a later contig comes
+    back as the serial loop's would; the command line tool takes --devices."""
+    import subprocess
+    from bamio import write_bam, write_fasta
+    from decodingustools_amd import EngineError, build as _b
+    from decodingustools_amd.bam import coverage_files
+    names = ["chr1", "chr2", "chr3", "chrX", "chrY", "chrM"]
+    lens = [150_000, 60_000, 90_000, 30_000, 45_000, 16_569]
+    recs = {0: synth.short_read_contig(lens[0], 30, 900), 1: synth.adversarial_contig(lens[1], 3000, 901, deep=True),
+            2: synth.long_read_contig(lens[2], 20, 902), 4: synth.short_read_contig(lens[4], 12, 904), 5: synth.short_read_contig(lens[5], 20, 905)}
+    refs = [synth.make_reference(l, 950 + i, lowercase=(i == 5)) for i, l in enumerate(lens)]
+    bam = str(tmp_path / "m.bam"); fa = str(tmp_path / "m.fa")
+    write_bam(bam, list(zip(names, lens)), recs, block_every=800)
+    write_fasta(fa, list(zip(names, refs)))
+    contigs = [(n, t, lens[t], refs[t], recs.get(t, ContigRecords.empty())) for t, n in enumerate(names)]
+    _, o_bed = oracle_run(contigs, make_options({}), str(tmp_path / "o.bed"))
+    one = tmp_path / "one"; one.mkdir()
+    coverage_files(bam, fa, str(one / "g.bed"), str(one / "s.json"), CallableOptions(), output_summary=str(one / "r.html"))
+    assert open(one / "g.bed").read() == o_bed
+    import json as _json
+    for devs in ([0, 0], [0, 0, 0], [0]):
+        d = tmp_path / ("multi%d" % len(devs)); d.mkdir()
+        coverage_files(bam, fa, str(d / "g.bed"), str(d / "s.json"), CallableOptions(), output_summary=str(d / "r.html"), devices=devs)
+        assert open(d / "g.bed").read() == o_bed, devs
+        a, b = _json.load(open(one / "s.json")), _json.load(open(d / "s.json"))
+        a["files"] = b["files"] = None                              # (the paths differ)
+        assert a == b, devs
+        for n in names:
+            f1, f2 = one / f"{n}_coverage.svg", d / f"{n}_coverage.svg"
+            assert f1.exists() == f2.exists() and (not f1.exists() or f1.read_bytes() == f2.read_bytes()), (devs, n)
+    # -L subset, through the tool
+    out = str(tmp_path / "cli.bed")
+    r = subprocess.run([_b.CLI, "coverage", bam, "-r", fa, "-o", out, "--devices", "0,0", "-L", "chr2", "-L", "chrY", "-L", "chrM"],
+                       cwd=str(tmp_path), capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    _, o_bed2 = oracle_run([contigs[1], contigs[4], contigs[5]], make_options({}), str(tmp_path / "o2.bed"))
+    assert open(out).read() == o_bed2
+    # the same tool giving everything back before it leaves (what a library caller's process does)
+    r = subprocess.run([_b.CLI, "coverage", bam, "-r", fa, "-o", out, "--devices", "0,0"], cwd=str(tmp_path), capture_output=True, text=True,
+                       env=dict(os.environ, DUT_CLI_TEARDOWN="1"))
+    assert r.returncode == 0 and open(out).read() == o_bed, r.stderr
+    # a file cut off inside a later contig: the first error in tid order is reported, nothing hangs
+    import shutil
+    bam_cut = str(tmp_path / "cut.bam")
+    data = open(bam, "rb").read()
+    open(bam_cut, "wb").write(data[:int(len(data) * 0.7)])
+    shutil.copy(bam + ".bai", bam_cut + ".bai")
+    with pytest.raises(EngineError) as ei:
+        coverage_files(bam_cut, fa, str(tmp_path / "g2.bed"), None, CallableOptions(), devices=[0, 0])
+    assert "Error processing contig" in str(ei.value) or "BAM" in str(ei.value)
+    with pytest.raises(EngineError):
+        coverage_files(bam, fa, str(tmp_path / "g3.bed"), None, CallableOptions(), devices=[0, 99])      # no such device

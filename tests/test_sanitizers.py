@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from bamio import write_bam
+from bamio import write_bam, write_fasta
 from decodingustools_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -40,31 +40,36 @@ def _inputs(tmp_path):
     write_bam(aligned, refs, recs, block_every=60)                       # blocks cut at record boundaries
     write_bam(straddle, refs, recs, long_cigar_tag=True)                 # records straddle blocks, CG tags
     write_bam(noidx, refs, recs, write_index=False, block_every=13)
+    fasta = str(tmp_path / "ref.fa")
+    write_fasta(fasta, [(n, synth.make_reference(l, 40 + i)) for i, (n, l) in enumerate(refs)])
     rng = random.Random(4)
     tree = str(tmp_path / "tree.json")
     open(tree, "w").write(TH.ftdna_tree(rng, 300, [rng.randrange(100, 29_000) for _ in range(500)]))
     bad = str(tmp_path / "bad.bam")
     d = bytearray(open(aligned, "rb").read()); d[len(d) // 2] ^= 0x10
     open(bad, "wb").write(bytes(d))
-    return [aligned, straddle, noidx, bad], tree
+    return [aligned, straddle, noidx, bad], tree, fasta
 
 
 @pytest.mark.parametrize("tag,flags,envvar", [("asan", ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined"], "ASAN_OPTIONS"),
                                               ("tsan", ["-fsanitize=thread"], "TSAN_OPTIONS")])
 def test_host_code_under_sanitizers(tmp_path, tag, flags, envvar):
     exe = _build(tmp_path, flags, tag)
-    bams, tree = _inputs(tmp_path)
+    bams, tree, fasta = _inputs(tmp_path)
     outs = {}
     for bam in bams:
         for threads in ("1", "5"):
             env = dict(os.environ, DUT_THREADS=threads)
             env[envvar] = "halt_on_error=1:detect_leaks=0" if tag == "asan" else "halt_on_error=1"
-            r = subprocess.run([exe, bam, tree], env=env, capture_output=True, text=True, timeout=600)
+            r = subprocess.run([exe, bam, tree, fasta], env=env, capture_output=True, text=True, timeout=600)
             assert r.returncode == 0, (bam, threads, r.stderr[-3000:])
             assert "runtime error" not in r.stderr and "Sanitizer" not in r.stderr, r.stderr[-3000:]
             outs.setdefault(bam, set()).add(r.stdout)
     for bam, o in outs.items():
         assert len(o) == 1, bam                                         # the thread count never changes the result
+    # the several-"device" call over the stand-in engine (one thread, reader pair and context per device): same BED text
+    good = next(iter(outs[bams[0]]))
+    assert good.count("bytes same") == 3 and "DIFFERENT" not in good and "a device that does not exist: rc -2" in good, good[-800:]
     # the same records whatever the block layout / index
     body = lambda s: [ln.split(" admit")[0] for ln in s.splitlines() if ln.startswith("tid")]
     assert body(next(iter(outs[bams[0]]))) == body(next(iter(outs[bams[2]]))) == body(next(iter(outs[bams[1]])))

@@ -27,12 +27,22 @@ del rec
 quiet = os.environ.get("E2E_QUIET") == "1"
 for threads in os.environ.get("E2E_THREADS", "16,1").split(","):
     for rep in range(int(os.environ.get("E2E_REPS", 2))):
-        for leave in os.environ.get("E2E_LEAVE", "0").split(","):     # DUT_CLI_LEAVE=1: the tool leaves the device context to the exit
-            env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads, DUT_CLI_LEAVE=leave)
+        for leave in os.environ.get("E2E_TEARDOWN", "0").split(","):     # DUT_CLI_TEARDOWN=1: the tool gives everything back before it leaves
+            env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads, DUT_CLI_TEARDOWN=leave)
+            def cpu_stat():
+                try:
+                    return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
+                except Exception:
+                    return {}
+            c0 = cpu_stat()
             t0 = time.time()
-            r = subprocess.run([os.environ.get("E2E_CLI", _b.CLI), "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")], cwd=out, env=env, capture_output=True, text=True)
+            r = subprocess.run([os.environ.get("E2E_CLI", _b.CLI), "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")] + os.environ.get("E2E_ARGS", "").split(),
+                               cwd=out, env=env, capture_output=True, text=True)
             dt = time.time() - t0
-            print(f"--- DUT_THREADS={threads} DUT_CLI_LEAVE={leave} run {rep}: {dt:.3f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)
+            c1 = cpu_stat()
+            if c0 and c1:
+                print("    cgroup cpu.stat over the run: " + ", ".join(f"{k} +{c1[k] - c0[k]}" for k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec") if k in c0), flush=True)
+            print(f"--- DUT_THREADS={threads} DUT_CLI_TEARDOWN={leave} run {rep}: {dt:.3f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)
             if not quiet or rep == 0:
                 print(r.stderr.strip(), flush=True)
 if os.path.exists(os.path.join(out, "o.bed")):

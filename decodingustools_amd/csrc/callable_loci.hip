@@ -657,6 +657,15 @@ inline uint64_t read_pass_sum(const uint8_t *q, unsigned long long ql, const uin
     return dut::qual_pass_sum(q, std::min<unsigned long long>(ql, y), thr, level) - minus;
 }
 
+// DUT_FAULT_INJECT=<what> (tests only; read at every upload): the named builder hands the bounds checks of the upload an
+// index that lies outside its array -- "rows" a window's group range, "runtab" a read's quality offset in the run table,
+// "rec" a record's quality offset -- so that a test can see the check refuse what would otherwise be a device fault.
+bool fault_injected(const char *what)
+{
+    const char *e = getenv("DUT_FAULT_INJECT");
+    return e && strcmp(e, what) == 0;
+}
+
 // bytes of read records per pinned buffer (DUT_REC_CHUNK: a test hook that puts the buffer seams inside the records of
 // one read with small inputs; a multiple of the record size; read once)
 uint64_t rec_chunk_bytes()
@@ -779,7 +788,12 @@ struct RunCur { uint32_t k, k1, x, y, qlen, flags; unsigned long long q0; };
 // One window: the cursors of `act` emit their pieces inside [W, W + kT) to out[0, cap) and move on; finished reads
 // leave the list.  Returns the number of pieces, or SIZE_MAX when `cap` did not suffice (the list is then spoilt: the
 // caller restores its copy).
-size_t sweep_window(std::vector<RunCur> &act, const uint32_t *cig, uint32_t W, unsigned long long qwin, uint2 *out, size_t cap)
+// `qend` = bytes of the padded quality allocation: every piece is checked against it as it is emitted -- the kernel loads
+// 16 bytes at allocation offset qwin + (uint32)(x + 16 u) for the unit(s) of the piece, and the lanes behind a window's
+// last entry repeat that entry's loads -- and *out_of_range is set when a load would leave the allocation (the upload then
+// fails with CL_ERR_RANGE instead of launching a kernel that faults).
+size_t sweep_window(std::vector<RunCur> &act, const uint32_t *cig, uint32_t W, unsigned long long qwin, uint2 *out, size_t cap,
+                    unsigned long long qend, std::atomic<bool> *out_of_range)
 {
     const uint32_t Wend = W + kT;
     size_t n = 0, keep = 0;
@@ -805,6 +819,9 @@ size_t sweep_window(std::vector<RunCur> &act, const uint32_t *cig, uint32_t W, u
                     do {
                         const uint32_t pe = std::min(tr, ((sr >> 4) + 2u) << 4);
                         out[n++] = make_uint2(ex, sr | ((pe - 1u) << 11) | cu.flags);
+                        // the first and the last unit the kernel loads for this piece, as it computes their addresses
+                        if (qwin + (uint32_t)(ex + ((sr >> 4) << 4)) + 16ull > qend || qwin + (uint32_t)(ex + (((pe - 1u) >> 4) << 4)) + 16ull > qend)
+                            out_of_range->store(true, std::memory_order_relaxed);
                         sr = pe;
                     } while (sr < tr);
                 }
@@ -852,6 +869,9 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
     const size_t per = std::max<size_t>(16, (size_t)n_win / (8 * (size_t)nt) + 1);
     const size_t ntasks = ((size_t)n_win + per - 1) / per;
     const size_t capE = run_chunk_entries();
+    const unsigned long long qend = c->n_qual + 2ull * kQualPad;
+    std::atomic<bool> oor{false};
+    const bool inject = fault_injected("runtab");                // test hook: one read's quality offset is moved out of range
     // the device array: an estimate first (a piece per ~12 aligned bases); a contig that needs more tells how much
     uint64_t want = c->n_qual / 12 + (uint64_t)n_win * 8 + 65536;
     for (int attempt = 0; attempt < 2; ++attempt) {
@@ -897,6 +917,7 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
                     const unsigned long long ql = qoff[r + 1] - qoff[r];
                     cu.qlen = ql > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ql;
                     cu.q0 = qoff[r]; cu.flags = ((r & 1u) << 29) | 0x80000000u;
+                    if (inject && r == c->n_reads / 2u) cu.q0 += 0x7FFFFFF0ull;
                     if (cu.k1 - cu.k > kLongOps && cu.x < W) {               // the last checkpoint at or before W
                         const uint32_t jlo = (cu.k + 63u) >> 6, jhi = (cu.k1 - 1u) >> 6;
                         if (jlo <= jhi && ckx[jlo] <= W) {
@@ -926,11 +947,11 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
                                 for (uint32_t r = win[w - 1].hi; r < m.hi; ++r) enter(r, W);   // the reads that start in this window
                             }
                             save = act;
-                            size_t cnt = sweep_window(act, cig, W, m.q0, cur_buf() + used, capE - used);
+                            size_t cnt = sweep_window(act, cig, W, m.q0, cur_buf() + used, capE - used, qend, &oor);
                             if (cnt == SIZE_MAX) {                           // the buffer is full: it leaves, the window starts over
                                 flush();
                                 act = save;
-                                cnt = sweep_window(act, cig, W, m.q0, cur_buf(), capE);
+                                cnt = sweep_window(act, cig, W, m.q0, cur_buf(), capE, qend, &oor);
                             }
                             if (cnt == SIZE_MAX) {
                                 // a window that no buffer holds (thousandfold depth): through a block of its own
@@ -938,7 +959,7 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
                                 for (;;) {
                                     big.clear(); big.resize(bc);
                                     act = save;
-                                    cnt = sweep_window(act, cig, W, m.q0, big.data(), bc);
+                                    cnt = sweep_window(act, cig, W, m.q0, big.data(), bc, qend, &oor);
                                     if (cnt != SIZE_MAX) break;
                                     bc *= 4;
                                 }
@@ -962,6 +983,7 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
         s = ring_finish(c);
         if (s != CL_OK) return s;
         const uint64_t total = dev_next.load();
+        if (oor.load()) return fail(c, CL_ERR_RANGE, "a match piece of the run table addresses quality bytes outside the resident array");
         if (total >= 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 match pieces in one contig");
         if (total <= dev_cap) { c->n_runtab = total; return CL_OK; }
         want = total;                                            // exact now: once more
@@ -1173,6 +1195,7 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
         if (c->form == 3) {
             std::atomic<bool> bad{false};
             const uint64_t ngr = c->n_row_groups;
+            if (fault_injected("rows") && c->n_win) win[c->n_win / 2].rlo += 0x7FFFFFF0u;
             dut::parallel_for(c->n_win, 8192, [&](size_t w) { if ((uint64_t)win[w].rlo + win[w].rn > ngr) bad.store(true); });
             if (bad.load()) return fail(c, CL_ERR_RANGE, "a window's pass-bit rows lie outside the resident row array");
         }
@@ -1803,8 +1826,15 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         const uint32_t *ro = c->h_rec_of.data();
         const uint32_t min_mapq = c->opt.min_mapping_quality;
         const bool heads_only = c->bits;
+        // byte form: k_pileup loads 16-byte units around a record's run [qoff, qoff + len): within 15 bytes of its ends,
+        // which the padding of the quality array covers as long as the run itself lies inside [0, n_qual] -- checked for
+        // every record as it is built (CL_ERR_RANGE instead of a launch that would fault)
+        std::atomic<bool> rec_oor{false};
+        std::atomic<bool> *roor = &rec_oor;
+        const unsigned long long nq_all = c->n_qual;
+        const size_t inject_read = (!heads_only && fault_injected("rec")) ? n / 2 : (size_t)-1;
         rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), ((uint64_t)n_rec + 1) * sizeof(ReadRec),
-                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq, heads_only](uint64_t off, uint64_t len, uint8_t *out) {
+                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq, heads_only, roor, nq_all, inject_read](uint64_t off, uint64_t len, uint8_t *out) {
             ReadRec *o = reinterpret_cast<ReadRec *>(out);
             const uint64_t j0 = off / sizeof(ReadRec), j1 = (off + len) / sizeof(ReadRec);
             if (j1 > n_rec) memset(static_cast<void *>(o + (std::max<uint64_t>(n_rec, j0) - j0)), 0, (j1 - std::max<uint64_t>(n_rec, j0)) * sizeof(ReadRec));   // the padding record
@@ -1821,12 +1851,15 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
                     o[jb - j0] = r;
                     continue;
                 }
-                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], hq[i], hq[i + 1] - hq[i],
+                const unsigned long long q0i = hq[i] + (i == inject_read ? 0x7FFFFFF0ull : 0ull);
+                if (q0i + (hq[i + 1] - hq[i]) > nq_all) roor->store(true, std::memory_order_relaxed);   // (runs lie inside the read's bytes)
+                gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], q0i, hq[i + 1] - hq[i],
                               [&](uint32_t k, const ReadRec &r) { const uint64_t j = jb + k; if (j >= j0 && j < j1) o[j - j0] = r; });
             }
         }, rec_chunk_bytes());
         if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
         if (rs != CL_OK) return rs;
+        if (rec_oor.load()) return fail(c, CL_ERR_RANGE, "a read record addresses quality bytes outside the resident array");
         tmr.lap("upload: records built + sent");
     }
     std::vector<uint32_t> wide_rec;                      // record forms: the wide reads' records, read by read

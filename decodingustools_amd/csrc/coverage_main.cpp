@@ -9,8 +9,12 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <algorithm>
 #include <string>
+#include <cerrno>
+#include <sys/types.h>
+#include <sys/wait.h>
 #include <unistd.h>
 #include <vector>
 
@@ -71,8 +75,20 @@ static int find_branch_main(int argc, char **argv, int tree_type)
     _exit(0);                              // outputs are closed; skip the HIP runtime's exit handlers (see main)
 }
 
+// DUT_TIMING=1: the wall clock (CLOCK_REALTIME, seconds) at the start of main and right before the process leaves, so
+// that a harness that started the tool can tell what the loader took before main and what the exit took after it
+static void stamp(const char *what)
+{
+    const char *e = getenv("DUT_TIMING");
+    if (!e || *e != '1') return;
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    fprintf(stderr, "[dut-timing] wall clock at %s: %.6f\n", what, (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec);
+}
+
 int main(int argc, char **argv)
 {
+    stamp("main");
     if (argc > 1 && !strcmp(argv[1], "find-y-branch")) return find_branch_main(argc, argv, DUT_TREE_YDNA);
     if (argc > 1 && !strcmp(argv[1], "find-mt-branch")) return find_branch_main(argc, argv, DUT_TREE_MTDNA);
     cl_options opt = {4, 500, 10, 20, 10, 1, 0.1};      // src/cli.rs:34-60
@@ -120,6 +136,42 @@ int main(int argc, char **argv)
     }
     if (bam.empty() || ref.empty()) { usage(); return 2; }
     if (devices.empty()) devices.push_back(0);
+    // The analysis runs in a child process and this one returns as soon as the child reports that every output file is
+    // written and closed: what is left then -- the kernel taking a few gigabytes of decode buffers, the pinned staging
+    // memory and the device context apart, 0.1 to 0.5 s depending on the box -- happens in the background, after the
+    // command has returned (the child closes its output streams first, so a caller that reads them to their end does
+    // not wait for it either).  Forked before anything touches the GPU.  DUT_CLI_FOREGROUND=1: one process, the caller
+    // waits for the teardown too.
+    int status_fd = -1;
+    {
+        const char *fg = getenv("DUT_CLI_FOREGROUND");
+        int fds[2];
+        if (!(fg && *fg == '1') && pipe(fds) == 0) {
+            const pid_t pid = fork();
+            if (pid > 0) {
+                close(fds[1]);
+                unsigned char code = 0;
+                ssize_t g;
+                do { g = read(fds[0], &code, 1); } while (g < 0 && errno == EINTR);
+                if (g == 1) { stamp("return (the child goes on releasing)"); _exit(code); }
+                int st = 0;                                   // the child ended without a word: its own status tells
+                while (waitpid(pid, &st, 0) < 0 && errno == EINTR) {}
+                _exit(WIFEXITED(st) ? WEXITSTATUS(st) : 1);
+            }
+            if (pid == 0) { close(fds[0]); status_fd = fds[1]; }
+            else { close(fds[0]); close(fds[1]); }            // no fork: in the foreground
+        }
+    }
+    auto leave = [&](int code) {
+        fflush(nullptr);
+        if (status_fd >= 0) {
+            const unsigned char b = (unsigned char)code;
+            if (write(status_fd, &b, 1) != 1) {}
+            close(status_fd);
+            close(1); close(2);                               // readers of the tool's output see its end now
+        }
+        _exit(code);
+    };
     char err[1024] = {0};
     // this process ends with the analysis: what the library holds (device contexts, readers, decode buffers) is left to
     // the exit (DUT_CLI_TEARDOWN=1: given back piece by piece first, as a library caller's process would)
@@ -128,8 +180,9 @@ int main(int argc, char **argv)
     const int rc = dut_coverage_files_multi(bam.c_str(), ref.c_str(), out.c_str(), "summary.json", summary.c_str(), &opt,
                                             contigs.empty() ? nullptr : contigs.data(), contigs.size(), devices.data(), devices.size(),
                                             flags, err, sizeof(err));
-    if (rc != CL_OK) { fprintf(stderr, "Error: Analysis error: %s\n", err); return 1; }
+    if (rc != CL_OK) { fprintf(stderr, "Error: Analysis error: %s\n", err); leave(1); }
     // every output file is written and closed: leave without the HIP runtime's exit handlers
-    fflush(nullptr);
-    _exit(0);
+    stamp("exit");
+    leave(0);
+    return 0;
 }

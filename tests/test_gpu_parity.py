@@ -1409,3 +1409,35 @@ def test_coverage_files_over_several_contexts_of_one_device(tmp_path):
     assert "Error processing contig" in str(ei.value) or "BAM" in str(ei.value)
     with pytest.raises(EngineError):
         coverage_files(bam, fa, str(tmp_path / "g3.bed"), None, CallableOptions(), devices=[0, 99])      # no such device
+
+
+@pytest.mark.parametrize("what,form", [("rows", "bits"), ("rec", "bytes"), ("runtab", "bytes")])
+def test_an_index_outside_its_array_is_an_error_return_not_a_fault(what, form, monkeypatch):
+    """What the pileup kernels index is checked on the host at every upload, in the product build: a window's range of row
+    groups against the resident rows, every record's run and every run-table piece -- the units the kernel loads for it,
+    clamped lanes included -- against the padded quality array.  DUT_FAULT_INJECT makes the named builder produce one
+    index outside its array (the situation behind the memory access fault of fuzz seed 300026): the upload must refuse
+    with CL_ERR_RANGE, launch nothing, and the context must take the next contig as if nothing had happened."""
+    from decodingustools_amd import EngineError
+    if form == "bytes":
+        monkeypatch.setenv("DUT_QUAL_FORM", "bytes")
+    L = 120_000
+    rec = synth.long_read_contig(L, 20, 41) if what == "runtab" else synth.short_read_contig(L, 30, 41)
+    ref = synth.make_reference(L, 42)
+    opt = CallableOptions()
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(1, L, ref)
+        eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        want = eng.contig_finish()
+        assert eng.contig_layout()["form"] == {"rows": 3, "rec": 0, "runtab": 2}[what]
+        monkeypatch.setenv("DUT_FAULT_INJECT", what)
+        eng.contig_begin(1, L, ref)
+        eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        with pytest.raises(EngineError) as ei:
+            eng.contig_finish()
+        assert ei.value.status == -6 and "outside the resident" in str(ei.value)
+        monkeypatch.delenv("DUT_FAULT_INJECT")
+        eng.contig_begin(1, L, ref)
+        eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        got = eng.contig_finish()
+    assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)

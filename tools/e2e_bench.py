@@ -28,7 +28,9 @@ quiet = os.environ.get("E2E_QUIET") == "1"
 for threads in os.environ.get("E2E_THREADS", "16,1").split(","):
     for rep in range(int(os.environ.get("E2E_REPS", 2))):
         for leave in os.environ.get("E2E_TEARDOWN", "0").split(","):     # DUT_CLI_TEARDOWN=1: the tool gives everything back before it leaves
-            env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads, DUT_CLI_TEARDOWN=leave)
+            env = dict(os.environ, DUT_TIMING="1", DUT_THREADS=threads, DUT_CLI_TEARDOWN=leave.rstrip("f"))
+            if leave.endswith("f"):
+                env["DUT_CLI_FOREGROUND"] = "1"                            # "0f": one process, the caller waits for the exit
             def cpu_stat():
                 try:
                     return {k: int(v) for k, v in (ln.split() for ln in open("/sys/fs/cgroup/cpu.stat"))}
@@ -38,8 +40,14 @@ for threads in os.environ.get("E2E_THREADS", "16,1").split(","):
             t0 = time.time()
             r = subprocess.run([os.environ.get("E2E_CLI", _b.CLI), "coverage", bam, "-r", fa, "-o", os.path.join(out, "o.bed")] + os.environ.get("E2E_ARGS", "").split(),
                                cwd=out, env=env, capture_output=True, text=True)
-            dt = time.time() - t0
+            t1 = time.time()
+            dt = t1 - t0
             c1 = cpu_stat()
+            import re
+            st = dict(re.findall(r"wall clock at (\w+): ([0-9.]+)", r.stderr))
+            if "main" in st and "exit" in st:
+                print(f"    before main {float(st['main']) - t0:.3f} s, main {float(st['exit']) - float(st['main']):.3f} s, from the end of main to the caller {t1 - float(st['exit']):.3f} s"
+                      + (" (the child releases in the background)" if "return" in st else " (the caller waits for the process's teardown)"), flush=True)
             if c0 and c1:
                 print("    cgroup cpu.stat over the run: " + ", ".join(f"{k} +{c1[k] - c0[k]}" for k in ("usage_usec", "nr_periods", "nr_throttled", "throttled_usec") if k in c0), flush=True)
             print(f"--- DUT_THREADS={threads} DUT_CLI_TEARDOWN={leave} run {rep}: {dt:.3f} s wall, rc={r.returncode}, {L / dt / 1e6:.1f} Mbase/s end to end", flush=True)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Kernel-level timing of the resident chr21-shaped contig under different CL_ABLATE settings /
-library variants (tools only; not part of the product or of bench.py)."""
+"""Kernel-level timing of the resident chr21-shaped contig (depth / read-length sweeps: KB_LEN, KB_DEPTH, KB_READLEN;
+DUT_QUAL_FORM=bytes for the byte forms; a library variant through DUT_CALLABLE_LIB).  Tools only; not part of the
+product or of bench.py.  (The CL_ABLATE hooks of the byte forms are read once at cl_create and exist only in the tuning
+build: tools/rt_ablate.sh.)"""
 import os, sys, time, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -9,7 +11,7 @@ from decodingustools_amd import CallableOptions, CallableProfiler, ContigProfile
 
 L = int(os.environ.get("KB_LEN", 46_709_983))
 depth = float(os.environ.get("KB_DEPTH", 30))
-ablates = [int(x, 0) for x in os.environ.get("KB_ABLATES", "0").split(",")]
+ablates = [0]
 steps = int(os.environ.get("KB_STEPS", 10))
 seed = synth.seed_for(2, 20)
 rec = synth.short_read_contig(L, depth, seed, read_len=int(os.environ.get('KB_READLEN', 150)))
@@ -23,7 +25,6 @@ process_single_contig(eng, counter, st, opt, 20, rec, ref)
 counter.close()
 eng.set_profiling(True)
 for ab in ablates:
-    os.environ["CL_ABLATE"] = str(ab)
     for _ in range(3):
         eng.contig_run()
     eng.sync(); eng.reset_kernel_ms()

@@ -164,8 +164,9 @@ template <typename T> struct DevBuf {
 // one buffer (memcpy from the caller's pageable memory, or records built in place) while the DMA of its other buffer
 // runs, so the link sees pinned memory only and the fills of all threads overlap all transfers.
 struct PinRing {
-    static constexpr int kCopyThreads = 16;                 // buffers exist for this many; threads() of them are used
-    static constexpr size_t kPinBytes = 8u << 20;
+    static constexpr int kCopyThreads = 16;                 // buffer pairs: plain copies use threads() of them, the walkers
+                                                            // that produce a stream into the buffers (rows, run table) all
+    static constexpr size_t kPinBytes = 4u << 20;
     static int threads()                                    // DUT_COPY_THREADS (1..16), default 8
     {
         static const int n = [] {
@@ -223,7 +224,7 @@ struct PinRing {
         }
         return true;
     }
-    explicit PinRing(int dev) : device(dev) { ok = ensure_slots(threads()); }
+    explicit PinRing(int dev) : device(dev) { ok = ensure_slots(kCopyThreads); }
     ~PinRing()
     {
         (void)hipSetDevice(device);
@@ -262,7 +263,7 @@ struct StagingSet {
     RawVec<uint8_t> ref, mapq;
     RawVec<int32_t> pos;
     RawVec<uint32_t> cigar_off, cigar, end, ck_x, ck_y, rec_cnt;
-    RawVec<unsigned long long> qual_off;
+    RawVec<unsigned long long> qual_off, rb_off;
     RawVec<uint64_t> qbits;
 };
 constexpr size_t kStagingSets = 2;
@@ -330,8 +331,11 @@ struct cl_ctx {
     // pass-bit form (the default): bit g = quality byte g of the contig passes min_base_quality (mod.rs:33), taken in
     // cl_push_reads' walk; and, from the same walk, the sum of the passing qualities over the M/=/X bases of the reads
     // with mapq >= min_mapping_quality (contig_profiler.rs:65-70: summed_baseq is per-read separable)
-    RawVec<uint64_t> h_qbits;
+    RawVec<uint64_t> h_qbits;        // the reads' bit strings (reference order; pass_rows.h), word-aligned per read
+    RawVec<unsigned long long> h_rb_off;   // n + 1 word offsets into h_qbits (| dut::kRowSparse)
+    RawVec<uint32_t> h_sc_off, h_sc; // the CIGARs of the sparse reads (n + 1 offsets)
     uint64_t host_sum_q = 0;         // of the contig being pushed
+    uint64_t host_n_ops = 0;         // CIGAR operations pushed for it (pass-bit form: none is staged; for cl_contig_layout)
     uint64_t dev_sum_q = 0;          // of the resident contig (handed to the summary workgroup of every run)
     bool rec_counted = true;           // false: a tile of long-read shape skipped the count (cl_contig_upload makes up for it if the contig gets the short-read form after all)
     uint32_t n_long = 0;                 // reads with more than kLongOps operations
@@ -392,12 +396,12 @@ static void swap_staging(cl_ctx *c, StagingSet &o)
 {
     c->h_ref.swap(o.ref); c->h_mapq.swap(o.mapq); c->h_pos.swap(o.pos); c->h_cigar_off.swap(o.cigar_off);
     c->h_cigar.swap(o.cigar); c->h_end.swap(o.end); c->h_ck_x.swap(o.ck_x); c->h_ck_y.swap(o.ck_y); c->h_qual_off.swap(o.qual_off);
-    c->h_qbits.swap(o.qbits); c->h_rec_cnt.swap(o.rec_cnt);
+    c->h_qbits.swap(o.qbits); c->h_rec_cnt.swap(o.rec_cnt); c->h_rb_off.swap(o.rb_off);
 }
 // a context without staging memory of its own takes a pooled set (cl_contig_begin) ...
 static void take_staging(cl_ctx *c)
 {
-    if (c->h_pos.cap || c->h_cigar.cap || c->h_qual_off.cap) return;
+    if (c->h_pos.cap || c->h_cigar.cap || c->h_qual_off.cap || c->h_qbits.cap) return;
     std::unique_ptr<StagingSet> s;
     {
         std::lock_guard<std::mutex> g(g_staging_mu);
@@ -413,7 +417,7 @@ static void give_staging(cl_ctx *c)
     if (!s) return;
     swap_staging(c, *s);
     s->ref.clear(); s->mapq.clear(); s->pos.clear(); s->cigar_off.clear(); s->cigar.clear(); s->end.clear();
-    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear(); s->qbits.clear(); s->rec_cnt.clear();
+    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear(); s->qbits.clear(); s->rec_cnt.clear(); s->rb_off.clear();
     std::lock_guard<std::mutex> g(g_staging_mu);
     if (g_staging.size() < kStagingSets) { g_staging.push_back(std::move(s)); return; }
     size_t small = 0;
@@ -739,11 +743,14 @@ void host_window_bounds(const cl_ctx *c, std::vector<WinMeta> &win, uint32_t &fl
             m.wlo = lb(wpos, n_wide, W - (long long)c->span_w + 1);
             m.wn = lb(wpos, n_wide, W - (long long)c->span_n + 1) - m.wlo;
         }
-        const uint32_t first = m.wn ? c->h_wide_idx[m.wlo] : m.lo;      // lo <= n: the offsets array has n + 1 entries
-        const unsigned long long qf = c->h_qual_off[first], qh = c->h_qual_off[m.hi];
-        m.q0 = qf; m.rlo = 0; m.rn = 0;
-        // the byte forms of k_pileup address the quality bytes of a window with 32-bit offsets
-        if (!c->bits && m.hi > first && qh - qf > 0xFFFF0000ull) fl.fetch_or(kErrRange);
+        m.q0 = 0; m.rlo = 0; m.rn = 0;
+        if (!c->bits) {
+            // the byte forms of k_pileup address the quality bytes of a window with 32-bit offsets
+            const uint32_t first = m.wn ? c->h_wide_idx[m.wlo] : m.lo;      // lo <= n: the offsets array has n + 1 entries
+            const unsigned long long qf = c->h_qual_off[first], qh = c->h_qual_off[m.hi];
+            m.q0 = qf;
+            if (m.hi > first && qh - qf > 0xFFFF0000ull) fl.fetch_or(kErrRange);
+        }
         win[w] = m;
     });
     flags = fl.load();
@@ -1008,14 +1015,15 @@ dut::RowReads row_reads(const cl_ctx *c)
 {
     dut::RowReads H;
     H.pos = c->h_pos.data(); H.end = c->h_end.data(); H.mapq = c->h_mapq.data();
-    H.cigar_off = c->h_cigar_off.data(); H.cigar = c->h_cigar.data(); H.qual_off = c->h_qual_off.data();
-    H.bits = c->h_qbits.data(); H.ck_x = c->h_ck_x.data(); H.ck_y = c->h_ck_y.data();
+    H.off = c->h_rb_off.data(); H.bits = c->h_qbits.data();
+    H.sc_off = c->h_sc_off.data(); H.sc = c->h_sc.data();
     H.min_mapq = c->opt.min_mapping_quality;
     return H;
 }
 
-// The pass-bit rows of the resident contig (pass_rows.h), built by one more walk over the staged CIGARs at upload and
-// streamed to HBM the way the run table is: a thread takes a range of windows and sweeps it with a list of read cursors;
+// The pass-bit rows of the resident contig (pass_rows.h), laid out at upload from the reads' reference-order bit strings
+// (no CIGAR is looked at but those of the few gapped reads) and streamed to HBM the way the run table is: a thread takes
+// a range of windows and sweeps it with a list of read cursors;
 // the groups of a window are written straight into the pinned buffers of the staging ring, a buffer leaves when the
 // next window no longer fits, buffers are placed in the device array in the order they fill (a window only needs its
 // own groups contiguous: its record holds their index).  win[w].rlo / rn = first group / number of groups.
@@ -1428,7 +1436,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->h_wide_idx.clear(); c->h_wide_pos.clear(); c->span_n = 0; c->span_w = 0; c->n_wide = 0; c->host_max_end = 0;
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->n_long = 0; c->host_err = 0; c->bounds_err = 0;
     c->h_rec_cnt.clear(); c->rec_counted = true;
-    c->h_qbits.clear(); c->host_sum_q = 0;
+    c->h_qbits.clear(); c->h_rb_off.clear(); c->h_sc_off.clear(); c->h_sc.clear(); c->host_sum_q = 0; c->host_n_ops = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -1499,6 +1507,195 @@ cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, u
     return CL_OK;
 }
 
+// cl_push_reads of the pass-bit form: nothing goes to the device here.  One walk over the tile, in chunks on all host
+// threads, does everything that needs the reads' CIGAR operations and quality bytes while both are in the cache:
+// validation (what protects the later walks' indexing; the CIGAR shapes htslib's resolve_cigar2 asserts on), every
+// read's end (pos + bam_cigar2rlen, the pileup node span), the base-quality test of mod.rs:33 -- one
+// bit per base, qual_pack.cpp --, the read's share of summed_baseq (contig_profiler.rs:65-70) and, for every read with
+// mapq >= min_mapping_quality that is not a plain match, its pass bits mapped through the CIGAR into REFERENCE order
+// (pass_rows.h): what cl_contig_upload then lays out as rows is a string of bits per read, and no CIGAR is staged at all
+// (but those of reads whose span dwarfs their query: long N gaps).  A refused tile leaves the context as it was.
+static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0, uint64_t q0, uint64_t ncig, uint64_t nq)
+{
+    const uint64_t n = t->n_reads;
+    const uint64_t rbase = c->h_pos.size();
+    StageTimer tmr;
+    const size_t grain = dut::grain_for(n, 65536);
+    const size_t nchunk = (n + grain - 1) / grain;
+    struct Chunk {
+        int bad = 0; uint32_t err = 0, span_n = 0, span_w = 0; uint64_t max_end = 0, sum_q = 0, n_ops = 0, n_words = 0, n_sc = 0;
+        std::vector<uint32_t> wide;
+    };
+    std::vector<Chunk> ch(nchunk);
+    const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
+    try {
+        c->h_rec_cnt.reserve(rbase + n); c->h_end.reserve(rbase + n);
+        c->h_rb_off.reserve(rbase + n + 1); c->h_sc_off.reserve(rbase + n + 1);
+    } catch (const std::bad_alloc &) {
+        return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
+    }
+    // (entries [rbase, rbase + n) of the staging arrays are written below; their sizes follow when the tile is accepted,
+    // so a refused tile leaves nothing but unused capacity behind)
+    uint32_t *const h_end = c->h_end.data() + rbase, *const h_rec_cnt = c->h_rec_cnt.data() + rbase;
+    unsigned long long *const rb_off = c->h_rb_off.data() + rbase;      // first the reads' word counts (| kRowSparse), then their offsets
+    uint32_t *const sc_off = c->h_sc_off.data() + rbase;
+    const uint32_t min_mapq = c->opt.min_mapping_quality;
+    const uint8_t min_bq = c->opt.min_base_quality;
+    const int plevel = dut::qual_pack_level();
+    const uint8_t *const qsrc = t->qual ? t->qual + q0 : nullptr;
+    // ---- first: what needs the CIGAR operations only -- validation, ends, how many words of bits every read will leave ----
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        Chunk &o = ch[k];
+        const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
+        int32_t last = a ? t->pos[a - 1] : last0;
+        for (size_t i = a; i < b; ++i) {
+            const int32_t p = t->pos[i];
+            if (p < 0 || (uint32_t)p >= c->contig_len) { if (!o.bad) o.bad = 1; }
+            else if (p < last) { if (!o.bad) o.bad = 2; }
+            last = p;
+            h_end[i] = (uint32_t)p; h_rec_cnt[i] = 0u; rb_off[i] = 0ull; sc_off[i] = 0u;
+            if (t->cigar_off[i + 1] < t->cigar_off[i] || t->qual_off[i + 1] < t->qual_off[i]) { if (!o.bad) o.bad = 3; continue; }
+            if (t->cigar_off[i] < cig0 || t->cigar_off[i + 1] > cig0 + ncig) { if (!o.bad) o.bad = 3; continue; }
+            if (t->qual_off[i] < q0 || t->qual_off[i + 1] > q0 + nq) { if (!o.bad) o.bad = 3; continue; }
+            const uint32_t q0i = t->cigar_off[i], nops = t->cigar_off[i + 1] - q0i;
+            const uint32_t *cig = t->cigar + q0i;
+            o.n_ops += nops;
+            unsigned long long l = 0;
+            uint32_t zero_len = 0;
+            for (uint32_t q = 0; q < nops; ++q) {
+                const uint32_t cw = cig[q], len = cw >> 4;
+                const uint32_t radv = (0x18Du >> (cw & 15u)) & 1u;              // M D N = X consume the reference
+                l += len & (0u - radv);
+                zero_len |= radv & (len == 0u ? 1u : 0u);                      // zero-length reference-consuming op
+            }
+            if (zero_len) o.err |= kErrCigar;
+            // a read that reaches a column with a single non-match op is undefined in htslib
+            if (l > 0 && nops == 1u && !(((0x181u >> (cig[0] & 15u)) & 1u) != 0u)) o.err |= kErrCigar;
+            const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
+            // an end beyond the engine's 32-bit coordinate range: flagged; the read then spans nothing
+            if (l <= 0xFFFF0000ull - (uint64_t)p) { h_end[i] = (uint32_t)((uint64_t)p + l); o.max_end = std::max<uint64_t>(o.max_end, (uint64_t)p + l); }
+            else o.err |= kErrRange;
+            if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
+            else o.span_n = std::max(o.span_n, sp);
+            const bool in_pileup = h_end[i] != (uint32_t)p;
+            h_rec_cnt[i] = in_pileup ? 1u : 0u;                               // the head record k_pileup_rows reads
+            const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
+            if (!in_pileup || !ql || t->mapq[i] < min_mapq) continue;          // in no row (mod.rs:25, :33)
+            const uint64_t span = h_end[i] - (uint32_t)p;
+            uint64_t nw;
+            if (nops == 1u) nw = (std::min<uint64_t>(span, ql) + 63) >> 6;     // a plain match: its thresholded string as it is
+            else if (span > 4 * ql + 1024) {                                   // a span that dwarfs the query: query order + the CIGAR
+                nw = ((ql + 63) >> 6) | dut::kRowSparse;
+                sc_off[i] = nops; o.n_sc += nops;
+            } else nw = (span + 63) >> 6;                                      // mapped into reference order below
+            rb_off[i] = nw;
+            o.n_words += nw & ~dut::kRowSparse;
+        }
+    });
+    tmr.lap("push: validate + spans");
+    // (entry rbase of the two offset arrays closes the tiles before this one; the walk above used it for this tile's
+    // first read: put back whenever the tile is refused)
+    const unsigned long long closing_rb = c->h_qbits.size();
+    const uint32_t closing_sc = (uint32_t)c->h_sc.size();
+    auto refuse = [&](cl_status st, const char *m) { rb_off[0] = closing_rb; sc_off[0] = closing_sc; return fail(c, st, m); };
+    for (const Chunk &o : ch) {                                // the first offence in tile order decides the message
+        if (o.bad == 1) return refuse(CL_ERR_INVALID, "read position outside [0, contig_len): the region fetch (mod.rs:53) never yields it");
+        if (o.bad == 2) return refuse(CL_ERR_UNSORTED, "reads are not coordinate sorted");
+        if (o.bad == 3) return refuse(CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    }
+    // ---- where every chunk's strings go: behind the contig's ----
+    std::vector<uint64_t> rb_base(nchunk + 1), sc_base(nchunk + 1);
+    rb_base[0] = c->h_qbits.size(); sc_base[0] = c->h_sc.size();
+    for (size_t k = 0; k < nchunk; ++k) { rb_base[k + 1] = rb_base[k] + ch[k].n_words; sc_base[k + 1] = sc_base[k] + ch[k].n_sc; }
+    if (sc_base[nchunk] > 0xFFFFFFF0ull) return refuse(CL_ERR_RANGE, "more than 2^32 CIGAR operations of gapped reads in one contig");
+    size_t n_wide_new = 0;
+    for (const Chunk &o : ch) n_wide_new += o.wide.size();
+    try {
+        c->h_qbits.reserve(rb_base[nchunk] + 2); c->h_sc.reserve(sc_base[nchunk] + 1);
+        c->h_pos.reserve(rbase + n); c->h_mapq.reserve(rbase + n);
+        c->h_wide_idx.reserve(c->h_wide_idx.size() + n_wide_new); c->h_wide_pos.reserve(c->h_wide_pos.size() + n_wide_new);
+    } catch (const std::bad_alloc &) {
+        return refuse(CL_ERR_NOMEM, "host staging allocation failed");
+    }
+    uint64_t *const bits = c->h_qbits.data();
+    uint32_t *const scw = c->h_sc.data();
+    // ---- then: what needs the quality bytes -- the base-quality test (one bit per base), the reads' shares of
+    //      summed_baseq, and the bits of every read that is not a plain match mapped through its CIGAR into reference
+    //      order -- written straight to their place (the chunks' ranges are disjoint) ----
+    std::atomic<bool> oom{false};
+    dut::parallel_for(nchunk, 1, [&](size_t k) {
+        Chunk &o = ch[k];
+        const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
+        uint64_t wat = rb_base[k], sat = sc_base[k];
+        RawVec<uint64_t> qw;                                    // a read's query-order bits
+        RawVec<dut::QueryStretch> um;                           // where its inserted / clipped bases lie
+        try {
+        for (size_t i = a; i < b; ++i) {
+            const unsigned long long cnt = rb_off[i];
+            const uint64_t nw = cnt & ~dut::kRowSparse;
+            rb_off[i] = wat | (cnt & dut::kRowSparse);
+            const uint32_t nsc = sc_off[i];
+            sc_off[i] = (uint32_t)sat;
+            if (!nw) continue;
+            const uint32_t q0i = t->cigar_off[i], nops = t->cigar_off[i + 1] - q0i;
+            const uint32_t *cig = t->cigar + q0i;
+            const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
+            const uint8_t *q = qsrc + (t->qual_off[i] - q0);
+            const uint64_t span = h_end[i] - (uint32_t)t->pos[i];
+            if (nops == 1u) {
+                o.sum_q += dut::qual_pass_read(q, std::min<uint64_t>(span, ql), min_bq, bits + wat, plevel);
+            } else {
+                const uint64_t nqw = (ql + 63) >> 6;
+                const bool sparse = (cnt & dut::kRowSparse) != 0ull;
+                uint64_t *dstq;
+                if (sparse) dstq = bits + wat;
+                else { qw.resize(nqw + 1); dstq = qw.data(); dstq[nqw] = 0ull; }
+                const uint64_t all = dut::qual_pass_read(q, ql, min_bq, dstq, plevel);      // every byte of the string that passes ...
+                um.resize(nops + 1);
+                size_t n_um = 0; unsigned long long qlen = 0;
+                if (sparse) {
+                    // (a gapped read keeps its query-order bits and its CIGAR; the mapping below runs into a scratch word
+                    // count of zero: only the list of its inserted / clipped bases is wanted)
+                    memcpy(scw + sat, cig, (size_t)nops * sizeof(uint32_t));
+                    unsigned long long y = 0;
+                    for (uint32_t j = 0; j < nops; ++j) {
+                        const uint32_t cw = cig[j], op = cw & 15u, l = cw >> 4;
+                        if (!((0x193u >> op) & 1u)) continue;
+                        if (!((0x181u >> op) & 1u)) { um[n_um].y = y; um[n_um].l = l; ++n_um; }
+                        y += l;
+                    }
+                    qlen = y;
+                } else {
+                    // ... mapped through the CIGAR into reference order, here where the operations are in the cache
+                    dut::ref_bits_from_query(qw.data(), ql, cig, nops, bits + wat, um.data(), &n_um, &qlen);
+                }
+                o.sum_q += all - dut::unmatched_pass_sum(q, ql, um.data(), n_um, qlen, min_bq);   // ... minus those of inserted / clipped bases
+            }
+            wat += nw; sat += nsc;
+        }
+        } catch (const std::bad_alloc &) { oom.store(true); }
+    });
+    tmr.lap("push: pass bits in reference order");
+    if (oom.load()) return refuse(CL_ERR_NOMEM, "host staging allocation failed");
+    // ---- the tile is accepted (nothing below can fail: the capacity is there) ----
+    for (const Chunk &o : ch) {
+        c->host_err |= o.err; c->host_sum_q += o.sum_q; c->host_n_ops += o.n_ops;
+        c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
+        c->host_max_end = std::max(c->host_max_end, o.max_end);
+        for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
+    }
+    c->h_qbits.resize(rb_base[nchunk]); c->h_sc.resize(sc_base[nchunk]);
+    c->h_qbits.data()[rb_base[nchunk]] = 0ull;                 // the word deposit_bits may read behind the last string
+    c->h_end.resize(rbase + n); c->h_rec_cnt.resize(rbase + n);
+    c->h_rb_off.resize(rbase + n + 1); c->h_sc_off.resize(rbase + n + 1);
+    rb_off[n] = rb_base[nchunk]; sc_off[n] = (uint32_t)sc_base[nchunk];
+    c->h_pos.append(t->pos, n);
+    c->h_mapq.append(t->mapq, n);
+    tmr.lap("push: stage small arrays");
+    c->q_dev += nq;                                          // (the contig's quality bytes so far: none on the device)
+    return CL_OK;
+}
+
 static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
 {
     if (!c || !t) return CL_ERR_INVALID;
@@ -1516,6 +1713,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     if (nq && !t->qual) return fail(c, CL_ERR_INVALID, "null qual array");
     if (c->h_cigar.size() + ncig > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "more than 2^32 CIGAR operations in one contig");
     if (c->q_dev + c->h_qual.size() + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality bytes in one contig");
+    if (c->bits) return push_reads_bits(c, t, cig0, q0, ncig, nq);      // the pass-bit form: no quality byte goes to the device
     const uint32_t cbase = (uint32_t)c->h_cigar.size();
     const uint64_t rbase = c->h_pos.size();
 
@@ -1525,8 +1723,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     //      the small arrays.  All are joined before the call returns (the caller's buffer is free again then);
     //      nothing of the context changes if the tile turns out to be invalid. ----
     struct RingGuard { cl_ctx *c; bool active = false; ~RingGuard() { if (active) (void)ring_finish(c); } } ring{c};
-    const bool bits = c->bits;                                // the pass-bit form: no quality byte goes to the device
-    const bool direct = !bits && nq >= kDirectQual;
+    const bool direct = nq >= kDirectQual;
     if (direct) {
         const uint8_t *src = t->qual + q0;
         const bool prefetched = c->pf_active && c->pf_src == src && c->pf_n == nq && c->h_qual.empty() && c->pf_off == c->q_dev;
@@ -1562,12 +1759,11 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     // that every thread has some)
     const size_t grain = dut::grain_for(n, 65536);
     const size_t nchunk = (n + grain - 1) / grain;
-    struct Chunk { int bad = 0; uint32_t n_long = 0, err = 0; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0, sum_q = 0; std::vector<uint32_t> wide; };
+    struct Chunk { int bad = 0; uint32_t n_long = 0, err = 0; uint32_t span_n = 0, span_w = 0; uint64_t max_end = 0; std::vector<uint32_t> wide; };
     std::vector<Chunk> ch(nchunk);
     const int32_t last0 = c->h_pos.empty() ? 0 : c->h_pos.back();
     try {
         c->h_rec_cnt.reserve(rbase + n);
-        if (bits) c->h_qbits.reserve(((qbase + nq + 63) >> 6) + 2);
         c->h_end.reserve(rbase + n);                           // entries [rbase, rbase + n) are written below; the
         c->h_ck_x.reserve(((cbase + ncig) >> 6) + 2);          // sizes follow when the tile is accepted (a refused
         c->h_ck_y.reserve(((cbase + ncig) >> 6) + 2);          // tile leaves only unused capacity behind)
@@ -1577,23 +1773,6 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     uint32_t *const h_end = c->h_end.data() + rbase, *const h_ck_x = c->h_ck_x.data(), *const h_ck_y = c->h_ck_y.data();
     uint32_t *const h_rec_cnt = c->h_rec_cnt.data() + rbase;
     const uint32_t min_mapq = c->opt.min_mapping_quality;
-    // pass-bit form: the bits of this tile's quality bytes [qbase, qbase + nq) of the contig.  A word of the bit array
-    // belongs to the chunk (below: to the block of reads) that holds its FIRST byte, so no two threads write one word;
-    // the word that holds byte qbase itself, when earlier tiles left it partly filled, is completed after the walk.
-    uint64_t *const qbits = c->h_qbits.data();
-    const uint8_t *const qsrc = t->qual ? t->qual + q0 : nullptr;
-    const uint8_t min_bq = c->opt.min_base_quality;
-    const int plevel = dut::qual_pack_level();
-    auto pack_range = [&](uint64_t ga, uint64_t gb) {          // the words whose first byte lies in tile bytes [ga, gb)
-        if (ga >= gb) return;
-        uint64_t w0 = (qbase + ga + 63) >> 6;
-        const uint64_t w1 = (qbase + gb + 63) >> 6;            // first word NOT of this range
-        if (w0 >= w1) return;
-        // whole words, then the tile's last, partial one (its upper bits stay zero)
-        const uint64_t wfull = std::min<uint64_t>(w1, (qbase + nq) >> 6);
-        if (wfull > w0) { dut::qual_pass_words(qsrc + ((w0 << 6) - qbase), wfull - w0, min_bq, qbits + w0, plevel); w0 = wfull; }
-        if (w0 < w1) qbits[w0] = dut::qual_pass_partial(qsrc + ((w0 << 6) - qbase), (uint32_t)(qbase + nq - (w0 << 6)), min_bq);
-    };
     // (a tile of long-read shape -- 8 or more operations per read -- will not get the short-read form: its reads'
     // records are not counted here, that would be a second pass over every operation)
     const bool count_recs = ncig < 8ull * n;
@@ -1601,15 +1780,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         Chunk &o = ch[k];
         const size_t a = k * grain, b = std::min<size_t>(n, a + grain);
         int32_t last = a ? t->pos[a - 1] : last0;
-        // blocks of 256 reads: their quality bytes (about 40 KB of short reads) are turned into pass bits first and are
-        // still in the cache when the reads' sums are taken
-        for (size_t ib = a; ib < b; ib += 256) {
-        const size_t ie = std::min(b, ib + 256);
-        if (bits) {
-            const uint64_t ga = t->qual_off[ib] - q0, gb = t->qual_off[ie] - q0;
-            if (t->qual_off[ib] >= q0 && ga <= gb && gb <= nq) pack_range(ga, gb);      // (else: flagged bad = 3 below)
-        }
-        for (size_t i = ib; i < ie; ++i) {
+        for (size_t i = a; i < b; ++i) {
             const int32_t p = t->pos[i];
             if (p < 0 || (uint32_t)p >= c->contig_len) { if (!o.bad) o.bad = 1; }
             else if (p < last) { if (!o.bad) o.bad = 2; }
@@ -1620,7 +1791,6 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             if (t->qual_off[i] < q0 || t->qual_off[i + 1] > q0 + nq) { if (!o.bad) o.bad = 3; continue; }
             const uint32_t q0i = t->cigar_off[i], q1i = t->cigar_off[i + 1], nops = q1i - q0i;
             unsigned long long l = 0;
-            uint64_t long_sum = 0;
             if (nops <= kLongOps) {
                 for (uint32_t q = q0i; q < q1i; ++q) {
                     const uint32_t cw = t->cigar[q], len = cw >> 4;
@@ -1634,12 +1804,6 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
                 o.n_long += 1;
                 uint32_t yq = 0;                                               // query advance (M I S = X), modulo 2^32
                 const uint32_t shift = cbase - cig0;                           // tile op index -> contig op index (mod 2^32)
-                // (pass-bit form: the read's share of summed_baseq is its whole quality string's passing bytes minus
-                // those of its inserted and clipped bases -- taken here, in the one loop over its operations)
-                const unsigned long long qli = t->qual_off[i + 1] - t->qual_off[i];
-                const uint8_t *qi = (bits && qli && t->mapq[i] >= min_mapq) ? qsrc + (t->qual_off[i] - q0) : nullptr;
-                unsigned long long y64 = 0;
-                uint64_t minus = 0;
                 for (uint32_t q = q0i; q < q1i; ++q) {
                     const uint32_t kc = q + shift;
                     if ((kc & 63u) == 0u) {
@@ -1652,13 +1816,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
                     l += radv ? len : 0u;
                     yq += qadv ? len : 0u;
                     if (radv && len == 0u) o.err |= kErrCigar;
-                    if (qadv) {
-                        if (qi && !radv)                                       // I S
-                            for (unsigned long long b2 = y64, e2 = std::min<unsigned long long>(qli, y64 + len); b2 < e2; ++b2) minus += qi[b2] >= min_bq ? qi[b2] : 0u;
-                        y64 += len;
-                    }
                 }
-                if (qi) long_sum = dut::qual_pass_sum(qi, std::min<unsigned long long>(qli, y64), min_bq, plevel) - minus;
             }
             const uint32_t sp = l > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)l;
             // an end beyond the engine's 32-bit coordinate range: flagged; the read then spans nothing
@@ -1666,17 +1824,8 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             else o.err |= kErrRange;
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
-            if (bits) {
-                // pass-bit form: a head record per read with a reference span (k_pileup_rows), and the read's share of
-                // summed_baseq (contig_profiler.rs:65-70): the passing qualities of its M/=/X bases that have a quality
-                // byte, for reads with mapq >= min_mapping_quality -- the bytes are in the cache from pack_range above
-                const bool in_pileup = h_end[i] != (uint32_t)p;
-                h_rec_cnt[i] = in_pileup ? 1u : 0u;
-                const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
-                if (in_pileup && ql && t->mapq[i] >= min_mapq)
-                    o.sum_q += nops > kLongOps ? long_sum : read_pass_sum(qsrc + (t->qual_off[i] - q0), ql, t->cigar + q0i, nops, min_bq, plevel);
-            } else if (count_recs) {
-                // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
+            // the records the short-read form would get for this read (counted here, where its CIGAR is hot)
+            if (count_recs) {
                 const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
                 const uint32_t mq = t->mapq[i];
                 uint32_t cnt;
@@ -1686,7 +1835,6 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
                 else cnt = gen_read_recs(p, h_end[i], mq, min_mapq, t->cigar + q0i, nops, 0ull, ql, [](uint32_t, const ReadRec &) {});
                 h_rec_cnt[i] = cnt;
             }
-        }
         }
     });
     tmr.lap("push: validate + spans");
@@ -1699,7 +1847,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
     // ---- staging of the small arrays (offsets rebased onto the contig's); undone if anything below fails, so that
     //      a refused tile leaves the context as it was ----
     struct Undo {
-        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; uint32_t n_long, host_err; bool has_long; uint32_t span_n, span_w; uint64_t max_end, sum_q; bool armed = true;
+        cl_ctx *c; size_t n_pos, n_cig, n_qual, n_wide; uint32_t n_long, host_err; bool has_long; uint32_t span_n, span_w; uint64_t max_end; bool armed = true;
         ~Undo()
         {
             if (!armed) return;
@@ -1708,26 +1856,24 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
             c->h_wide_idx.resize(n_wide); c->h_wide_pos.resize(n_wide); c->n_long = n_long; c->host_err = host_err;
             c->h_end.resize(n_pos); c->h_ck_x.resize((n_cig >> 6) + 2); c->h_ck_y.resize((n_cig >> 6) + 2);
             c->h_rec_cnt.resize(n_pos);
-            c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end; c->host_sum_q = sum_q;
+            c->has_long = has_long; c->span_n = span_n; c->span_w = span_w; c->host_max_end = max_end;
         }
-    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->n_long, c->host_err, c->has_long, c->span_n, c->span_w, c->host_max_end, c->host_sum_q};
+    } undo{c, c->h_pos.size(), c->h_cigar.size(), c->h_qual.size(), c->h_wide_idx.size(), c->n_long, c->host_err, c->has_long, c->span_n, c->span_w, c->host_max_end};
     try {
         for (const Chunk &o : ch) {
             if (o.n_long) c->has_long = true;
             c->n_long += o.n_long; c->host_err |= o.err;
             c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
             c->host_max_end = std::max(c->host_max_end, o.max_end);
-            c->host_sum_q += o.sum_q;
             for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
         }
         c->h_end.resize(rbase + n); c->h_ck_x.resize(((cbase + ncig) >> 6) + 2); c->h_ck_y.resize(((cbase + ncig) >> 6) + 2);
         c->h_rec_cnt.resize(rbase + n);
-        if (!bits && !count_recs) c->rec_counted = false;
-
+        if (!count_recs) c->rec_counted = false;
         c->h_pos.append(t->pos, n);
         c->h_mapq.append(t->mapq, n);
         c->h_cigar.append(t->cigar + cig0, ncig);
-        if (!direct && !bits) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
+        if (!direct) c->h_qual.insert(c->h_qual.end(), t->qual + q0, t->qual + q0 + nq);
         const size_t o0 = c->h_cigar_off.size();               // == rbase + 1: entry r+1 closes read r
         c->h_cigar_off.resize(o0 + n);
         c->h_qual_off.resize(o0 + n);
@@ -1747,16 +1893,7 @@ static cl_status cl_push_reads_impl(cl_ctx *c, const cl_read_tile *t)
         if (rs != CL_OK) return rs;
     }
     tmr.lap("push: wait for the qualities");
-    if (bits && nq) {
-        // (last: nothing fails from here on.)  The word that holds the tile's first byte, when that is not the word's
-        // first, belongs to no block of the walk -- its first byte is an earlier tile's --: completed here; the bits
-        // above the contig's bytes so far are zero (a tile's last word is written whole, zeros above its bytes)
-        const uint64_t head = (qbase & 63ull) ? std::min<uint64_t>(nq, 64ull - (qbase & 63ull)) : 0ull;
-        if (head) qbits[qbase >> 6] |= dut::qual_pass_partial(qsrc, (uint32_t)head, min_bq) << (qbase & 63ull);
-        c->h_qbits.resize(((qbase + nq + 63) >> 6) + 1);       // (capacity reserved above: the data stay where they are)
-        c->h_qbits[c->h_qbits.size() - 1] = 0ull;              // the pad word deposit_bits may read
-    }
-    if (direct || bits) c->q_dev += nq;                      // (pass-bit form: the contig's quality bytes so far, none on the device)
+    if (direct) c->q_dev += nq;
     undo.armed = false;
     return CL_OK;
 }
@@ -1778,7 +1915,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     HIP_TRY(c, hipSetDevice(c->device));
     drop_prefetch(c);
     c->n_reads = (uint32_t)c->h_pos.size();
-    c->n_cigar = c->h_cigar.size();
+    c->n_cigar = c->bits ? c->host_n_ops : c->h_cigar.size();
     if (!c->bits) {
         cl_status fs = flush_staged_qual(c);
         if (fs != CL_OK) return fs;
@@ -1893,7 +2030,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // context's or another's (giving back and re-faulting a few hundred megabytes per contig was a fifth of a contig's
     // host time).
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
-    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qbits.clear();
+    c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qbits.clear(); c->h_rb_off.clear(); c->h_sc_off.clear(); c->h_sc.clear();
     c->h_rec_of.clear(); c->h_wide_rec_of.clear();       // (capacity kept for the context's next contig)
     c->h_rec_cnt.clear();
     give_staging(c);
@@ -1934,6 +2071,12 @@ cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_o
 
 cl_status cl_debug_qual_pack(const uint8_t *qual, uint64_t n, uint8_t min_base_quality, int level, uint64_t *words_out, uint64_t *sum_out)
 {
+    if (level >= 10 && level <= 12) {                            // the one-pass form cl_push_reads uses per read
+        if ((n && !qual) || !words_out) return CL_ERR_INVALID;
+        const uint64_t sm = dut::qual_pass_read(qual, n, min_base_quality, words_out, level - 10);
+        if (sum_out) *sum_out = sm;
+        return CL_OK;
+    }
     if ((n && !qual) || level < 0 || level > 2) return CL_ERR_INVALID;
     if (words_out) {
         dut::qual_pass_words(qual, n >> 6, min_base_quality, words_out, level);
@@ -2130,7 +2273,8 @@ cl_status cl_contig_abort(cl_ctx *c)
     }
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qual.clear(); c->h_qbits.clear(); c->h_rec_cnt.clear();
-    c->q_dev = 0; c->host_sum_q = 0;
+    c->h_rb_off.clear(); c->h_sc_off.clear(); c->h_sc.clear();
+    c->q_dev = 0; c->host_sum_q = 0; c->host_n_ops = 0;
     c->in_contig = false; c->uploaded = false; c->ran = false;
     return CL_OK;
 }

@@ -23,21 +23,26 @@
 namespace dut {
 
 constexpr uint32_t kRowGroupWords = 256;          // 32-bit words per group of 4 rows (T = 2048: 64 blocks x 4 rows)
-constexpr uint32_t kRowLongOps = 64;              // reads with more CIGAR ops have (reference, query) checkpoints
+constexpr unsigned long long kRowSparse = 1ull << 63;   // flag in a read's bit offset: query-order bits + its CIGAR (below)
 
-// host views of the staged contig (callable_loci.hip fills these from the context's staging arrays)
+// host views of the staged contig (callable_loci.hip fills these from the context's staging arrays).  cl_push_reads
+// leaves every read with mapq >= min_mapq and a reference span as a string of pass bits in REFERENCE order -- bit j of
+// the string <-> position pos + j: the pass bit of the M/=/X base there, 0 for D, N and bases without a quality byte --,
+// word-aligned in `bits` from word off[i] to off[i + 1] (a plain match read: its thresholded quality string as it is; any
+// other read: mapped through its CIGAR in the walk that validates the tile, where the operations are in the cache).  Only
+// a read whose span dwarfs its query (long N gaps: span > 4 ql + 1024) stays in QUERY order, flagged kRowSparse, with
+// its CIGAR in sc[sc_off[i], sc_off[i + 1]): it is walked per window.
 struct RowReads {
     const int32_t *pos;
     const uint32_t *end;                          // pos + bam_cigar2rlen
     const uint8_t *mapq;
-    const uint32_t *cigar_off, *cigar;
-    const unsigned long long *qual_off;           // n + 1; also the bit offsets into `bits`
-    const uint64_t *bits;                         // bit g = quality byte g passes min_base_quality
-    const uint32_t *ck_x, *ck_y;                  // checkpoint before every 64th operation of the contig's CIGAR array
+    const unsigned long long *off;                // n + 1 word offsets into `bits` (| kRowSparse)
+    const uint64_t *bits;
+    const uint32_t *sc_off, *sc;                  // CIGARs of the sparse reads (n + 1 offsets)
     uint32_t min_mapq;
 };
 
-struct RowCur { uint32_t k, k1, x, y, qlen, pos, end; unsigned long long q0; };
+struct RowCur { uint32_t k, k1, x, y, qlen, pos, end; unsigned long long o; bool sparse; };
 
 struct RowScratch { std::vector<uint32_t> rend; };
 
@@ -60,29 +65,88 @@ inline void deposit_bits(const uint64_t *src, unsigned long long o, uint32_t n, 
     }
 }
 
-// a read that covers positions at or after W enters the sweep (reads below min_mapq never do, mod.rs:25); reads with
-// more than kRowLongOps operations that start before W enter at their last checkpoint at or before W
+// A read's pass bits from query order (qw: bit k <-> base k, ql bases, one readable word behind them) to reference
+// order: rw[0, ceil(span / 64)) is written whole.  What the column walk visits as (alignment, qpos) with !is_del are the
+// bases of M/=/X operations (mod.rs:30-37); a base without a quality byte (k >= ql) never passes.  Written without a
+// branch on the kind of operation (insertions and deletions alternate at random in long reads: a mispredicted branch per
+// operation cost more than the work): every operation appends `lr` bits to the reference string -- its length if it
+// consumes the reference, else 0 -- of which the first `lq` come from the query bits -- if it is a match -- and the rest
+// are zeros.  unmatched[0, *n_unmatched): where the inserted / clipped bases lie in the query (the caller's scratch holds
+// nops entries), for unmatched_pass_sum.
+struct QueryStretch { unsigned long long y, l; };
+inline void ref_bits_from_query(const uint64_t *qw, unsigned long long ql, const uint32_t *cig, uint32_t nops, uint64_t *rw,
+                                QueryStretch *unmatched, size_t *n_unmatched, unsigned long long *query_len)
+{
+    uint64_t acc = 0;
+    uint32_t accn = 0;
+    size_t wout = 0, nu = 0;
+    unsigned long long y = 0;
+    for (uint32_t j = 0; j < nops; ++j) {
+        const uint32_t cw = cig[j], op = cw & 15u;
+        const unsigned long long l = cw >> 4;
+        const unsigned long long ism = (0x181u >> op) & 1u, radv = (0x18Du >> op) & 1u, qadv = (0x193u >> op) & 1u;
+        unmatched[nu].y = y; unmatched[nu].l = l;                   // (kept only for I and S)
+        nu += (size_t)(qadv & (ism ^ 1ull));
+        const unsigned long long avail = y < ql ? ql - y : 0ull;
+        unsigned long long have = std::min(avail, l) & (0ull - ism);   // bits that come from the query
+        unsigned long long rem = l & (0ull - radv);                    // bits this operation appends
+        unsigned long long src = std::min(y, ql);                      // (clamped: read, then masked away, when have = 0)
+        y += l & (0ull - qadv);
+        while (rem) {                                               // one trip unless the operation crosses a word
+            const unsigned long long take = std::min<unsigned long long>(rem, 64u - accn);
+            const unsigned long long tb = std::min(have, take);
+            const unsigned long long w = src >> 6;
+            const uint32_t s = (uint32_t)(src & 63ull);
+            uint64_t v = (qw[w] >> s) | ((qw[w + 1] << 1) << (63u - s));
+            v &= tb >= 64ull ? ~0ull : ((1ull << tb) - 1ull);
+            acc |= v << accn;
+            accn += (uint32_t)take; src += tb; have -= tb; rem -= take;
+            if (accn == 64u) { rw[wout++] = acc; acc = 0; accn = 0; }
+        }
+    }
+    if (accn) rw[wout++] = acc;
+    *n_unmatched = nu;
+    *query_len = y;
+}
+
+// The passing quality bytes of a read that are NOT bases of M/=/X operations: inserted and clipped bases (listed by
+// ref_bits_from_query), and whatever the quality string holds beyond the CIGAR's query length (contig_profiler.rs:65-70
+// sums over the matched bases only: the read's share of summed_baseq is the sum over its whole string minus this).
+inline uint64_t unmatched_pass_sum(const uint8_t *q, unsigned long long ql, const QueryStretch *unmatched, size_t n_unmatched,
+                                   unsigned long long query_len, uint8_t thr)
+{
+    uint64_t s = 0;
+    if (ql == 0) return 0;
+    for (size_t k = 0; k < n_unmatched; ++k) {
+        const unsigned long long y = unmatched[k].y, l = unmatched[k].l;
+        const unsigned long long cnt = y < ql ? std::min(ql - y, l) : 0ull;
+        // the first four bases without a branch (insertions are short), the rest of a long one in a loop
+        for (unsigned b = 0; b < 4u; ++b) {
+            const uint8_t v = q[std::min(y + b, ql - 1ull)];
+            s += (b < cnt && v >= thr) ? v : 0u;
+        }
+        for (unsigned long long b = 4; b < cnt; ++b) s += q[y + b] >= thr ? q[y + b] : 0u;
+    }
+    for (unsigned long long b = query_len; b < ql; ++b) s += q[b] >= thr ? q[b] : 0u;
+    return s;
+}
+
+// a read that covers positions at or after W enters the sweep (reads below min_mapq never do, mod.rs:25; neither do
+// reads that left no bits: no quality string)
 inline void rows_enter(std::vector<RowCur> &act, const RowReads &H, uint32_t r, uint32_t W)
 {
     if (H.mapq[r] < H.min_mapq) return;
+    const unsigned long long o0 = H.off[r] & ~kRowSparse, o1 = H.off[r + 1] & ~kRowSparse;
+    if (o1 == o0) return;
     RowCur cu;
-    cu.k = H.cigar_off[r]; cu.k1 = H.cigar_off[r + 1]; cu.x = (uint32_t)H.pos[r]; cu.y = 0;
-    cu.pos = cu.x; cu.end = H.end[r];
-    if (cu.k >= cu.k1 || cu.end <= W || cu.end <= cu.pos) return;
-    const unsigned long long ql = H.qual_off[r + 1] - H.qual_off[r];
-    cu.qlen = ql > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ql;
-    cu.q0 = H.qual_off[r];
-    if (cu.k1 - cu.k > kRowLongOps && cu.x < W) {
-        const uint32_t jlo = (cu.k + 63u) >> 6, jhi = (cu.k1 - 1u) >> 6;
-        if (jlo <= jhi && H.ck_x[jlo] <= W) {
-            uint32_t lo_j = jlo, hi_j = jhi;
-            while (lo_j < hi_j) {
-                const uint32_t mid = lo_j + ((hi_j - lo_j + 1u) >> 1);
-                if (H.ck_x[mid] <= W) lo_j = mid; else hi_j = mid - 1u;
-            }
-            cu.k = lo_j << 6; cu.x = H.ck_x[lo_j]; cu.y = H.ck_y[lo_j];
-        }
-    }
+    cu.pos = (uint32_t)H.pos[r]; cu.end = H.end[r];
+    if (cu.end <= W || cu.end <= cu.pos) return;
+    cu.o = o0 << 6;
+    cu.sparse = (H.off[r] & kRowSparse) != 0ull;
+    const unsigned long long nb = (o1 - o0) << 6;                   // bits stored (whole words: the tail is zeros)
+    cu.qlen = nb > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)nb;
+    cu.k = cu.k1 = 0; cu.x = cu.pos; cu.y = 0;
+    if (cu.sparse) { cu.k = H.sc_off[r]; cu.k1 = H.sc_off[r + 1]; if (cu.k >= cu.k1) return; }
     act.push_back(cu);
 }
 
@@ -129,18 +193,27 @@ inline size_t rows_window(std::vector<RowCur> &act, const RowReads &H, uint32_t 
         rend[r] = e;                                                // (a row's end only grows: min_end stays a lower bound)
         min_end = std::min(min_end, e);
         rot = r + 1u == nr ? 0u : r + 1u;
-        // -- its M/=/X bases inside the window (what the column walk visits as (alignment, qpos) with !is_del)
+        if (!cu.sparse) {
+            // -- reference-order bits: the window's stretch of the string, as it is
+            const uint32_t sp = cu.pos > W ? cu.pos : W;
+            unsigned long long tp = cu.end < Wend ? cu.end : Wend;
+            tp = std::min<unsigned long long>(tp, (unsigned long long)cu.pos + cu.qlen);
+            if (sp < tp) deposit_bits(H.bits, cu.o + (sp - cu.pos), (uint32_t)(tp - sp), out, r, sp - W);
+            if (cu.end > Wend) act[keep++] = cu;
+            continue;
+        }
+        // -- a sparse read: its M/=/X bases inside the window, operation by operation
         while (cu.k < cu.k1 && cu.x < Wend) {
-            const uint32_t cw = H.cigar[cu.k], op = cw & 15u, l = cw >> 4;
+            const uint32_t cw = H.sc[cu.k], op = cw & 15u, l = cw >> 4;
             const uint32_t radv = (0x18Du >> op) & 1u, qadv = (0x193u >> op) & 1u, ism = (0x181u >> op) & 1u;
             const uint32_t xe = cu.x + (radv ? l : 0u);
             if (xe < cu.x) { cu.k = cu.k1; break; }                 // wraps the 32-bit coordinate: flagged kErrRange at push
             if (ism) {
                 const uint32_t sp = cu.x > W ? cu.x : W;
-                const uint32_t lq = cu.y < cu.qlen ? std::min(cu.qlen - cu.y, l) : 0u;   // bases that have a quality byte
+                const uint32_t lq = cu.y < cu.qlen ? std::min(cu.qlen - cu.y, l) : 0u;   // bases that have a (possibly zero) bit
                 unsigned long long tp = xe < Wend ? xe : Wend;
                 tp = std::min<unsigned long long>(tp, (unsigned long long)cu.x + lq);
-                if (sp < tp) deposit_bits(H.bits, cu.q0 + cu.y + (sp - cu.x), (uint32_t)(tp - sp), out, r, sp - W);
+                if (sp < tp) deposit_bits(H.bits, cu.o + cu.y + (sp - cu.x), (uint32_t)(tp - sp), out, r, sp - W);
             }
             if (xe > Wend) break;                                   // the operation goes on in the next window
             cu.x = xe; cu.y += qadv ? l : 0u; cu.k += 1u;

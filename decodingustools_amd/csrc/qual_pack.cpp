@@ -93,6 +93,40 @@ bool has_avx2()
     return v;
 }
 
+// one read in one pass: its pass words (bits above n zero) and the sum of its passing bytes
+__attribute__((target("avx2"))) uint64_t read_avx2(const uint8_t *q, uint64_t n, uint8_t thr, uint64_t *out)
+{
+    const __m256i t = _mm256_set1_epi8((char)thr), z = _mm256_setzero_si256();
+    __m256i acc = z;
+    uint64_t i = 0, w = 0;
+    for (; i + 64 <= n; i += 64, ++w) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q + i));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q + i + 32));
+        const __m256i ma = _mm256_cmpeq_epi8(_mm256_max_epu8(a, t), a), mb = _mm256_cmpeq_epi8(_mm256_max_epu8(b, t), b);
+        out[w] = (uint64_t)(uint32_t)_mm256_movemask_epi8(ma) | ((uint64_t)(uint32_t)_mm256_movemask_epi8(mb) << 32);
+        acc = _mm256_add_epi64(acc, _mm256_add_epi64(_mm256_sad_epu8(_mm256_and_si256(a, ma), z), _mm256_sad_epu8(_mm256_and_si256(b, mb), z)));
+    }
+    uint64_t lanes[4];
+    _mm256_storeu_si256(reinterpret_cast<__m256i *>(lanes), acc);
+    uint64_t sum = lanes[0] + lanes[1] + lanes[2] + lanes[3];
+    if (i < n) {
+        uint64_t m = 0;
+        uint64_t k = 0;
+        if (i + 32 <= n) {
+            const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(q + i));
+            const __m256i ma = _mm256_cmpeq_epi8(_mm256_max_epu8(a, t), a);
+            m = (uint64_t)(uint32_t)_mm256_movemask_epi8(ma);
+            const __m256i sd = _mm256_sad_epu8(_mm256_and_si256(a, ma), z);
+            _mm256_storeu_si256(reinterpret_cast<__m256i *>(lanes), sd);
+            sum += lanes[0] + lanes[1] + lanes[2] + lanes[3];
+            k = 32;
+        }
+        for (; i + k < n; ++k) { const uint8_t v = q[i + k]; if (v >= thr) { m |= 1ull << k; sum += v; } }
+        out[w] = m;
+    }
+    return sum;
+}
+
 } // namespace
 
 int qual_pack_level() { return has_avx2() ? 2 : 1; }
@@ -104,6 +138,14 @@ void qual_pass_words(const uint8_t *q, uint64_t n_words, uint8_t thr, uint64_t *
 }
 
 uint64_t qual_pass_partial(const uint8_t *q, uint32_t n, uint8_t thr) { return mask64_scalar(q, n > 64 ? 64 : n, thr); }
+
+uint64_t qual_pass_read(const uint8_t *q, uint64_t n, uint8_t thr, uint64_t *out, int level)
+{
+    if (level >= 2 && has_avx2()) return read_avx2(q, n, thr, out);
+    qual_pass_words(q, n >> 6, thr, out, level);
+    if (n & 63ull) out[n >> 6] = qual_pass_partial(q + (n & ~63ull), (uint32_t)(n & 63ull), thr);
+    return qual_pass_sum(q, n, thr, level);
+}
 
 uint64_t qual_pass_sum(const uint8_t *q, uint64_t n, uint8_t thr, int level)
 {

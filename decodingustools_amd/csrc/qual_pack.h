@@ -11,6 +11,8 @@ int qual_pack_level();
 void qual_pass_words(const uint8_t *q, uint64_t n_words, uint8_t thr, uint64_t *out, int level = 2);
 // the same for n <= 64 bytes: bits [n, 64) are zero
 uint64_t qual_pass_partial(const uint8_t *q, uint32_t n, uint8_t thr);
+// both in one pass over a read's n quality bytes: out[0, ceil(n / 64)) (zeros above bit n), returns the sum
+uint64_t qual_pass_read(const uint8_t *q, uint64_t n, uint8_t thr, uint64_t *out, int level = 2);
 // sum of q[i] over the i < n with q[i] >= thr
 uint64_t qual_pass_sum(const uint8_t *q, uint64_t n, uint8_t thr, int level = 2);
 

@@ -211,7 +211,7 @@ cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_o
 
 /* Host only: the pass bits of n quality bytes (words_out: ceil(n / 64) 64-bit words, bit i of word i / 64 <-> byte i,
  * zeros above byte n) and the sum of the passing bytes, as cl_push_reads takes them -- at `level` 0 scalar, 1 SSE2,
- * 2 AVX2 where the CPU has it (else SSE2). */
+ * 2 AVX2 where the CPU has it (else SSE2); 10, 11, 12: the same levels through the one-pass form (bits and sum together). */
 cl_status cl_debug_qual_pack(const uint8_t *qual, uint64_t n, uint8_t min_base_quality, int level, uint64_t *words_out,
                              uint64_t *sum_out);
 /* A context WITHOUT a device, for the CPU test suite only: cl_contig_begin / cl_push_reads (pass-bit form) stage a

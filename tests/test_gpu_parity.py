@@ -1441,3 +1441,11 @@ def test_an_index_outside_its_array_is_an_error_return_not_a_fault(what, form, m
         eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
         got = eng.contig_finish()
     assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
+
+
+@pytest.mark.parametrize("thr", [0, 20, 128, 255])
+def test_quality_packing_on_this_hosts_cpu(thr):
+    """The base-quality test is taken on the host (qual_pack.cpp): scalar, SSE2 and -- where the CPU has it, as the GPU
+    boxes' CPUs do and the build container's does not -- AVX2 must agree bit for bit, sums included."""
+    import test_qual_rows as TQ
+    TQ.test_pass_bits_and_sums_agree_at_every_level(thr)

@@ -41,7 +41,7 @@ def test_pass_bits_and_sums_agree_at_every_level(thr):
         for i in np.flatnonzero(want_bits):
             want_words[i // 64] |= np.uint64(1) << np.uint64(i % 64)
         want_sum = int(q[want_bits].astype(np.int64).sum())
-        for level in (0, 1, 2):
+        for level in (0, 1, 2, 10, 11, 12):
             words, s = pack(q, thr, level)
             assert np.array_equal(words, want_words), (n, level)
             assert s == want_sum, (n, level)
@@ -178,6 +178,8 @@ def test_a_refused_tile_leaves_the_bits_as_they_were():
         with pytest.raises(EngineError):
             st.push_reads(bad_pos, rec.mapq[25:40], rec.cigar_off[25:41], rec.cigar, rec.qual_off[25:41], rec.qual)
         st.push_reads(rec.pos[25:], rec.mapq[25:], rec.cigar_off[25:], rec.cigar, rec.qual_off[25:], rec.qual)
+        with pytest.raises(EngineError):                                          # a refused tile as the last one, too
+            st.push_reads(bad_pos, rec.mapq[25:40], rec.cigar_off[25:41], rec.cigar, rec.qual_off[25:41], rec.qual)
         ng, rows, sum_q = st.pass_rows()
         qc, _ = column_sums(ng, rows, want["extent"])
         assert np.array_equal(qc, want["qc"]) and sum_q == want["summed_baseq"]
@@ -193,3 +195,35 @@ def test_a_window_deeper_than_its_first_buffer_of_groups():
     rec = ContigRecords.from_reads(reads)
     ng = check(rec, 3000, dict(max_depth=0), tiles=[(0, rec.n)])
     assert ng[0] == 75
+
+
+def test_rows_of_gapped_reads_and_every_cigar_shape():
+    """Reads whose span dwarfs their query (long N gaps) keep query-order bits and are walked per window; every other
+    shape is mapped to reference order at push: S / I / H at the start, runs behind D, I and N, '=' / 'X', more than 64
+    operations, reads that end on a window seam, a deletion across a seam, absent and truncated quality strings."""
+    rng = np.random.default_rng(31)
+    shapes = ["5S145M", "3I147M", "2S3I95M50M", "10H140M", "75M2D75M", "60M1I30M4D59M", "40M300N60M50S", "1M1D1M1D148M",
+              "20=5X30=1I10X2D84=", "150S", "4I", "30M5000N30M", "7M1I" * 40, "2M1D" * 70 + "10M", "148M2S", "1S1M1S",
+              "100M70000N100M", "10M2040N10M", "8M3D9M", "64M", "50M9000N1M"]
+    reads = []
+    for i in range(900):
+        cig = shapes[i % len(shapes)]
+        p = int(rng.integers(0, 100_000))
+        if cig == "8M3D9M":
+            p = 2040 + 2048 * int(rng.integers(0, 40))               # the deletion spans a window seam
+        if cig == "64M":
+            p = 2048 * int(rng.integers(1, 40)) - 64                  # ends exactly on a seam
+        from decodingustools_amd.records import cigar_from_string, cigar_query_length
+        ql = cigar_query_length(cigar_from_string(cig))
+        quals = [int(x) for x in rng.choice([5, 19, 20, 35, 255], size=ql)]
+        if i % 7 == 0:
+            quals = quals[:ql // 3]                                   # truncated
+        if i % 31 == 0:
+            quals = None
+        reads.append((p, cig, int(rng.choice([0, 9, 10, 60, 60])), quals))
+    reads.sort(key=lambda r: r[0])
+    rec = ContigRecords.from_reads(reads)
+    L = 190_000
+    for o in (None, dict(min_mapping_quality=0, min_base_quality=0), dict(min_base_quality=36)):
+        check(rec, L, o, seed=3)
+        check(rec, L, o, tiles=[(0, rec.n)])

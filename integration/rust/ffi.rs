@@ -1,6 +1,6 @@
 //! src/callable_loci/ffi.rs -- one declaration per symbol of include/callable_loci.h that the
 //! coverage path uses.  Not compiled in this repository (no Rust toolchain in the image).
-use std::os::raw::{c_char, c_int, c_void};
+use std::os::raw::{c_char, c_int, c_uint, c_void};
 
 #[repr(C)]
 pub struct ClOptions {            // CallableOptions, options.rs:2-9
@@ -37,4 +37,18 @@ extern "C" {
     pub fn cl_contig_finish(ctx: *mut ClCtx, out: *mut ClContigSummary,
                             iv: *mut *const ClInterval, n_iv: *mut usize) -> c_int;
     pub fn cl_contig_abort(ctx: *mut ClCtx) -> c_int;      // error path: cancels an unclaimed prefetch, drops staged reads
+    pub fn cl_contig_layout(ctx: *mut ClCtx, out: *mut ClLayoutInfo) -> c_int;   // what is resident: form, rows, HBM held
+    // include/dut_bam.h: files in, files out, over one or several devices of a node (no collective: one process)
+    pub fn dut_coverage_files_multi(bam: *const c_char, fasta: *const c_char, bed: *const c_char,
+                                    summary_json: *const c_char, summary_html: *const c_char, opt: *const ClOptions,
+                                    contigs: *const *const c_char, n_contigs: usize, devices: *const c_int, n_devices: usize,
+                                    flags: c_uint, err: *mut c_char, err_len: usize) -> c_int;
+}
+
+#[repr(C)] #[derive(Default)]
+pub struct ClLayoutInfo {         // cl_layout_info, include/callable_loci.h
+    pub form: i32, pub counter_planes: u32,
+    pub n_reads: u64, pub n_records: u64, pub n_windows: u64, pub n_qual: u64, pub n_cigar: u64,
+    pub row_groups: u64, pub max_groups: u64, pub run_table_entries: u64,
+    pub device_bytes: u64, pub upload_h2d_bytes: u64,
 }

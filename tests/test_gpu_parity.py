@@ -31,6 +31,7 @@ BYTES_TOO = {
     "test_a_refused_tile_leaves_the_contig_as_it_was", "test_long_reads_in_tiles_with_a_refused_tile_between",
     "test_an_error_behind_a_quality_prefetch_leaves_nothing_in_flight", "test_outlier_spans_do_not_widen_every_window",
 }
+BYTES_TOO.add("test_one_long_indel_rich_read_inside_a_short_read_contig")
 BYTES_ONLY = {"test_run_table_through_small_pinned_buffers", "test_run_table_window_whose_last_piece_belongs_to_the_first_read"}
 
 
@@ -1449,3 +1450,39 @@ def test_quality_packing_on_this_hosts_cpu(thr):
     boxes' CPUs do and the build container's does not -- AVX2 must agree bit for bit, sums included."""
     import test_qual_rows as TQ
     TQ.test_pass_bits_and_sums_agree_at_every_level(thr)
+
+
+def test_one_long_indel_rich_read_inside_a_short_read_contig(tmp_path):
+    """A hybrid contig: 30x of 150-base reads (fewer than 8 operations per read on average: the record forms) and ONE
+    100 kb read with an indel every ~12 bases (some 16 000 operations, wide: it spans 49 windows).  Pass-bit form: the
+    read is one head record and a string of bits like any other; byte form: all its ~8 000 piece records are candidates
+    of every window it spans -- slower there, the same result everywhere."""
+    L = 400_000
+    short = synth.short_read_contig(L, 30, 5150)
+    rng = np.random.default_rng(5151)
+    ops = []
+    total = 0
+    while total < 100_000:
+        m = int(rng.integers(4, 22)); ops.append(f"{m}M"); total += m
+        k = int(rng.integers(1, 4)); ops.append(f"{k}{'ID'[int(rng.integers(0, 2))]}")
+    cig = "".join(ops) + "30M"
+    reads = [(int(short.pos[i]), None) for i in range(short.n)]
+    long_rec = ContigRecords.from_reads([(150_000, cig, 60, 30, 0, "long1")])
+    # merge: the long read goes where its position sorts
+    k = int(np.searchsorted(short.pos, 150_000))
+    def cat(a, b, c):
+        return np.concatenate([a, b, c])
+    co_s, qo_s, no_s = short.cigar_off.astype(np.int64), short.qual_off.astype(np.int64), short.qname_off.astype(np.int64)
+    nc, nq, nn = long_rec.cigar.shape[0], long_rec.qual.shape[0], long_rec.qname.shape[0]
+    rec = ContigRecords(
+        pos=cat(short.pos[:k], long_rec.pos, short.pos[k:]).astype(np.int32), flag=cat(short.flag[:k], long_rec.flag, short.flag[k:]).astype(np.uint16),
+        mapq=cat(short.mapq[:k], long_rec.mapq, short.mapq[k:]).astype(np.uint8),
+        cigar_off=cat(co_s[:k + 1], co_s[k:k + 1] + nc, co_s[k + 1:] + nc).astype(np.uint32),
+        cigar=cat(short.cigar[:co_s[k]], long_rec.cigar, short.cigar[co_s[k]:]).astype(np.uint32),
+        qual_off=cat(qo_s[:k + 1], qo_s[k:k + 1] + nq, qo_s[k + 1:] + nq).astype(np.uint64),
+        qual=cat(short.qual[:qo_s[k]], long_rec.qual, short.qual[qo_s[k]:]).astype(np.uint8),
+        qname_off=cat(no_s[:k + 1], no_s[k:k + 1] + nn, no_s[k + 1:] + nn).astype(np.uint32),
+        qname=cat(short.qname[:no_s[k]], long_rec.qname, short.qname[no_s[k]:]).astype(np.uint8)).validate()
+    assert rec.cigar.shape[0] < 8 * rec.n and rec.n == short.n + 1
+    ref = synth.make_reference(L, 5152)
+    compare([("chrH", 7, L, ref, rec)], dict(), tmp_path, "hybrid", dump=False)

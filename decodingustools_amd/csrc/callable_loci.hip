@@ -1649,7 +1649,7 @@ static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0
                 const bool sparse = (cnt & dut::kRowSparse) != 0ull;
                 uint64_t *dstq;
                 if (sparse) dstq = bits + wat;
-                else { qw.resize(nqw + 1); dstq = qw.data(); dstq[nqw] = 0ull; }
+                else { qw.resize(nqw + 2); dstq = qw.data(); dstq[nqw] = 0ull; dstq[nqw + 1] = 0ull; }   // (two readable words behind the bits: the mapping looks one word ahead of a clamped position)
                 const uint64_t all = dut::qual_pass_read(q, ql, min_bq, dstq, plevel);      // every byte of the string that passes ...
                 um.resize(nops + 1);
                 size_t n_um = 0; unsigned long long qlen = 0;
@@ -1931,7 +1931,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     // forms (pass bits: always; bytes: short reads) read records (built below) and nothing else per read; the run-table
     // form pos, mapq and end of the windows' candidates, and the table that the walk in size_for_extent() builds from the
     // staged CIGARs.  No form reads a CIGAR or an offset array: neither is uploaded.
-    HIP_TRY(c, c->d_end.reserve(n + 1));
+    if (form == 2) HIP_TRY(c, c->d_end.reserve(n + 1));
     if (!c->bits) HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

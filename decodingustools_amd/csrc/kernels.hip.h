@@ -1096,30 +1096,40 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
         }
     }
 
-    // ---- the window's rows: this wave's groups wv, wv + 4, ... into its counter planes ----
+    // ---- the window's rows: this wave's groups wv, wv + 4, ... into its counter planes.  The wave number is taken
+    //      from a scalar register so that the tests on group numbers are scalar branches: a group slot past the window's
+    //      last group costs nothing (the kernel is bound by vector issue), and the loads of a next trip are only issued
+    //      when there is one (more than 16 groups: depth beyond 64) ----
     uint32_t c[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) c[p] = 0u;
     unsigned long long nbits = 0;                          // set bits seen by this lane (-> quality_bases)
     if (ng) {
-        for (uint32_t g0 = wv; g0 < ng; g0 += (uint32_t)kWaves * G) {      // wave-uniform
+        const uint32_t wvs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
+        for (uint32_t g0 = wvs; g0 < ng; g0 += (uint32_t)kWaves * G) {
+            const bool more = g0 + (uint32_t)kWaves * G < ng;
             uint4 nx[G];
+            if (more) {
 #pragma unroll
-            for (int j = 0; j < G; ++j) {                  // the next trip's groups are requested first
-                const uint32_t g = g0 + (uint32_t)kWaves * (G + j);
-                nx[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
+                for (int j = 0; j < G; ++j) {
+                    const uint32_t g = g0 + (uint32_t)kWaves * (G + j);
+                    nx[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
+                }
             }
             uint32_t pc = 0;
 #pragma unroll
             for (int j = 0; j < G; ++j) {
-                const bool in = g0 + (uint32_t)kWaves * j < ng;
-                const uint4 x = in ? rv[j] : make_uint4(0u, 0u, 0u, 0u);
-                bs_add4<NP>(c, x);
-                pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                if (g0 + (uint32_t)kWaves * j < ng) {
+                    const uint4 x = rv[j];
+                    bs_add4<NP>(c, x);
+                    pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
+                }
             }
             nbits += pc;
+            if (more) {
 #pragma unroll
-            for (int j = 0; j < G; ++j) rv[j] = nx[j];
+                for (int j = 0; j < G; ++j) rv[j] = nx[j];
+            }
         }
     }
 #pragma unroll
@@ -1168,6 +1178,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
                 sl += (uint32_t)((int32_t)wl >> 16); vl[2 * h + 1] = sl;
             }
         }
+        // (a thread's sum of differences may be negative: two's complement in 32 bits, so the two scans stay separate)
         const uint32_t ir = dpp_incl_scan_u32(sr), il = dpp_incl_scan_u32(sl);
         if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
         __syncthreads();

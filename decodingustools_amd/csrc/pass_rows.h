@@ -65,7 +65,7 @@ inline void deposit_bits(const uint64_t *src, unsigned long long o, uint32_t n, 
     }
 }
 
-// A read's pass bits from query order (qw: bit k <-> base k, ql bases, one readable word behind them) to reference
+// A read's pass bits from query order (qw: bit k <-> base k, ql bases, TWO readable words behind them) to reference
 // order: rw[0, ceil(span / 64)) is written whole.  What the column walk visits as (alignment, qpos) with !is_del are the
 // bases of M/=/X operations (mod.rs:30-37); a base without a quality byte (k >= ql) never passes.  Written without a
 // branch on the kind of operation (insertions and deletions alternate at random in long reads: a mispredicted branch per

@@ -7,6 +7,8 @@
 #include "../../include/dut_haplogroup.h"
 #include "../../include/dut_report.h"
 #include "../../decodingustools_amd/csrc/host_parallel.h"
+#include "../../decodingustools_amd/csrc/pass_rows.h"
+#include "../../decodingustools_amd/csrc/qual_pack.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -53,9 +55,124 @@ static unsigned long long checksum(const void *p, size_t n)
     return h;
 }
 
+// The host half of the pass-bit form (qual_pack.cpp, pass_rows.h) on random reads with buffers of exactly the documented
+// sizes, so that the sanitizers see every byte it touches: quality bytes -> pass bits (every level) -> reference order
+// through the CIGAR -> rows of one window range; the column sums must be what a per-base walk counts.
+static int pass_bit_selftest()
+{
+    uint64_t state = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&](uint64_t m) { state ^= state << 13; state ^= state >> 7; state ^= state << 17; return state % m; };
+    constexpr uint32_t T = 2048;
+    int bad = 0;
+    for (int round = 0; round < 60; ++round) {
+        const uint8_t thr = (uint8_t)(round % 3 == 0 ? 0 : (round % 3 == 1 ? 20 : 200));
+        const uint32_t n = 40 + (uint32_t)rnd(200);
+        std::vector<int32_t> pos; std::vector<uint32_t> end; std::vector<uint8_t> mapq;
+        std::vector<unsigned long long> off(1, 0ull); std::vector<uint32_t> sc_off(1, 0u), sc;
+        std::vector<uint64_t> bits;
+        std::vector<uint32_t> want(4 * T, 0);                  // qc_depth of positions [0, 4 T)
+        uint32_t p = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            p += (uint32_t)rnd(120);
+            std::vector<uint32_t> cig;
+            const int kind = (int)rnd(5);
+            unsigned long long qlen = 0, span = 0;
+            if (kind == 0) { const uint32_t l = 1 + (uint32_t)rnd(300); cig.push_back(l << 4); }
+            else {
+                if (rnd(3) == 0) cig.push_back(((uint32_t)(1 + rnd(9)) << 4) | 4u);        // S
+                const int nops = 1 + (int)rnd(kind == 4 ? 150 : 12);
+                for (int j = 0; j < nops; ++j) {
+                    cig.push_back(((uint32_t)(1 + rnd(kind == 3 ? 70 : 20)) << 4) | (uint32_t)(rnd(4) == 0 ? 7u : 0u));   // M or =
+                    const uint32_t o = (uint32_t)rnd(kind == 2 ? 6 : 4);
+                    if (o == 0) cig.push_back(((uint32_t)(1 + rnd(3)) << 4) | 1u);           // I
+                    else if (o == 1) cig.push_back(((uint32_t)(1 + rnd(5)) << 4) | 2u);      // D
+                    else if (o >= 4) cig.push_back(((uint32_t)(1500 + rnd(3000)) << 4) | 3u); // N: a gapped (sparse) read
+                }
+                cig.push_back(((uint32_t)(1 + rnd(30)) << 4) | 0u);
+            }
+            for (uint32_t cw : cig) { const uint32_t op = cw & 15u, l = cw >> 4; if ((0x193u >> op) & 1u) qlen += l; if ((0x18Du >> op) & 1u) span += l; }
+            unsigned long long ql = rnd(7) == 0 ? qlen / 2 : qlen;                             // sometimes a truncated quality string
+            if (rnd(23) == 0) ql = 0;
+            std::vector<uint8_t> q((size_t)ql);
+            for (auto &b : q) b = (uint8_t)(rnd(4) == 0 ? rnd(256) : 30 + rnd(12));
+            const uint8_t mq = (uint8_t)(rnd(6) == 0 ? 3 : 60);
+            pos.push_back((int32_t)p); end.push_back(p + (uint32_t)span); mapq.push_back(mq);
+            // what the column walk counts
+            if (mq >= 10 && ql) {
+                unsigned long long x = p, y = 0;
+                for (uint32_t cw : cig) {
+                    const uint32_t op = cw & 15u, l = cw >> 4;
+                    if ((0x181u >> op) & 1u) for (uint32_t k = 0; k < l; ++k) if (y + k < ql && q[(size_t)(y + k)] >= thr && x + k < want.size()) want[(size_t)(x + k)] += 1;
+                    if ((0x18Du >> op) & 1u) x += l;
+                    if ((0x193u >> op) & 1u) y += l;
+                }
+            }
+            // what cl_push_reads leaves (push_reads_bits, second phase), with exact-size buffers
+            unsigned long long o0 = bits.size();
+            if (mq >= 10 && ql && span) {
+                if (cig.size() == 1) {
+                    const uint64_t nb = std::min<uint64_t>(span, ql);
+                    std::vector<uint64_t> w((size_t)((nb + 63) >> 6));
+                    const int level = round % 3;
+                    const uint64_t sm = dut::qual_pass_read(q.data(), nb, thr, w.data(), level);
+                    uint64_t naive = 0; for (uint64_t k = 0; k < nb; ++k) naive += q[(size_t)k] >= thr ? q[(size_t)k] : 0u;
+                    if (sm != naive) ++bad;
+                    bits.insert(bits.end(), w.begin(), w.end());
+                } else {
+                    const uint64_t nqw = (ql + 63) >> 6;
+                    const bool sparse = span > 4 * ql + 1024;
+                    std::vector<uint64_t> qw((size_t)nqw + 2, 0ull);
+                    const uint64_t all = dut::qual_pass_read(q.data(), ql, thr, qw.data(), 2);
+                    std::vector<dut::QueryStretch> um(cig.size() + 1);
+                    size_t n_um = 0; unsigned long long qcl = 0;
+                    if (sparse) {
+                        bits.insert(bits.end(), qw.begin(), qw.begin() + (size_t)nqw);
+                        sc.insert(sc.end(), cig.begin(), cig.end());
+                        o0 |= dut::kRowSparse;
+                    } else {
+                        std::vector<uint64_t> rw((size_t)((span + 63) >> 6));
+                        dut::ref_bits_from_query(qw.data(), ql, cig.data(), (uint32_t)cig.size(), rw.data(), um.data(), &n_um, &qcl);
+                        bits.insert(bits.end(), rw.begin(), rw.end());
+                        const uint64_t un = dut::unmatched_pass_sum(q.data(), ql, um.data(), n_um, qcl, thr);
+                        uint64_t naive = 0; unsigned long long y = 0;
+                        for (uint32_t cw : cig) { const uint32_t op = cw & 15u, l = cw >> 4; if ((0x181u >> op) & 1u) for (uint32_t k = 0; k < l; ++k) if (y + k < ql && q[(size_t)(y + k)] >= thr) naive += q[(size_t)(y + k)]; if ((0x193u >> op) & 1u) y += l; }
+                        if (all - un != naive) ++bad;
+                    }
+                }
+            }
+            off.back() = o0; off.push_back(bits.size());
+            sc_off.push_back((uint32_t)sc.size());
+        }
+        bits.push_back(0ull);                                   // the one word deposit_bits may read behind the last string
+        if (sc.empty()) sc.push_back(0u);
+        dut::RowReads H;
+        H.pos = pos.data(); H.end = end.data(); H.mapq = mapq.data(); H.off = off.data(); H.bits = bits.data();
+        H.sc_off = sc_off.data(); H.sc = sc.data(); H.min_mapq = 10;
+        std::vector<dut::RowCur> act;
+        dut::RowScratch scr;
+        uint32_t next = 0;
+        for (uint32_t w = 0; w < 4; ++w) {
+            const uint32_t W = w * T;
+            while (next < n && (uint32_t)pos[next] < W + T) { dut::rows_enter(act, H, next, W); ++next; }
+            size_t cap = 2, ng;
+            std::vector<dut::RowCur> start = act;
+            std::vector<uint32_t> buf;
+            for (;;) { buf.assign(cap * dut::kRowGroupWords, 0xFFFFFFFFu); act = start; ng = dut::rows_window<T>(act, H, W, buf.data(), cap, scr); if (ng != SIZE_MAX) break; cap *= 2; }
+            for (uint32_t x = 0; x < T; ++x) {
+                uint32_t cnt = 0;
+                for (size_t r = 0; r < 4 * ng; ++r) cnt += (buf[(r >> 2) * dut::kRowGroupWords + ((x >> 5) << 2) + (r & 3)] >> (x & 31u)) & 1u;
+                if (cnt != want[W + x]) ++bad;
+            }
+        }
+    }
+    printf("pass-bit selftest: %d mismatch(es)\n", bad);
+    return bad;
+}
+
 int main(int argc, char **argv)
 {
     if (argc < 2) { fprintf(stderr, "usage: sanitize_host <bam> [tree.json]\n"); return 2; }
+    if (pass_bit_selftest() != 0) return 5;
     char err[512] = {0};
     // BAM reader: every contig, with and without sequences, twice (buffer reuse), in reverse order too
     dut_bam *b = dut_bam_open(argv[1], err, sizeof(err));

@@ -13,7 +13,7 @@ from bamio import write_bam, write_fasta
 from decodingustools_amd import synth
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = [os.path.join(ROOT, "decodingustools_amd", "csrc", f) for f in ("bam_io.cpp", "host_coverage.cpp", "report.cpp", "haplogroup.cpp")]
+SRC = [os.path.join(ROOT, "decodingustools_amd", "csrc", f) for f in ("bam_io.cpp", "host_coverage.cpp", "report.cpp", "haplogroup.cpp", "qual_pack.cpp")]
 DRIVER = os.path.join(ROOT, "tests", "native", "sanitize_host.cpp")
 
 
@@ -69,6 +69,7 @@ def test_host_code_under_sanitizers(tmp_path, tag, flags, envvar):
         assert len(o) == 1, bam                                         # the thread count never changes the result
     # the several-"device" call over the stand-in engine (one thread, reader pair and context per device): same BED text
     good = next(iter(outs[bams[0]]))
+    assert "pass-bit selftest: 0 mismatch(es)" in good                 # the host half of the pass-bit form under the sanitizers
     assert good.count("bytes same") == 3 and "DIFFERENT" not in good and "a device that does not exist: rc -2" in good, good[-800:]
     # the same records whatever the block layout / index
     body = lambda s: [ln.split(" admit")[0] for ln in s.splitlines() if ln.startswith("tid")]

@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
     if (w >= a.n_win) return;
     const uint32_t tid = threadIdx.x;
     const uint32_t W = w * (uint32_t)T;
-    const uint32_t lane = tid & 63u, wv = tid >> 6;
+    // (the wave number from a scalar register: whatever is indexed or bounded by it below is scalar code)
+    const uint32_t lane = tid & 63u, wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const uint32_t p0 = W + tid * PER;
 
     const WinMeta wm = a.win[w];
@@ -1105,8 +1106,7 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
     for (int p = 0; p < NP; ++p) c[p] = 0u;
     unsigned long long nbits = 0;                          // set bits seen by this lane (-> quality_bases)
     if (ng) {
-        const uint32_t wvs = (uint32_t)__builtin_amdgcn_readfirstlane((int)wv);
-        for (uint32_t g0 = wvs; g0 < ng; g0 += (uint32_t)kWaves * G) {
+        for (uint32_t g0 = wv; g0 < ng; g0 += (uint32_t)kWaves * G) {
             const bool more = g0 + (uint32_t)kWaves * G < ng;
             uint4 nx[G];
             if (more) {

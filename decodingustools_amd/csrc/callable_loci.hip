@@ -1270,7 +1270,7 @@ template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
     // serves every threshold now and only ORF = true is instantiated)
 #define CL_LAUNCH(DEEP_, LONG_) hipLaunchKernelGGL((k_pileup<(int)kT, DEBUG, true, DEEP_, LONG_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
 #define CL_LAUNCH_L(DEEP_) do { if (c->form == 2) CL_LAUNCH(DEEP_, 2); else CL_LAUNCH(DEEP_, 0); } while (0)
-#define CL_LAUNCH_R(DEEP_, NP_) hipLaunchKernelGGL((k_pileup_rows<(int)kT, DEBUG, DEEP_, NP_>), dim3(grid), dim3(kBlock), 0, c->stream, a)
+#define CL_LAUNCH_R(DEEP_, NP_) hipLaunchKernelGGL((k_pileup_rows<(int)kT, DEBUG, DEEP_, NP_, CL_ROWS_BLOCK>), dim3(grid), dim3(CL_ROWS_BLOCK), 0, c->stream, a)
 #define CL_LAUNCH_RN(DEEP_) do { if (c->max_groups <= 63u) CL_LAUNCH_R(DEEP_, 8); else if (c->max_groups <= 16383u) CL_LAUNCH_R(DEEP_, 16); else CL_LAUNCH_R(DEEP_, 32); } while (0)
     // the 32-bit counter variant is used only when the window bounds asked for it (kNeedDeep)
     if (c->form == 3) {

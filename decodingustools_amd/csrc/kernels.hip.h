@@ -991,15 +991,21 @@ __device__ __forceinline__ uint32_t bs_less_than(const uint32_t (&c)[NP], unsign
     return lt;
 }
 
-template <int T, bool DEBUG, bool DEEP, int NP>
-__global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_rows(PileupArgs a)
+// BS: threads per workgroup -- 256 (8 positions per thread in the final phase, 4 waves) or 128 (16 positions, 2 waves:
+// what a wave does once per window -- scans, reductions, the planes' hand-over -- is done half as often)
+#ifndef CL_ROWS_BLOCK
+#define CL_ROWS_BLOCK 128
+#endif
+template <int T, bool DEBUG, bool DEEP, int NP, int BS>
+__global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS == 128 ? 6 : 8)) void k_pileup_rows(PileupArgs a)
 {
+    constexpr int kBlock = BS;                             // (shadows the namespace's 256 inside this kernel)
     constexpr int PER = T / kBlock;
-    static_assert(PER == 8 && T == 2048, "a lane owns a block of 32 positions: T = 64 x 32");
+    static_assert((PER == 8 || PER == 16) && T == 2048, "a lane owns a block of 32 positions: T = 64 x 32");
     constexpr int kWaves = kBlock / 64;
     constexpr uint32_t kLutLds = 256;
     constexpr int kDiffWords = DEEP ? T : T / 2;
-    constexpr int G = 4;                                   // groups a wave keeps in flight
+    constexpr int G = BS == 128 ? 6 : 4;                   // groups a wave has in flight: 12 / 16 per window before a second trip
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_low[kDiffWords];
     __shared__ uint32_t s_pl[kWaves][NP][64];              // the waves' counter planes
@@ -1043,9 +1049,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
         uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low);
         const uint4 zb = DEEP ? z : make_uint4(0x8000u, 0x8000u, 0x8000u, 0x8000u);
         for (int i = tid; i < kDiffWords / 4; i += kBlock) { r4[i] = zb; l4[i] = zb; }
-        if (tid < kLutLds) {
-            const uint32_t v = (tid >= a.o.min_depth_for_low_mapq && tid > 0) ? a.lut[tid] : 0xFFFFFFFFu;
-            s_lut[tid] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v;
+        for (uint32_t i = tid; i < kLutLds; i += kBlock) {
+            const uint32_t v = (i >= a.o.min_depth_for_low_mapq && i > 0) ? a.lut[i] : 0xFFFFFFFFu;
+            s_lut[i] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v;
         }
     }
     __syncthreads();
@@ -1107,15 +1113,6 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
     unsigned long long nbits = 0;                          // set bits seen by this lane (-> quality_bases)
     if (ng) {
         for (uint32_t g0 = wv; g0 < ng; g0 += (uint32_t)kWaves * G) {
-            const bool more = g0 + (uint32_t)kWaves * G < ng;
-            uint4 nx[G];
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < G; ++j) {
-                    const uint32_t g = g0 + (uint32_t)kWaves * (G + j);
-                    nx[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
-                }
-            }
             uint32_t pc = 0;
 #pragma unroll
             for (int j = 0; j < G; ++j) {
@@ -1126,9 +1123,12 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
                 }
             }
             nbits += pc;
-            if (more) {
+            if (g0 + (uint32_t)kWaves * G < ng) {          // a deeper window: the next trip's groups (requested only now)
 #pragma unroll
-                for (int j = 0; j < G; ++j) rv[j] = nx[j];
+                for (int j = 0; j < G; ++j) {
+                    const uint32_t g = g0 + (uint32_t)kWaves * (G + j);
+                    rv[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
+                }
             }
         }
     }
@@ -1188,9 +1188,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
 #pragma unroll
         for (int i = 0; i < PER; ++i) { vr[i] += offr; vl[i] += offl; mx = vr[i] > mx ? vr[i] : mx; }
         const uint32_t n_ok = p0 >= a.extent ? 0u : (a.extent - p0 < (uint32_t)PER ? a.extent - p0 : (uint32_t)PER);
-        // this thread's 8 positions are byte (tid & 3) of block tid >> 2
-        const uint32_t lt8 = (s_lt[tid >> 2] >> (8u * (tid & 3u))) & 0xFFu;
-        const uint32_t gt8 = (s_gt[tid >> 2] >> (8u * (tid & 3u))) & 0xFFu;
+        // this thread's PER positions are PER consecutive bits of block (tid * PER) >> 5
+        const uint32_t lt8 = (s_lt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & ((1u << PER) - 1u);
+        const uint32_t gt8 = (s_gt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & ((1u << PER) - 1u);
 
         uint32_t S[PER / 4];
         uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, ncov = 0;
@@ -1251,9 +1251,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 uint32_t qc = 0;
-                const uint32_t bit = 8u * (tid & 3u) + (uint32_t)i;
+                const uint32_t bit = ((tid * PER) & 31u) + (uint32_t)i;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) qc |= ((s_pl[0][p][tid >> 2] >> bit) & 1u) << p;
+                for (int p = 0; p < NP; ++p) qc |= ((s_pl[0][p][(tid * PER) >> 5] >> bit) & 1u) << p;
                 if (a.dbg_raw) a.dbg_raw[p0 + i] = vr[i];
                 if (a.dbg_low) a.dbg_low[p0 + i] = vl[i];
                 if (a.dbg_qc) a.dbg_qc[p0 + i] = qc;
@@ -1270,7 +1270,9 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
             uint32_t prevb = tid > 0 ? (uint32_t)s_last[tid - 1] : (S[0] & 0xFFu);
             // 0x01 for the positions < extent
             const uint32_t okb = (1u << n_ok) - 1u;
-            const uint32_t okw[2] = {__umul24(okb & 15u, 0x204081u) & 0x01010101u, __umul24((okb >> 4) & 15u, 0x204081u) & 0x01010101u};
+            uint32_t okw[PER / 4];
+#pragma unroll
+            for (int h = 0; h < PER / 4; ++h) okw[h] = __umul24((okb >> (4 * h)) & 15u, 0x204081u) & 0x01010101u;
 #pragma unroll
             for (int h = 0; h < PER / 4; ++h) {
                 const uint32_t P = (S[h] << 8) | prevb;
@@ -1285,21 +1287,40 @@ __global__ __launch_bounds__(kBlock, (DEEP || NP > 8) ? 4 : 8) void k_pileup_row
             for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
         }
         if (!DEEP && NP == 8) {
-            // a thread's counts are <= 8, every wave total <= 512: packed words, one butterfly reduction each; the
-            // wave's set bits are < 2^18 (16 groups of 4 rows x 2048 bits)
-            uint32_t pk[4];
-            pk[0] = cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
-            pk[1] = cnt[3] | (cnt[4] << 10) | (cnt[5] << 20);
-            pk[2] = ncov | (nb << 10);
-            pk[3] = (uint32_t)nbits;
+            // a thread's counts are <= PER and every wave total <= 64 PER: packed words, one butterfly reduction each --
+            // three 10-bit fields per word for 8 positions per thread (totals <= 512), two 11-bit fields for 16 (<= 1024);
+            // the wave's set bits are < 2^19 (32 groups of 4 rows x 2048 bits)
+            constexpr int NW = PER == 8 ? 4 : 5;
+            uint32_t pk[NW];
+            if (PER == 8) {
+                pk[0] = cnt[0] | (cnt[1] << 10) | (cnt[2] << 20);
+                pk[1] = cnt[3] | (cnt[4] << 10) | (cnt[5] << 20);
+                pk[2] = ncov | (nb << 10);
+                pk[3] = (uint32_t)nbits;
+            } else {
+                pk[0] = cnt[0] | (cnt[1] << 11);
+                pk[1] = cnt[2] | (cnt[3] << 11);
+                pk[2] = cnt[4] | (cnt[5] << 11);
+                pk[3] = ncov | (nb << 11);
+                pk[NW - 1] = (uint32_t)nbits;
+            }
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pk[q] = dpp_wave_sum_u32(pk[q]);
+            for (int q = 0; q < NW; ++q) pk[q] = dpp_wave_sum_u32(pk[q]);
             if (lane == 0) {
                 unsigned long long *t = s_wtot[wv];
-                t[0] = pk[0] & 1023u; t[1] = (pk[0] >> 10) & 1023u; t[2] = pk[0] >> 20;
-                t[3] = pk[1] & 1023u; t[4] = (pk[1] >> 10) & 1023u; t[5] = pk[1] >> 20;
-                t[6] = pk[2] & 1023u; t[9] = pk[2] >> 10;
-                t[7] = pk[3]; t[8] = 0;
+                if (PER == 8) {
+                    t[0] = pk[0] & 1023u; t[1] = (pk[0] >> 10) & 1023u; t[2] = pk[0] >> 20;
+                    t[3] = pk[1] & 1023u; t[4] = (pk[1] >> 10) & 1023u; t[5] = pk[1] >> 20;
+                    t[6] = pk[2] & 1023u; t[9] = pk[2] >> 10;
+                    t[7] = pk[3];
+                } else {
+                    t[0] = pk[0] & 2047u; t[1] = pk[0] >> 11;
+                    t[2] = pk[1] & 2047u; t[3] = pk[1] >> 11;
+                    t[4] = pk[2] & 2047u; t[5] = pk[2] >> 11;
+                    t[6] = pk[3] & 2047u; t[9] = pk[3] >> 11;
+                    t[7] = pk[NW - 1];
+                }
+                t[8] = 0;
                 t[10] = win_len; t[11] = win_mq;
             }
         } else {

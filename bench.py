@@ -812,7 +812,12 @@ def run_chr21(args, rank, world, dev_id, torch, dist, coll_dev):
             tr, why = measure_traffic(cache_dir)
             if tr is not None:
                 def rows_key(length):
-                    return "k_pileup_rows@" + str(((((length + 2047) // 2048) + 7) // 8) * 8 * 256)
+                    # Grid_Size counts work-items: windows rounded up to a multiple of 8, times the threads per window
+                    wins = ((((length + 2047) // 2048) + 7) // 8) * 8
+                    for bs in (128, 256):
+                        if "k_pileup_rows@" + str(wins * bs) in tr:
+                            return "k_pileup_rows@" + str(wins * bs)
+                    return None
                 k0 = tr.get(rows_key(L)) or tr.get("k_pileup_form0")
                 if k0:
                     out["roofline"]["traffic"] = k0["bytes"]

@@ -25,6 +25,12 @@ class cl_read_tile(C.Structure):
                 ("qual_off", C.c_void_p), ("qual", C.c_void_p)]
 
 
+class cl_read_tile_bits(C.Structure):
+    _fields_ = [("n_reads", C.c_uint64), ("pos", C.c_void_p), ("mapq", C.c_void_p),
+                ("cigar_off", C.c_void_p), ("cigar", C.c_void_p),
+                ("qual_off", C.c_void_p), ("pass_bits", C.c_void_p), ("pass_sum", C.c_void_p)]
+
+
 class cl_contig_summary(C.Structure):
     _fields_ = [("state_counts", C.c_uint64 * 6), ("n_covered_bases", C.c_uint64),
                 ("summed_coverage", C.c_uint64), ("summed_baseq", C.c_uint64),
@@ -53,7 +59,8 @@ class cl_site_tile(C.Structure):
 class dut_records(C.Structure):
     _fields_ = [("n", C.c_uint64), ("pos", C.c_void_p), ("flag", C.c_void_p), ("mapq", C.c_void_p),
                 ("cigar_off", C.c_void_p), ("cigar", C.c_void_p), ("qual_off", C.c_void_p),
-                ("qual", C.c_void_p), ("qname_off", C.c_void_p), ("qname", C.c_void_p)]
+                ("qual", C.c_void_p), ("qname_off", C.c_void_p), ("qname", C.c_void_p),
+                ("pass_bits", C.c_void_p), ("pass_sum", C.c_void_p)]
 
 
 class dut_contig_stats(C.Structure):
@@ -108,6 +115,7 @@ SYMBOLS = [
     ("cl_contig_reserve", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64]),
     ("cl_contig_prefetch_qual", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64]),
     ("cl_push_reads", C.c_int, [C.c_void_p, C.POINTER(cl_read_tile)]),
+    ("cl_push_reads_bits", C.c_int, [C.c_void_p, C.POINTER(cl_read_tile_bits)]),
     ("cl_contig_finish", C.c_int, [C.c_void_p, C.POINTER(cl_contig_summary),
                                    C.POINTER(C.POINTER(cl_interval)), C.POINTER(C.c_size_t)]),
     ("cl_contig_abort", C.c_int, [C.c_void_p]),
@@ -122,6 +130,7 @@ SYMBOLS = [
     ("cl_reset_kernel_ms", C.c_int, [C.c_void_p]),
     ("cl_contig_bytes", C.c_int, [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("cl_contig_layout", C.c_int, [C.c_void_p, C.POINTER(cl_layout_info)]),
+    ("cl_debug_ref_n_bits", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]),
     ("cl_debug_qual_pack", C.c_int, [C.c_void_p, C.c_uint64, C.c_uint8, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]),
     ("cl_debug_host_create", C.c_int, [C.POINTER(cl_options), C.POINTER(C.c_void_p)]),
     ("cl_debug_pass_rows", C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64),
@@ -168,6 +177,7 @@ SYMBOLS = [
     ("dut_bam_ref_mapped", C.c_int64, [C.c_void_p, C.c_int]),
     ("dut_bam_read_contig", C.c_int, [C.c_void_p, C.c_int, C.POINTER(dut_records), C.POINTER(C.c_void_p),
                                       C.POINTER(C.c_void_p)]),
+    ("dut_bam_read_contig_bits", C.c_int, [C.c_void_p, C.c_int, C.c_uint8, C.POINTER(dut_records)]),
     ("dut_fasta_open", C.c_void_p, [C.c_char_p, C.c_char_p, C.c_size_t]),
     ("dut_fasta_close", None, [C.c_void_p]),
     ("dut_fasta_fetch", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]),

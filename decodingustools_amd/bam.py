@@ -55,6 +55,23 @@ class BamReader:
             rec.seq4 = _arr(sq.value, (int(rec.seq_off[-1]) + 1) // 2, np.uint8)
         return rec.validate()
 
+    def fetch_contig_bits(self, tid: int, min_base_quality: int):
+        """dut_bam_read_contig_bits: the records with the base-quality test taken at parse -> (ContigRecords without
+        quality bytes, pass_bits uint64, pass_sum uint32)."""
+        r = _lib.dut_records()
+        st = self._lib.dut_bam_read_contig_bits(self._h, tid, min_base_quality, C.byref(r))
+        if st != 0:
+            raise EngineError(st, self._lib.dut_bam_error(self._h).decode())
+        n = int(r.n)
+        coff = _arr(r.cigar_off, n + 1, np.uint32); qoff = _arr(r.qual_off, n + 1, np.uint64)
+        noff = _arr(r.qname_off, n + 1, np.uint32)
+        rec = ContigRecords(
+            pos=_arr(r.pos, n, np.int32), flag=_arr(r.flag, n, np.uint16), mapq=_arr(r.mapq, n, np.uint8),
+            cigar_off=coff, cigar=_arr(r.cigar, int(coff[-1]), np.uint32), qual_off=qoff,
+            qual=np.zeros(0, np.uint8), qname_off=noff, qname=_arr(r.qname, int(noff[-1]), np.uint8))
+        bits = _arr(r.pass_bits, (int(qoff[-1]) + 63) // 64 + 1, np.uint64)
+        return rec, bits, _arr(r.pass_sum, n, np.uint32)
+
     def close(self):
         if self._h:
             self._lib.dut_bam_close(self._h)

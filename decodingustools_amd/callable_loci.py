@@ -128,6 +128,17 @@ class Engine:
         t.pos, t.mapq, t.cigar_off, t.cigar, t.qual_off, t.qual = [_ptr(a) for a in arrs]
         self._check(self._lib.cl_push_reads(self._h, C.byref(t)))
 
+    def push_reads_bits(self, pos, mapq, cigar_off, cigar, qual_off, pass_bits, pass_sum):
+        """cl_push_reads_bits: the packed pass-bitmask variant (the caller has taken the base-quality test)."""
+        t = _lib.cl_read_tile_bits()
+        arrs = [np.ascontiguousarray(pos, np.int32), np.ascontiguousarray(mapq, np.uint8),
+                np.ascontiguousarray(cigar_off, np.uint32), np.ascontiguousarray(cigar, np.uint32),
+                np.ascontiguousarray(qual_off, np.uint64), np.ascontiguousarray(pass_bits, np.uint64),
+                np.ascontiguousarray(pass_sum, np.uint32)]
+        t.n_reads = arrs[0].shape[0]
+        t.pos, t.mapq, t.cigar_off, t.cigar, t.qual_off, t.pass_bits, t.pass_sum = [_ptr(a) for a in arrs]
+        self._check(self._lib.cl_push_reads_bits(self._h, C.byref(t)))
+
     def contig_abort(self):
         self._check(self._lib.cl_contig_abort(self._h))
 

@@ -4,6 +4,7 @@
 #include "../../include/dut_bam.h"
 #include "../../include/dut_report.h"
 #include "host_parallel.h"
+#include "qual_pack.h"
 
 #include <dlfcn.h>
 #include <unistd.h>
@@ -356,6 +357,9 @@ struct dut_bam {
     RawBuf<uint8_t> mapq, qual, qname, seq4;
     RawBuf<uint32_t> cigar_off, cigar, qname_off;
     RawBuf<uint64_t> qual_off, seq_off;
+    // dut_bam_read_contig_bits: the base-quality test taken at parse (one bit per base) and the reads' sums
+    RawBuf<uint64_t> qbits;
+    RawBuf<uint32_t> qsum;
 };
 
 namespace {
@@ -509,9 +513,16 @@ int64_t dut_bam_ref_mapped(const dut_bam *b, int tid)
     return (b && b->has_index && tid >= 0 && (size_t)tid < b->ref_mapped.size()) ? b->ref_mapped[tid] : -1;
 }
 
-static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4)
+// bits_thr >= 0: the packed variant -- instead of copying a record's quality bytes the parser tests them against
+// min_base_quality = bits_thr (mod.rs:33) while they are in the cache, leaves one bit per base (bit d_qual + k of qbits)
+// and the sum of the passing values over the bases of the record's M/=/X operations (contig_profiler.rs:65-70)
+static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4, int bits_thr = -1)
 {
     if (!b || !out || tid < 0 || (size_t)tid >= b->refs.size()) return CL_ERR_INVALID;
+    const bool want_bits = bits_thr >= 0;
+    const uint8_t thr = (uint8_t)(want_bits ? bits_thr : 0);
+    const int plevel = dut::qual_pack_level();
+    b->qbits.clear(); b->qsum.clear();
     b->err.clear();
     b->pos.clear(); b->flag.clear(); b->mapq.clear(); b->qual.clear(); b->qname.clear(); b->cigar.clear(); b->seq4.clear();
     b->cigar_off.clear(); b->qname_off.clear(); b->qual_off.clear(); b->seq_off.clear();
@@ -565,14 +576,23 @@ static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const
     uint32_t *d_coff = nullptr, *d_cig = nullptr, *d_noff = nullptr;
     uint64_t *d_qoff = nullptr, *d_soff = nullptr;
     uint8_t *d_qual = nullptr, *d_name = nullptr, *d_seq = nullptr;
+    uint64_t *d_qbits = nullptr; uint32_t *d_qsum = nullptr;
     // room for the totals so far; the destination pointers are refreshed (the buffers may move)
     auto make_room = [&]() -> bool {
         const size_t seq_bytes_old = b->seq4.n, seq_bytes_new = want_seq ? (size_t)((n_bases + 1) / 2) : 0;
         if (!b->pos.reserve(n) || !b->flag.reserve(n) || !b->mapq.reserve(n) || !b->cigar_off.reserve(n + 1) || !b->qual_off.reserve(n + 1) ||
-            !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) || !b->cigar.reserve(n_cig) || !b->qual.reserve(n_qual) ||
+            !b->qname_off.reserve(n + 1) || !b->seq_off.reserve(n + 1) || !b->cigar.reserve(n_cig) || !b->qual.reserve(want_bits ? 1 : n_qual) ||
             !b->qname.reserve(n_name) || !b->seq4.reserve(seq_bytes_new + 1)) { b->err = "out of memory"; return false; }
         if (want_seq && seq_bytes_new > seq_bytes_old) memset(b->seq4.p + seq_bytes_old, 0, seq_bytes_new - seq_bytes_old);
         b->seq4.n = seq_bytes_new;
+        if (want_bits) {
+            // the bit array grows zeroed (records OR their bits in, the words at record seams from two threads)
+            const size_t words_old = b->qbits.n, words_new = (size_t)((n_qual + 63) >> 6) + 2;
+            if (!b->qbits.reserve(words_new) || !b->qsum.reserve(n + 1)) { b->err = "out of memory"; return false; }
+            if (words_new > words_old) memset(b->qbits.p + words_old, 0, (words_new - words_old) * sizeof(uint64_t));
+            b->qbits.n = words_new;
+            d_qbits = b->qbits.p; d_qsum = b->qsum.p;
+        }
         d_pos = b->pos.p; d_flag = b->flag.p; d_mapq = b->mapq.p;
         d_coff = b->cigar_off.p; d_cig = b->cigar.p; d_noff = b->qname_off.p;
         d_qoff = b->qual_off.p; d_soff = b->seq_off.p;
@@ -588,7 +608,39 @@ static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const
         memcpy(d_cig + x.d_cig, r + x.cig_off, 4ull * x.n_cigar);
         memcpy(d_name + x.d_name, r + 32, x.l_name);
         const uint8_t *pk = r + 32 + x.l_name + 1 + 4ull * rd16(r + 12);
-        memcpy(d_qual + x.d_qual, pk + (x.l_seq + 1) / 2, x.l_seq);
+        if (!want_bits) memcpy(d_qual + x.d_qual, pk + (x.l_seq + 1) / 2, x.l_seq);
+        else {
+            // the quality bytes, tested where they lie: pass words (zeros above l_seq) and the sum over the whole string ...
+            static thread_local std::vector<uint64_t> lw;
+            const uint8_t *q = pk + (x.l_seq + 1) / 2;
+            const size_t nw = ((size_t)x.l_seq + 63) >> 6;
+            if (lw.size() < nw + 1) lw.resize(nw + 1);
+            uint64_t total = x.l_seq ? dut::qual_pass_read(q, x.l_seq, thr, lw.data(), plevel) : 0;
+            // ... minus the passing values of inserted / clipped bases and of whatever lies beyond the CIGAR's query length
+            if (total) {
+                const uint8_t *cg = r + x.cig_off;
+                uint64_t y = 0, minus = 0;
+                for (uint32_t j = 0; j < x.n_cigar; ++j) {
+                    const uint32_t cw = rd32(cg + 4ull * j), op = cw & 15u, l = cw >> 4;
+                    if (!((0x193u >> op) & 1u)) continue;
+                    if (!((0x181u >> op) & 1u))
+                        for (uint64_t k = y, e = std::min<uint64_t>(x.l_seq, y + l); k < e; ++k) minus += q[k] >= thr ? q[k] : 0u;
+                    y += l;
+                }
+                for (uint64_t k = y; k < x.l_seq; ++k) minus += q[k] >= thr ? q[k] : 0u;
+                total -= minus;
+            }
+            d_qsum[idx] = (uint32_t)std::min<uint64_t>(total, 0xFFFFFFFFull);
+            const uint64_t B = x.d_qual;
+            const uint32_t sh = (uint32_t)(B & 63ull);
+            uint64_t *dst = d_qbits + (B >> 6);
+            for (size_t k = 0; k < nw; ++k) {
+                const uint64_t v = lw[k];
+                if (!v) continue;
+                __atomic_fetch_or(&dst[k], v << sh, __ATOMIC_RELAXED);
+                if (sh && (v >> (64u - sh))) __atomic_fetch_or(&dst[k + 1], v >> (64u - sh), __ATOMIC_RELAXED);
+            }
+        }
         if (want_seq && x.l_seq) {
             // nibble-continuous store: bytes shared with the neighbouring records are OR-ed atomically
             auto code = [&](uint32_t i) -> uint8_t { return (i & 1u) ? (uint8_t)(pk[i >> 1] & 15u) : (uint8_t)(pk[i >> 1] >> 4); };
@@ -687,7 +739,7 @@ static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const
                 if (last.cut != SIZE_MAX) { st.cur = last.cut; end = true; }
                 else st.cur = last.e;
                 b->pos.n = b->flag.n = b->mapq.n = n;
-                b->cigar.n = n_cig; b->qual.n = n_qual; b->qname.n = n_name;
+                b->cigar.n = n_cig; b->qual.n = want_bits ? 0 : n_qual; b->qname.n = n_name; b->qsum.n = want_bits ? n : 0;
                 t_parse += tnow() - tp0;
                 done_parallel = true;
             }
@@ -725,7 +777,7 @@ static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const
         const RecInfo *ri = recs.data();
         parallel_for(recs.size(), 8192, [&](size_t k) { store(buf + ri[k].off, ri[k], n0 + k); });
         b->pos.n = b->flag.n = b->mapq.n = n;
-        b->cigar.n = n_cig; b->qual.n = n_qual; b->qname.n = n_name;
+        b->cigar.n = n_cig; b->qual.n = want_bits ? 0 : n_qual; b->qname.n = n_name; b->qsum.n = want_bits ? n : 0;
         st.cur = o;
         t_parse += tnow() - tp0;
     }
@@ -740,8 +792,14 @@ static int dut_bam_read_contig_impl(dut_bam *b, int tid, dut_records *out, const
     out->n = n;
     out->pos = b->pos.p; out->flag = b->flag.p; out->mapq = b->mapq.p;
     out->cigar_off = b->cigar_off.p; out->cigar = b->cigar.p;
-    out->qual_off = b->qual_off.p; out->qual = b->qual.p;
+    out->qual_off = b->qual_off.p; out->qual = want_bits ? nullptr : b->qual.p;
     out->qname_off = b->qname_off.p; out->qname = b->qname.p;
+    out->pass_bits = nullptr; out->pass_sum = nullptr;
+    if (want_bits) {
+        if (!b->qbits.reserve(2) || !b->qsum.reserve(1)) { b->err = "out of memory"; return CL_ERR_INVALID; }   // (a contig without records)
+        if (b->qbits.n == 0) { b->qbits.p[0] = b->qbits.p[1] = 0; }
+        out->pass_bits = b->qbits.p; out->pass_sum = b->qsum.p;
+    }
     if (want_seq) { *seq_off = b->seq_off.p; *seq4 = b->seq4.p; }
     return CL_OK;
 }
@@ -750,6 +808,13 @@ int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **
 {
     // no exception leaves the library through the C ABI
     try { return dut_bam_read_contig_impl(b, tid, out, seq_off, seq4); }
+    catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
+    catch (...) { return CL_ERR_INVALID; }
+}
+
+int dut_bam_read_contig_bits(dut_bam *b, int tid, uint8_t min_base_quality, dut_records *out)
+{
+    try { return dut_bam_read_contig_impl(b, tid, out, nullptr, nullptr, (int)min_base_quality); }
     catch (const std::bad_alloc &) { return CL_ERR_NOMEM; }
     catch (...) { return CL_ERR_INVALID; }
 }
@@ -986,6 +1051,11 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
     if (!bam_path || !fasta_path || !bed_path || !opt || !devices || n_devices == 0) { set_err(err, err_len, "null argument"); return CL_ERR_INVALID; }
     const int device_id = devices[0];
     const bool leave = (flags & DUT_FILES_LEAVE_TO_EXIT) != 0;
+    // the engine's default form wants one bit per base (cl_create reads the same variable): the reader then takes the
+    // base-quality test while it parses the records and no quality byte leaves it
+    const char *qf = getenv("DUT_QUAL_FORM");
+    const char *pr = getenv("DUT_PACKED_READER");                   // =0: bytes from the reader, tested in cl_push_reads (for A/B timing)
+    const bool use_bits = !(qf && strcmp(qf, "bytes") == 0) && !(pr && pr[0] == '0');
     char e[512] = {0};
     double tm = io_now();
     dut_bam_stats *bstats = dut_bam_stats_new(10000);                  // api/coverage.rs:56-59
@@ -1071,7 +1141,7 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
                             dut::Thread fb;
                             if (dut_bam_ref_len(db, t) > 0)
                                 fb = dut::spawn_or_run([&]() { frc = dut_fasta_fetch(df, dut_bam_ref_name(db, t), &bases, &blen); });
-                            drc = dut_bam_read_contig(db, t, &rec, nullptr, nullptr);
+                            drc = use_bits ? dut_bam_read_contig_bits(db, t, opt->min_base_quality, &rec) : dut_bam_read_contig(db, t, &rec, nullptr, nullptr);
                             if (fb.joinable()) fb.join();
                             if (drc != CL_OK) { fail_rest(i, drc, std::string("Error processing contig: ") + dut_bam_error(db)); break; }
                             if (frc != CL_OK) { fail_rest(i, frc, std::string("Error processing contig: ") + dut_fasta_error(df)); break; }
@@ -1147,7 +1217,7 @@ static int dut_coverage_files_impl(const char *bam_path, const char *fasta_path,
             dut::Thread fb;
             if (dut_bam_ref_len(s.bam, t) > 0)
                 fb = dut::spawn_or_run([&]() { s.frc = dut_fasta_fetch(s.fa, dut_bam_ref_name(s.bam, t), &s.bases, &s.blen); });
-            s.rc = dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
+            s.rc = use_bits ? dut_bam_read_contig_bits(s.bam, t, opt->min_base_quality, &s.rec) : dut_bam_read_contig(s.bam, t, &s.rec, nullptr, nullptr);
             if (fb.joinable()) fb.join();
         };
         dut::Thread ahead;

@@ -335,6 +335,11 @@ struct cl_ctx {
     RawVec<unsigned long long> h_rb_off;   // n + 1 word offsets into h_qbits (| dut::kRowSparse)
     RawVec<uint32_t> h_sc_off, h_sc; // the CIGARs of the sparse reads (n + 1 offsets)
     uint64_t host_sum_q = 0;         // of the contig being pushed
+    // ... and the reads' other separable sums (contig_profiler.rs:74, 79-82): reference spans of the reads
+    // the pileup holds (-> summed_coverage) and mapq x span over those with mapq >= min_mapping_quality (-> summed_mapq)
+    uint64_t host_sum_cov = 0, host_sum_mapq = 0;
+    uint64_t dev_sum_cov = 0, dev_sum_mapq = 0;   // of the resident contig
+    uint32_t head_span = kHeadSpanMax;   // most positions one head of k_pileup_rows spans (DUT_HEAD_SPAN: a test hook)
     uint64_t host_n_ops = 0;         // CIGAR operations pushed for it (pass-bit form: none is staged; for cl_contig_layout)
     uint64_t dev_sum_q = 0;          // of the resident contig (handed to the summary workgroup of every run)
     bool rec_counted = true;           // false: a tile of long-read shape skipped the count (cl_contig_upload makes up for it if the contig gets the short-read form after all)
@@ -351,6 +356,8 @@ struct cl_ctx {
     DevBuf<uint8_t> d_ref;
     DevBuf<uint32_t> d_end;
     DevBuf<ReadRec> d_rec;           // the records of the short-read form of k_pileup
+    DevBuf<uint2> d_heads;           // pass-bit form: the heads k_pileup_rows reads, {pos, span | low << 31}
+    DevBuf<uint32_t> d_refn;         // pass-bit form: bit p = the reference base at p is 'N' / 'n' or lies beyond the reference
     DevBuf<uint4> d_rows;            // pass-bit form: the windows' rows, groups of 4 rows x 64 blocks (1 KB each)
     uint64_t n_row_groups = 0;
     uint32_t max_groups = 0;         // most groups of any window: picks the number of counter planes of k_pileup_rows
@@ -1163,12 +1170,21 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     HIP_TRY(c, c->d_last_state.reserve(c->n_win + 1));
     HIP_TRY(c, c->d_win_wide.reserve(c->n_win + 1));
     HIP_TRY(c, hipMemsetAsync(c->d_win_wide.p, 0, c->n_win + 1, c->stream));
-    // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80)
-    HIP_TRY(c, c->d_ref.reserve(padded + 16));
+    // reference bytes: [0,ref_len) from the caller, 'N' beyond (mod.rs:79-80).  The pass-bit form needs one bit of a
+    // base -- is it 'N' / 'n' (mod.rs:100-101) --, taken here, where the bytes pass through the host's hands anyway:
+    // 1/8 of the transfer, 1/8 of what every run reads
+    if (c->form == 3) HIP_TRY(c, c->d_refn.reserve(padded / 32 + 4)); else HIP_TRY(c, c->d_ref.reserve(padded + 16));
     {
         const uint8_t *ref = c->h_ref.data();
         const uint64_t nref = std::min<uint64_t>(c->h_ref.size(), padded);
-        cl_status rs = ring_start(c, c->d_ref.p, padded + 16, [ref, nref](uint64_t off, uint64_t len, uint8_t *out) {
+        cl_status rs;
+        if (c->form == 3)
+            rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_refn.p), padded / 8, [ref, nref](uint64_t off, uint64_t len, uint8_t *out) {
+                // (a buffer of the ring is a whole number of 64-bit words: 4 MB, and padded / 8 = 256 bytes per window)
+                const uint64_t p = off * 8;
+                dut::ref_n_words(ref + std::min<uint64_t>(p, nref), p < nref ? nref - p : 0, len / 8, reinterpret_cast<uint64_t *>(out), dut::qual_pack_level());
+            });
+        else rs = ring_start(c, c->d_ref.p, padded + 16, [ref, nref](uint64_t off, uint64_t len, uint8_t *out) {
             const uint64_t have = off < nref ? std::min<uint64_t>(len, nref - off) : 0;
             if (have) memcpy(out, ref + off, have);
             if (have < len) memset(out + have, 'N', len - have);
@@ -1259,7 +1275,8 @@ void launch_rle(cl_ctx *c)
     hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
                        c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
                        c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
-                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu), c->form == 3 ? (unsigned long long)c->dev_sum_q : 0ull);
+                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu), c->form == 3 ? (unsigned long long)c->dev_sum_q : 0ull,
+                       c->form == 3 ? (unsigned long long)c->dev_sum_cov : 0ull, c->form == 3 ? (unsigned long long)c->dev_sum_mapq : 0ull);
 }
 
 template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
@@ -1301,9 +1318,9 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     if (prof) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     PileupArgs a;
     a.R = R; a.o = c->dopt;
- a.rec = c->d_rec.p; a.end = c->d_end.p; a.win = c->d_win.p;
+    a.rec = c->d_rec.p; a.heads = c->d_heads.p; a.end = c->d_end.p; a.win = c->d_win.p;
     a.wide_idx = c->d_wide_idx.p;
-    a.ref = c->d_ref.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
+    a.ref = c->d_ref.p; a.refn = c->d_refn.p; a.lut = c->d_lut.p; a.state = c->d_state.p; a.winpart = c->d_winpart.p;
     a.runs = c->d_runs.p; a.first_state = c->d_first_state.p; a.last_state = c->d_last_state.p;
     if (debug) { HIP_TRY(c, c->d_state.reserve((size_t)c->n_win * kT + 16)); a.state = c->d_state.p; }
     a.extent = c->extent; a.n_win = c->n_win; a.n_win8 = (c->n_win + 7) / 8;
@@ -1355,6 +1372,9 @@ cl_status cl_create(const cl_options *opt, int device_id, void *stream, cl_ctx *
     // records for short reads, the run table for long ones) -- the forms of rounds 1-3, kept selectable so that their
     // measurements stay reproducible.  Default: the pass-bit form (k_pileup_rows).  Read per context.
     { const char *qf = getenv("DUT_QUAL_FORM"); c->bits = !(qf && strcmp(qf, "bytes") == 0); }
+    // DUT_HEAD_SPAN (a test hook): spans beyond this many positions are cut into several heads -- 2^31 - 1 in earnest, which
+    // only a contig of more than 2 Gb can hold; the tests put the seams into ordinary reads
+    { const char *hs = getenv("DUT_HEAD_SPAN"); if (hs) { const unsigned long long v = strtoull(hs, nullptr, 0); if (v >= 1 && v <= kHeadSpanMax) c->head_span = (uint32_t)v; } }
     if (hipSetDevice(device_id) != hipSuccess) { delete c; return CL_ERR_DEVICE; }
     if (stream) { c->stream = (hipStream_t)stream; c->own_stream = false; }
     else {
@@ -1398,7 +1418,7 @@ void cl_destroy(cl_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     tmr.lap("destroy: sync");
     c->d_pos.release(); c->d_mapq.release();
-    c->d_qual.release(); c->d_rows.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release();
+    c->d_qual.release(); c->d_rows.release(); c->d_ref.release(); c->d_end.release(); c->d_rec.release(); c->d_heads.release(); c->d_refn.release();
     c->d_win.release(); c->d_win_off.release(); c->d_state.release();
     c->d_wide_idx.release();
     c->d_runs.release(); c->d_first_state.release(); c->d_last_state.release(); c->d_win_wide.release();
@@ -1437,6 +1457,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->n_long = 0; c->host_err = 0; c->bounds_err = 0;
     c->h_rec_cnt.clear(); c->rec_counted = true;
     c->h_qbits.clear(); c->h_rb_off.clear(); c->h_sc_off.clear(); c->h_sc.clear(); c->host_sum_q = 0; c->host_n_ops = 0;
+    c->host_sum_cov = 0; c->host_sum_mapq = 0;
     c->in_contig = true; c->uploaded = false; c->ran = false; c->has_long = false;
     return CL_OK;
 }
@@ -1515,7 +1536,26 @@ cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, u
 // mapq >= min_mapping_quality that is not a plain match, its pass bits mapped through the CIGAR into REFERENCE order
 // (pass_rows.h): what cl_contig_upload then lays out as rows is a string of bits per read, and no CIGAR is staged at all
 // (but those of reads whose span dwarfs their query: long N gaps).  A refused tile leaves the context as it was.
-static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0, uint64_t q0, uint64_t ncig, uint64_t nq)
+// n bits of `src` from bit offset sb into dst[0, ceil(n / 64)): whole words, zeros above bit n
+static inline void copy_bits_to_words(uint64_t *dst, const uint64_t *src, unsigned long long sb, unsigned long long n)
+{
+    const unsigned long long w0 = sb >> 6;
+    const uint32_t s = (uint32_t)(sb & 63ull);
+    const unsigned long long nw = (n + 63) >> 6;
+    for (unsigned long long w = 0; w < nw; ++w) {
+        const unsigned long long left = n - (w << 6);                    // bits still wanted from here on (>= 1)
+        const uint32_t want = left >= 64ull ? 64u : (uint32_t)left;
+        uint64_t v = src[w0 + w] >> s;
+        if (s + want > 64u) v |= src[w0 + w + 1] << (64u - s);
+        if (want < 64u) v &= (1ull << want) - 1ull;
+        dst[w] = v;
+    }
+}
+
+// (pbits / psum: the packed variant, cl_push_reads_bits -- the caller has taken the base-quality test: bit
+// t->qual_off[i] + k of pbits <-> quality value k of read i, psum[i] the read's share of summed_baseq; t->qual is unused)
+static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0, uint64_t q0, uint64_t ncig, uint64_t nq,
+                                 const uint64_t *pbits = nullptr, const uint32_t *psum = nullptr)
 {
     const uint64_t n = t->n_reads;
     const uint64_t rbase = c->h_pos.size();
@@ -1524,6 +1564,7 @@ static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0
     const size_t nchunk = (n + grain - 1) / grain;
     struct Chunk {
         int bad = 0; uint32_t err = 0, span_n = 0, span_w = 0; uint64_t max_end = 0, sum_q = 0, n_ops = 0, n_words = 0, n_sc = 0;
+        uint64_t sum_cov = 0, sum_mapq = 0;
         std::vector<uint32_t> wide;
     };
     std::vector<Chunk> ch(nchunk);
@@ -1541,6 +1582,7 @@ static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0
     uint32_t *const sc_off = c->h_sc_off.data() + rbase;
     const uint32_t min_mapq = c->opt.min_mapping_quality;
     const uint8_t min_bq = c->opt.min_base_quality;
+    const uint64_t head_span = c->head_span;
     const int plevel = dut::qual_pack_level();
     const uint8_t *const qsrc = t->qual ? t->qual + q0 : nullptr;
     // ---- first: what needs the CIGAR operations only -- validation, ends, how many words of bits every read will leave ----
@@ -1578,10 +1620,15 @@ static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0
             if (sp > kWideSpan) { o.wide.push_back((uint32_t)i); o.span_w = std::max(o.span_w, sp); }
             else o.span_n = std::max(o.span_n, sp);
             const bool in_pileup = h_end[i] != (uint32_t)p;
-            h_rec_cnt[i] = in_pileup ? 1u : 0u;                               // the head record k_pileup_rows reads
+            const uint64_t span = h_end[i] - (uint32_t)p;
+            // the heads k_pileup_rows reads: one, unless the span is beyond what a head holds
+            h_rec_cnt[i] = in_pileup ? (uint32_t)((span + head_span - 1) / head_span) : 0u;
+            // the read's shares of summed_coverage and summed_mapq (contig_profiler.rs:79-82, :74 -- over its columns,
+            // D and N included: SURVEY 8a-7)
+            o.sum_cov += span;
+            if (t->mapq[i] >= min_mapq) o.sum_mapq += (uint64_t)t->mapq[i] * span;
             const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
             if (!in_pileup || !ql || t->mapq[i] < min_mapq) continue;          // in no row (mod.rs:25, :33)
-            const uint64_t span = h_end[i] - (uint32_t)p;
             uint64_t nw;
             if (nops == 1u) nw = (std::min<uint64_t>(span, ql) + 63) >> 6;     // a plain match: its thresholded string as it is
             else if (span > 4 * ql + 1024) {                                   // a span that dwarfs the query: query order + the CIGAR
@@ -1640,9 +1687,25 @@ static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0
             const uint32_t q0i = t->cigar_off[i], nops = t->cigar_off[i + 1] - q0i;
             const uint32_t *cig = t->cigar + q0i;
             const unsigned long long ql = t->qual_off[i + 1] - t->qual_off[i];
-            const uint8_t *q = qsrc + (t->qual_off[i] - q0);
+            const uint8_t *q = qsrc ? qsrc + (t->qual_off[i] - q0) : nullptr;
             const uint64_t span = h_end[i] - (uint32_t)t->pos[i];
-            if (nops == 1u) {
+            if (pbits) {
+                // the packed variant: the bits are there, in query order from bit qual_off[i]
+                const bool sparse = (cnt & dut::kRowSparse) != 0ull;
+                o.sum_q += psum[i];
+                if (nops == 1u) copy_bits_to_words(bits + wat, pbits, t->qual_off[i], std::min<uint64_t>(span, ql));
+                else if (sparse) {
+                    copy_bits_to_words(bits + wat, pbits, t->qual_off[i], ql);
+                    memcpy(scw + sat, cig, (size_t)nops * sizeof(uint32_t));
+                } else {
+                    const uint64_t nqw = (ql + 63) >> 6;
+                    qw.resize(nqw + 2); qw[nqw] = 0ull; qw[nqw + 1] = 0ull;
+                    copy_bits_to_words(qw.data(), pbits, t->qual_off[i], ql);
+                    um.resize(nops + 1);
+                    size_t n_um = 0; unsigned long long qlen = 0;
+                    dut::ref_bits_from_query(qw.data(), ql, cig, nops, bits + wat, um.data(), &n_um, &qlen);
+                }
+            } else if (nops == 1u) {
                 o.sum_q += dut::qual_pass_read(q, std::min<uint64_t>(span, ql), min_bq, bits + wat, plevel);
             } else {
                 const uint64_t nqw = (ql + 63) >> 6;
@@ -1680,6 +1743,7 @@ static cl_status push_reads_bits(cl_ctx *c, const cl_read_tile *t, uint32_t cig0
     // ---- the tile is accepted (nothing below can fail: the capacity is there) ----
     for (const Chunk &o : ch) {
         c->host_err |= o.err; c->host_sum_q += o.sum_q; c->host_n_ops += o.n_ops;
+        c->host_sum_cov += o.sum_cov; c->host_sum_mapq += o.sum_mapq;
         c->span_n = std::max(c->span_n, o.span_n); c->span_w = std::max(c->span_w, o.span_w);
         c->host_max_end = std::max(c->host_max_end, o.max_end);
         for (uint32_t i : o.wide) { c->h_wide_idx.push_back((uint32_t)(rbase + i)); c->h_wide_pos.push_back(t->pos[i]); }
@@ -1906,6 +1970,36 @@ cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t)
     catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
 }
 
+static cl_status cl_push_reads_bits_impl(cl_ctx *c, const cl_read_tile_bits *b)
+{
+    if (!c || !b) return CL_ERR_INVALID;
+    if (!c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_push_reads_bits outside cl_contig_begin .. upload");
+    if (!c->bits) return fail(c, CL_ERR_INVALID, "cl_push_reads_bits: this context runs the byte forms (DUT_QUAL_FORM=bytes), which need the quality bytes: use cl_push_reads");
+    const uint64_t n = b->n_reads;
+    if (n == 0) return CL_OK;
+    if (!b->pos || !b->mapq || !b->cigar_off || !b->qual_off) return fail(c, CL_ERR_INVALID, "null tile array");
+    if (c->h_pos.size() + n >= (1ull << 29)) return fail(c, CL_ERR_RANGE, "more than 2^29 reads in one contig");
+    const uint32_t cig0 = b->cigar_off[0];
+    const uint64_t q0 = b->qual_off[0];
+    if (b->cigar_off[n] < cig0 || b->qual_off[n] < q0) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    const uint64_t ncig = (uint64_t)b->cigar_off[n] - cig0, nq = b->qual_off[n] - q0;
+    if (ncig && !b->cigar) return fail(c, CL_ERR_INVALID, "null cigar array");
+    if (nq && (!b->pass_bits || !b->pass_sum)) return fail(c, CL_ERR_INVALID, "null pass_bits / pass_sum array");
+    if (c->q_dev + nq >= (1ull << 38)) return fail(c, CL_ERR_RANGE, "more than 2^38 quality values in one contig");
+    cl_read_tile t;
+    t.n_reads = n; t.pos = b->pos; t.mapq = b->mapq; t.cigar_off = b->cigar_off; t.cigar = b->cigar; t.qual_off = b->qual_off; t.qual = nullptr;
+    static const uint64_t kNoBits[2] = {0, 0};
+    static const uint32_t kNoSum[1] = {0};
+    return push_reads_bits(c, &t, cig0, q0, ncig, nq, b->pass_bits ? b->pass_bits : kNoBits, b->pass_sum ? b->pass_sum : kNoSum);
+}
+
+cl_status cl_push_reads_bits(cl_ctx *c, const cl_read_tile_bits *b)
+{
+    try { return cl_push_reads_bits_impl(c, b); }
+    catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }
+    catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
+}
+
 
 static cl_status cl_contig_upload_impl(cl_ctx *c)
 {
@@ -1921,7 +2015,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if (fs != CL_OK) return fs;
     }
     c->n_qual = c->q_dev;
-    c->dev_sum_q = c->host_sum_q;
+    c->dev_sum_q = c->host_sum_q; c->dev_sum_cov = c->bits ? c->host_sum_cov : 0; c->dev_sum_mapq = c->bits ? c->host_sum_mapq : 0;
     c->n_wide = (uint32_t)c->h_wide_idx.size();
     const size_t n = c->n_reads;
     c->form = pick_form(c);
@@ -1934,8 +2028,9 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     if (form == 2) HIP_TRY(c, c->d_end.reserve(n + 1));
     if (!c->bits) HIP_TRY(c, c->d_qual.grow_keep(c->n_qual + 2 * kQualPad, c->n_qual ? kQualPad + c->n_qual : 0, c->stream));
     HIP_TRY(c, c->d_wide_idx.reserve(c->n_wide + 1));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
     tmr0.lap("upload: device buffers");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    tmr0.lap("upload: stream idle");
     StageTimer tmr;
     // everything goes through the pinned staging ring (pageable vectors -> pinned buffers -> HBM, the fills overlapping
     // the transfers)
@@ -1948,7 +2043,41 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         if ((rs = ring_copy(c, c->d_end.p, c->h_end.data(), n * sizeof(uint32_t))) != CL_OK) return rs;
     }
     c->h_rec_of.clear(); c->h_wide_rec_of.clear(); c->n_rec = 0;
-    if (form != 2) {
+    if (form == 3) {
+        // the heads (kernels.hip.h): 8 bytes per read the pileup holds -- [pos, pos + span) and whether its mapq counts
+        // as low (mod.rs:22-28) --, built straight into the pinned buffers; a span beyond kHeadSpanMax is cut into
+        // several heads (h_rec_cnt, counted by cl_push_reads' walk)
+        if ((rs = build_rec_index(c)) != CL_OK) return rs;
+        tmr.lap("upload: record index");
+        const uint32_t n_rec = c->n_rec;
+        HIP_TRY(c, c->d_heads.reserve((size_t)n_rec + 1));
+        const int32_t *hp = c->h_pos.data(); const uint8_t *hm = c->h_mapq.data(); const uint32_t *he = c->h_end.data();
+        const uint32_t *ro = c->h_rec_of.data();
+        const uint32_t max_low = c->opt.max_low_mapq, hs = c->head_span;
+        rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_heads.p), ((uint64_t)n_rec + 1) * sizeof(uint2),
+                        [hp, hm, he, ro, n, n_rec, max_low, hs](uint64_t off, uint64_t len, uint8_t *out) {
+            uint2 *o = reinterpret_cast<uint2 *>(out);
+            const uint64_t j0 = off / sizeof(uint2), j1 = (off + len) / sizeof(uint2);
+            if (j1 > n_rec) memset(static_cast<void *>(o + (std::max<uint64_t>(n_rec, j0) - j0)), 0, (j1 - std::max<uint64_t>(n_rec, j0)) * sizeof(uint2));   // the padding head
+            if (j0 >= n_rec) return;
+            // the read that holds head j0: the last one whose range starts at or before it
+            size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
+            for (; i < n && ro[i] < j1; ++i) {
+                const uint64_t jb = ro[i], je = ro[i + 1];
+                const uint32_t low = (uint32_t)hm[i] <= max_low ? 0x80000000u : 0u;
+                uint64_t x = (uint32_t)hp[i];
+                const uint64_t e = he[i];
+                for (uint64_t j = jb; j < je; ++j, x += hs) {
+                    if (j < j0 || j >= j1) continue;
+                    const uint64_t sp = std::min<uint64_t>(hs, e - x);
+                    o[j - j0] = make_uint2((uint32_t)x, (uint32_t)sp | low);
+                }
+            }
+        }, rec_chunk_bytes());
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+        tmr.lap("upload: heads built + sent");
+    } else if (form != 2) {
         // the records (kernels.hip.h: ReadRec): the host's walk over the CIGARs, so that the device decodes none --
         // north_star's "CIGAR-expanded ref spans" on the host side of the boundary.  Counted first (the reads' record
         // ranges are what the windows' candidate ranges index), then built straight into the pinned buffers: a buffer
@@ -1962,16 +2091,15 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
         const uint32_t *hc = c->h_cigar_off.data(), *hcig = c->h_cigar.data(); const unsigned long long *hq = c->h_qual_off.data();
         const uint32_t *ro = c->h_rec_of.data();
         const uint32_t min_mapq = c->opt.min_mapping_quality;
-        const bool heads_only = c->bits;
         // byte form: k_pileup loads 16-byte units around a record's run [qoff, qoff + len): within 15 bytes of its ends,
         // which the padding of the quality array covers as long as the run itself lies inside [0, n_qual] -- checked for
         // every record as it is built (CL_ERR_RANGE instead of a launch that would fault)
         std::atomic<bool> rec_oor{false};
         std::atomic<bool> *roor = &rec_oor;
         const unsigned long long nq_all = c->n_qual;
-        const size_t inject_read = (!heads_only && fault_injected("rec")) ? n / 2 : (size_t)-1;
+        const size_t inject_read = fault_injected("rec") ? n / 2 : (size_t)-1;
         rs = ring_start(c, reinterpret_cast<uint8_t *>(c->d_rec.p), ((uint64_t)n_rec + 1) * sizeof(ReadRec),
-                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq, heads_only, roor, nq_all, inject_read](uint64_t off, uint64_t len, uint8_t *out) {
+                        [hp, hm, he, hc, hcig, hq, ro, n, n_rec, min_mapq, roor, nq_all, inject_read](uint64_t off, uint64_t len, uint8_t *out) {
             ReadRec *o = reinterpret_cast<ReadRec *>(out);
             const uint64_t j0 = off / sizeof(ReadRec), j1 = (off + len) / sizeof(ReadRec);
             if (j1 > n_rec) memset(static_cast<void *>(o + (std::max<uint64_t>(n_rec, j0) - j0)), 0, (j1 - std::max<uint64_t>(n_rec, j0)) * sizeof(ReadRec));   // the padding record
@@ -1980,14 +2108,6 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
             size_t i = (size_t)(std::upper_bound(ro, ro + n + 1, (uint32_t)j0) - ro) - 1;
             for (; i < n && ro[i] < j1; ++i) {
                 const uint64_t jb = ro[i];
-                if (heads_only) {
-                    // the read as the pileup holds it, [pos, end) (mod.rs:22-28)
-                    if (ro[i + 1] == jb || jb < j0) continue;
-                    ReadRec r;
-                    r.pos = hp[i]; r.span = he[i] - (uint32_t)hp[i]; r.qual_lo = 0u; r.meta = (uint32_t)hm[i] | 0x100u;
-                    o[jb - j0] = r;
-                    continue;
-                }
                 const unsigned long long q0i = hq[i] + (i == inject_read ? 0x7FFFFFF0ull : 0ull);
                 if (q0i + (hq[i + 1] - hq[i]) > nq_all) roor->store(true, std::memory_order_relaxed);   // (runs lie inside the read's bytes)
                 gen_read_recs(hp[i], he[i], hm[i], min_mapq, hcig + hc[i], hc[i + 1] - hc[i], q0i, hq[i + 1] - hq[i],
@@ -2083,6 +2203,13 @@ cl_status cl_debug_qual_pack(const uint8_t *qual, uint64_t n, uint8_t min_base_q
         if (n & 63ull) words_out[n >> 6] = dut::qual_pass_partial(qual + (n & ~63ull), (uint32_t)(n & 63ull), min_base_quality);
     }
     if (sum_out) *sum_out = dut::qual_pass_sum(qual, n, min_base_quality, level);
+    return CL_OK;
+}
+
+cl_status cl_debug_ref_n_bits(const uint8_t *ref, uint64_t n_bases, uint64_t n_words, int level, uint64_t *words_out)
+{
+    if ((n_bases && !ref) || (n_words && !words_out) || level < 0 || level > 2) return CL_ERR_INVALID;
+    dut::ref_n_words(ref, n_bases, n_words, words_out, level);
     return CL_OK;
 }
 
@@ -2274,7 +2401,7 @@ cl_status cl_contig_abort(cl_ctx *c)
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();
     c->h_end.clear(); c->h_ck_x.clear(); c->h_ck_y.clear(); c->h_qual.clear(); c->h_qbits.clear(); c->h_rec_cnt.clear();
     c->h_rb_off.clear(); c->h_sc_off.clear(); c->h_sc.clear();
-    c->q_dev = 0; c->host_sum_q = 0; c->host_n_ops = 0;
+    c->q_dev = 0; c->host_sum_q = 0; c->host_n_ops = 0; c->host_sum_cov = 0; c->host_sum_mapq = 0;
     c->in_contig = false; c->uploaded = false; c->ran = false;
     return CL_OK;
 }
@@ -2320,12 +2447,12 @@ cl_status cl_contig_bytes(cl_ctx *c, uint64_t *input_bytes, uint64_t *output_byt
     // What one run of the resident form must read at least once, counted strictly: the array elements the form's kernel
     // addresses, nothing it does not (no CIGAR word: none is resident in any form), and what it must write: the intervals
     // (12 bytes each; the per-position counters and states never reach HBM).
-    //   every form   reference bytes (extent) + one 32-byte window record per window
-    //   pass bits    the rows (1 KB per group of 4 rows) + a 16-byte head record per read with a span + the wide list
+    //   every form   reference bytes (extent; pass bits: one bit per position) + one 32-byte window record per window
+    //   pass bits    the rows (1 KB per group of 4 rows) + an 8-byte head per read with a span + the wide list
     //   bytes, 0     the quality bytes + the 16-byte records (heads and pieces) + the wide list
     //   bytes, 2     the quality bytes + 8 bytes per piece of the run table + pos 4, end 4, mapq 1 per read + the wide list
-    uint64_t in = (uint64_t)c->extent + (uint64_t)c->n_win * sizeof(WinMeta);
-    if (c->form == 3) in += c->n_row_groups * (uint64_t)(dut::kRowGroupWords * sizeof(uint32_t)) + (uint64_t)c->n_rec * sizeof(ReadRec) + (uint64_t)c->n_wide * 4;
+    uint64_t in = (c->form == 3 ? ((uint64_t)c->extent + 7) / 8 : (uint64_t)c->extent) + (uint64_t)c->n_win * sizeof(WinMeta);
+    if (c->form == 3) in += c->n_row_groups * (uint64_t)(dut::kRowGroupWords * sizeof(uint32_t)) + (uint64_t)c->n_rec * sizeof(uint2) + (uint64_t)c->n_wide * 4;
     else if (c->form == 0) in += c->n_qual + (uint64_t)c->n_rec * sizeof(ReadRec) + (uint64_t)c->n_wide * 4;
     else in += c->n_qual + c->n_runtab * 8 + (uint64_t)c->n_reads * 9 + (uint64_t)c->n_wide * 4;
     if (input_bytes) *input_bytes = in;
@@ -2345,7 +2472,7 @@ cl_status cl_contig_layout(cl_ctx *c, cl_layout_info *out)
     out->counter_planes = c->form == 3 ? (c->max_groups <= 63u ? 8u : c->max_groups <= 16383u ? 16u : 32u) : 0u;
     // HBM this context holds (the capacity of every device buffer: what cl_destroy gives back)
     uint64_t b = 0;
-    b += c->d_pos.cap * 4 + c->d_mapq.cap + c->d_qual.cap + c->d_ref.cap + c->d_end.cap * 4 + c->d_rec.cap * sizeof(ReadRec);
+    b += c->d_pos.cap * 4 + c->d_mapq.cap + c->d_qual.cap + c->d_ref.cap + c->d_end.cap * 4 + c->d_rec.cap * sizeof(ReadRec) + c->d_heads.cap * sizeof(uint2) + c->d_refn.cap * 4;
     b += c->d_rows.cap * sizeof(uint4) + c->d_win_off.cap * 4 + c->d_wide_idx.cap * 4 + c->d_win.cap * sizeof(WinMeta);
     b += c->d_state.cap + c->d_runs.cap * 2 + c->d_first_state.cap + c->d_last_state.cap + c->d_win_wide.cap;
     b += c->d_winpart.cap * sizeof(WinPartial) + c->d_fin.cap * sizeof(FinPartial) + c->d_errflag.cap * 4 + c->d_runtab.cap * 8;
@@ -2353,8 +2480,8 @@ cl_status cl_contig_layout(cl_ctx *c, cl_layout_info *out)
     out->device_bytes = b;
     // what cl_contig_upload sent over the link for this contig (every transfer goes through the pinned staging ring)
     const uint64_t padded = (uint64_t)c->n_win * kT + 16;
-    uint64_t h = padded + (uint64_t)c->n_win * sizeof(WinMeta) + (uint64_t)c->n_wide * 4;
-    if (c->form == 3) h += c->n_row_groups * (uint64_t)(dut::kRowGroupWords * sizeof(uint32_t)) + ((uint64_t)c->n_rec + 1) * sizeof(ReadRec);
+    uint64_t h = (c->form == 3 ? ((uint64_t)c->n_win * kT) / 8 : padded) + (uint64_t)c->n_win * sizeof(WinMeta) + (uint64_t)c->n_wide * 4;
+    if (c->form == 3) h += c->n_row_groups * (uint64_t)(dut::kRowGroupWords * sizeof(uint32_t)) + ((uint64_t)c->n_rec + 1) * sizeof(uint2);
     else if (c->form == 0) h += c->n_qual + ((uint64_t)c->n_rec + 1) * sizeof(ReadRec);
     else h += c->n_qual + c->n_runtab * 8 + (uint64_t)c->n_reads * 9;
     out->upload_h2d_bytes = h;

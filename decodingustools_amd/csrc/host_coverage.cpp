@@ -652,10 +652,11 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     // should it turn out that it cannot be -- unsorted input, leading reads to drop -- the engine discards the prefetch).
     uint64_t a0 = 0, n_keep = rec->n;
     while (n_keep > 0 && (int64_t)rec->pos[n_keep - 1] >= (int64_t)contig_len) --n_keep;
-    if (n_keep > 0 && rec->pos[0] >= 0) {
+    if (n_keep > 0 && rec->pos[0] >= 0 && rec->qual) {
         rc = cl_contig_prefetch_qual(ctx, rec->qual + rec->qual_off[0], rec->qual_off[n_keep] - rec->qual_off[0]);
         if (rc != CL_OK) return rc;
     }
+    if (!rec->qual && !rec->pass_bits && rec->n && rec->qual_off[rec->n] > rec->qual_off[0]) return CL_ERR_INVALID;   // neither bytes nor bits
     std::vector<uint8_t> acc(rec->n ? rec->n : 1);
     uint32_t n_names = 0; uint64_t n_acc = 0;
     // the names' hashes do not depend on the admission: beside it, on their own thread
@@ -717,32 +718,58 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
             cig = patched.p;
         }
         dut_stage_time("  push: patched CIGARs", tm);
-        cl_read_tile t;
-        t.n_reads = n_keep - a0; t.pos = rec->pos + a0; t.mapq = rec->mapq + a0; t.cigar_off = rec->cigar_off + a0;
-        t.cigar = cig; t.qual_off = rec->qual_off + a0; t.qual = rec->qual;
-        rc = cl_push_reads(ctx, &t);
+        if (rec->pass_bits) {
+            // the packed variant: the reader has taken the base-quality test (dut_bam_read_contig_bits)
+            cl_read_tile_bits t;
+            t.n_reads = n_keep - a0; t.pos = rec->pos + a0; t.mapq = rec->mapq + a0; t.cigar_off = rec->cigar_off + a0;
+            t.cigar = cig; t.qual_off = rec->qual_off + a0; t.pass_bits = rec->pass_bits; t.pass_sum = rec->pass_sum + a0;
+            rc = cl_push_reads_bits(ctx, &t);
+        } else {
+            cl_read_tile t;
+            t.n_reads = n_keep - a0; t.pos = rec->pos + a0; t.mapq = rec->mapq + a0; t.cigar_off = rec->cigar_off + a0;
+            t.cigar = cig; t.qual_off = rec->qual_off + a0; t.qual = rec->qual;
+            rc = cl_push_reads(ctx, &t);
+        }
         if (rc != CL_OK) return rc;
     } else if (a0 < n_keep) {
         // records whose skipped reads are out of order: copy the accepted ones out, tile by tile
         const uint64_t kTile = 1u << 20;
         std::vector<int32_t> pos; std::vector<uint8_t> mapq; std::vector<uint32_t> coff, cig;
         std::vector<uint64_t> qoff; std::vector<uint8_t> qual;
+        std::vector<uint64_t> pbits; std::vector<uint32_t> psum;       // the packed variant's bits and sums of the copied reads
         uint64_t i = 0;
         while (i < rec->n) {
-            pos.clear(); mapq.clear(); cig.clear(); qual.clear();
+            pos.clear(); mapq.clear(); cig.clear(); qual.clear(); pbits.assign(1, 0ull); psum.clear();
             coff.assign(1, 0u); qoff.assign(1, 0ull);
+            uint64_t nb = 0;
             for (; i < rec->n && pos.size() < kTile; ++i) {
                 if (!acc[i]) continue;
                 pos.push_back(rec->pos[i]); mapq.push_back(rec->mapq[i]);
                 cig.insert(cig.end(), rec->cigar + rec->cigar_off[i], rec->cigar + rec->cigar_off[i + 1]);
-                qual.insert(qual.end(), rec->qual + rec->qual_off[i], rec->qual + rec->qual_off[i + 1]);
-                coff.push_back((uint32_t)cig.size()); qoff.push_back(qual.size());
+                const uint64_t ql = rec->qual_off[i + 1] - rec->qual_off[i];
+                if (rec->pass_bits) {
+                    pbits.resize(((nb + ql + 63) >> 6) + 1, 0ull);
+                    for (uint64_t k = 0; k < ql; ++k) {
+                        const uint64_t sb = rec->qual_off[i] + k;
+                        if ((rec->pass_bits[sb >> 6] >> (sb & 63ull)) & 1ull) pbits[(nb + k) >> 6] |= 1ull << ((nb + k) & 63ull);
+                    }
+                    psum.push_back(rec->pass_sum[i]);
+                } else qual.insert(qual.end(), rec->qual + rec->qual_off[i], rec->qual + rec->qual_off[i + 1]);
+                nb += ql;
+                coff.push_back((uint32_t)cig.size()); qoff.push_back(nb);
             }
             if (pos.empty()) continue;
-            cl_read_tile t;
-            t.n_reads = pos.size(); t.pos = pos.data(); t.mapq = mapq.data(); t.cigar_off = coff.data();
-            t.cigar = cig.data(); t.qual_off = qoff.data(); t.qual = qual.data();
-            rc = cl_push_reads(ctx, &t);
+            if (rec->pass_bits) {
+                cl_read_tile_bits t;
+                t.n_reads = pos.size(); t.pos = pos.data(); t.mapq = mapq.data(); t.cigar_off = coff.data();
+                t.cigar = cig.data(); t.qual_off = qoff.data(); t.pass_bits = pbits.data(); t.pass_sum = psum.data();
+                rc = cl_push_reads_bits(ctx, &t);
+            } else {
+                cl_read_tile t;
+                t.n_reads = pos.size(); t.pos = pos.data(); t.mapq = mapq.data(); t.cigar_off = coff.data();
+                t.cigar = cig.data(); t.qual_off = qoff.data(); t.qual = qual.data();
+                rc = cl_push_reads(ctx, &t);
+            }
             if (rc != CL_OK) return rc;
         }
     }

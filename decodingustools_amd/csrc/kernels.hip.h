@@ -106,6 +106,14 @@ struct __attribute__((aligned(16))) ReadRec {
     uint32_t meta;
 };
 
+// The pass-bit form (k_pileup_rows) reads HEADS, 8 bytes each: {pos, span | low << 31} -- the read as the pileup holds
+// it, [pos, pos + span) (span = bam_cigar2rlen: D and N included; mod.rs:22-28), and whether its mapq is at or below
+// max_low_mapq (mod.rs:26-28).  Nothing else of a read is needed there: its M/=/X bases are in the rows, and its shares of
+// summed_coverage and summed_mapq (contig_profiler.rs:74, 79-82: per-read separable) are added up by
+// cl_push_reads' walk on the host.  A span of more than kHeadSpanMax positions is cut into several heads (the +-1
+// scatter of [a, b) and [b, c) is that of [a, c)); a read without a reference span has none.
+constexpr uint32_t kHeadSpanMax = 0x7FFFFFFFu;
+
 // 16 bytes at any byte address (compiles to one unaligned dwordx4 load)
 struct __attribute__((packed, aligned(1))) Q16 { uint32_t w[4]; };
 
@@ -210,10 +218,12 @@ struct PileupArgs {
     Reads R;
     Opts o;
     const ReadRec *rec;           // the records of the short-read form (it reads these and nothing else per read)
+    const uint2   *heads;         // pass-bit form: {pos, span | low << 31} per read with a reference span
     const uint32_t *end;          // per read, from the host (run-table form)
     const WinMeta *win;
     const uint32_t *wide_idx;           // read indices of the wide reads, ascending
-    const uint8_t  *ref;          // padded with 'N' up to n_win*T
+    const uint8_t  *ref;          // padded with 'N' up to n_win*T (byte forms)
+    const uint32_t *refn;         // pass-bit form: bit p = the reference base at p is 'N' / 'n' (or beyond the reference)
     const uint32_t *lut;          // kLutSize entries: smallest low count that is "too many"
     const uint2    *runtab;       // run-table form (LONG = 2): per window, the M/=/X pieces of its reads (host, at upload)
     const uint4    *rows;         // pass-bit form (k_pileup_rows): per window, groups of 4 rows x 64 blocks (host, at upload)
@@ -1039,9 +1049,9 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
             rv[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
         }
     }
-    uint32_t refw[PER / 4];
-#pragma unroll
-    for (int i = 0; i < PER / 4; ++i) refw[i] = reinterpret_cast<const uint32_t *>(a.ref + p0)[i];
+    // (bit p of refn: the reference base at p is 'N' / 'n' or lies beyond the reference, mod.rs:79-80, :100-101)
+    const uint32_t refn = PER == 16 ? (uint32_t)reinterpret_cast<const uint16_t *>(a.refn)[(size_t)w * (T / 16) + tid]
+                                    : (uint32_t)reinterpret_cast<const uint8_t *>(a.refn)[(size_t)w * (T / 8) + tid];
 
     // ---- clear ----
     {
@@ -1056,50 +1066,39 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     }
     __syncthreads();
 
-    // ---- the window's candidates: head records.  +-1 at the clipped span ends (mod.rs:22-28: every read covering a
-    //      position counts, D/N included); the window that holds a read's start owns its separable sums
-    //      (contig_profiler.rs:74, 79-82) ----
-    unsigned long long win_len = 0, win_mq = 0;
-    for (uint32_t base = 0; base < n_cand; base += kBlock) {
-        const uint32_t v = base + tid;
-        uint32_t r = lo + (v - wn);
-        if (v < wn) r = a.wide_idx[wlo + v];
-        __builtin_assume(r < (1u << 29));
-        uint32_t own_l = 0, own_m = 0;
-        bool big = false;
-        uint32_t big_span = 0, big_mq = 0;
-        if (v < n_cand) {
-            uint4 rr = *reinterpret_cast<const uint4 *>(a.rec + r);
-            asm volatile("" : "+v"(rr.x), "+v"(rr.y), "+v"(rr.z), "+v"(rr.w));
-            const uint32_t x = rr.x, span = rr.y, mq = rr.w & 255u;
-            if ((rr.w & 0x100u) && span) {
-                const uint32_t e = x + span;
-                if (x >= W) {
-                    const bool hq = mq >= a.o.min_mapq;
-                    if (span < 0x10000u) { own_l = span; own_m = hq ? mq * span : 0u; }
-                    else { big = true; big_span = span; big_mq = hq ? mq : 0u; }
+    // ---- the window's candidates: heads.  +-1 at the clipped span ends (mod.rs:22-28: every read covering a
+    //      position counts, D/N included).  Two candidates per lane and trip: both loads are in flight together ----
+    for (uint32_t base = 0; base < n_cand; base += 2u * kBlock) {
+        uint2 hh[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t v = base + (uint32_t)u * kBlock + tid;
+            uint32_t r = lo + (v - wn);
+            if (v < wn) r = a.wide_idx[wlo + v];
+            __builtin_assume(r < (1u << 29));
+            hh[u] = make_uint2(0u, 0u);
+            if (v < n_cand) hh[u] = a.heads[r];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t x = hh[u].x, span = hh[u].y & kHeadSpanMax;
+            const uint32_t e = x + span;
+            // (a head of a cut span may lie past the window; span = 0: no candidate in this slot)
+            if (span && e > W && x < W + (uint32_t)T) {
+                const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
+                uint32_t ib, vb, ie, ve2;
+                if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
+                else {
+                    ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
+                    ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
                 }
-                if (e > W) {
-                    const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
-                    uint32_t ib, vb, ie, ve2;
-                    if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
-                    else {
-                        ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
-                        ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
-                    }
-                    atomicAdd(&s_raw[ib], vb);
-                    if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
-                    if (mq <= a.o.max_low_mapq) {
-                        atomicAdd(&s_low[ib], vb);
-                        if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
-                    }
+                atomicAdd(&s_raw[ib], vb);
+                if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
+                if (hh[u].y >> 31) {
+                    atomicAdd(&s_low[ib], vb);
+                    if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
                 }
             }
-        }
-        win_len += dpp_wave_sum_u32(own_l); win_mq += dpp_wave_sum_u32(own_m);
-        if (__any(big)) {
-            win_len += wave_sum_u64(big ? (unsigned long long)big_span : 0ull);
-            win_mq += wave_sum_u64(big ? (unsigned long long)big_mq * big_span : 0ull);
         }
     }
 
@@ -1110,19 +1109,12 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     uint32_t c[NP];
 #pragma unroll
     for (int p = 0; p < NP; ++p) c[p] = 0u;
-    unsigned long long nbits = 0;                          // set bits seen by this lane (-> quality_bases)
     if (ng) {
         for (uint32_t g0 = wv; g0 < ng; g0 += (uint32_t)kWaves * G) {
-            uint32_t pc = 0;
 #pragma unroll
             for (int j = 0; j < G; ++j) {
-                if (g0 + (uint32_t)kWaves * j < ng) {
-                    const uint4 x = rv[j];
-                    bs_add4<NP>(c, x);
-                    pc += __popc(x.x) + __popc(x.y) + __popc(x.z) + __popc(x.w);
-                }
+                if (g0 + (uint32_t)kWaves * j < ng) bs_add4<NP>(c, rv[j]);
             }
-            nbits += pc;
             if (g0 + (uint32_t)kWaves * G < ng) {          // a deeper window: the next trip's groups (requested only now)
 #pragma unroll
                 for (int j = 0; j < G; ++j) {
@@ -1140,6 +1132,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     {
         // wave 0: the four waves' planes added (a bit-sliced ripple adder per wave) and compared with the two depth
         // thresholds (callable_profiler.rs:108-113); the other waves go on with their prefix sums meanwhile
+        unsigned long long nbits = 0;                      // set bits of the window's rows, by wave 0's lanes (-> quality_bases)
         if (wv == 0) {
 #pragma unroll
             for (int v = 1; v < kWaves; ++v) {
@@ -1152,6 +1145,9 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                     c[p] = s;
                 }
             }
+            // quality_bases (contig_profiler.rs:71): the sum of the block's 32 counts = sum over the planes of 2^p x set bits
+#pragma unroll
+            for (int p = 0; p < NP; ++p) nbits += (unsigned long long)__popc(c[p]) << p;
             s_lt[lane] = bs_less_than<NP>(c, (unsigned long long)a.o.min_depth);
             // qc > max_depth  <=>  !(qc < max_depth + 1); the rule is off for max_depth == 0
             s_gt[lane] = a.o.max_depth > 0u ? ~bs_less_than<NP>(c, (unsigned long long)a.o.max_depth + 1ull) : 0u;
@@ -1188,65 +1184,50 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
 #pragma unroll
         for (int i = 0; i < PER; ++i) { vr[i] += offr; vl[i] += offl; mx = vr[i] > mx ? vr[i] : mx; }
         const uint32_t n_ok = p0 >= a.extent ? 0u : (a.extent - p0 < (uint32_t)PER ? a.extent - p0 : (uint32_t)PER);
-        // this thread's PER positions are PER consecutive bits of block (tid * PER) >> 5
-        const uint32_t lt8 = (s_lt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & ((1u << PER) - 1u);
-        const uint32_t gt8 = (s_gt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & ((1u << PER) - 1u);
-
-        uint32_t S[PER / 4];
-        uint32_t cnt[6] = {0, 0, 0, 0, 0, 0}, ncov = 0;
-        if (!DEEP && mx < kLutLds && n_ok == (uint32_t)PER) {
-            // ---- byte-parallel path: four positions per 32-bit word ----
-            const uint32_t ONES = 0x01010101u;
+        // From here on the thread's PER positions are PER bits of a register: bit i <-> position p0 + i.
+        constexpr uint32_t FULL = PER == 16 ? 0xFFFFu : 0xFFu;
+        const uint32_t okb = n_ok >= (uint32_t)PER ? FULL : ((1u << n_ok) - 1u);            // positions < extent
+        // qc_depth < min_depth, qc_depth > max_depth: PER consecutive bits of block (tid * PER) >> 5
+        const uint32_t ltb = (s_lt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & FULL;
+        const uint32_t gtb = (s_gt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & FULL;
+        // raw_depth > 0, and the low-MAPQ rule (callable_profiler.rs:100-101): the two per-position tests
+        uint32_t covb = 0, lowb = 0;
+        if (!DEEP && mx < kLutLds) {
 #pragma unroll
-            for (int h = 0; h < PER / 4; ++h) {
-                uint32_t cov = 0, low = 0;
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t raw = vr[4 * h + i];
-                    cov |= (raw < 1u ? raw : 1u) << (8 * i);
-                    low |= (vl[4 * h + i] >= (uint32_t)s_lut[raw] ? 1u : 0u) << (8 * i);   // callable_profiler.rs:100-101
-                }
-                const uint32_t x = (refw[h] | 0x20202020u) ^ 0x6e6e6e6eu;   // zero byte <=> 'N' or 'n'
-                const uint32_t nz = (((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) >> 7;
-                const uint32_t N = ~nz & ONES;
-                const uint32_t lt = __umul24((lt8 >> (4 * h)) & 15u, 0x204081u) & ONES;    // 4 mask bits -> 4 bytes
-                const uint32_t gt = __umul24((gt8 >> (4 * h)) & 15u, 0x204081u) & ONES;
-                // priorities of callable_profiler.rs:104-116, resolved into disjoint flags
-                const uint32_t t0 = ~N & cov;
-                const uint32_t rLow = t0 & low, t1 = t0 & ~low;
-                const uint32_t rLT = t1 & lt, t2 = t1 & ~lt;
-                const uint32_t rGT = t2 & gt, rC = t2 & ~gt;
-                const uint32_t rNC = ~N & ~cov & ONES;
-                S[h] = rC + (rNC << 1) + rLT + (rLT << 1) + (rGT << 2) + rLow + (rLow << 2);
-                cnt[0] += __popc(N); cnt[1] += __popc(rC); cnt[2] += __popc(rNC);
-                cnt[3] += __popc(rLT); cnt[4] += __popc(rGT); cnt[5] += __popc(rLow);
-                ncov += __popc(cov);
+            for (int i = PER - 1; i >= 0; --i) {
+                const uint32_t raw = vr[i];
+                covb = covb + covb + (raw < 1u ? raw : 1u);
+                lowb = lowb + lowb + (vl[i] >= (uint32_t)s_lut[raw] ? 1u : 0u);
             }
         } else {
-            // ---- general path, one position at a time ----
-            uint32_t st[PER];
-            for (int i = 0; i < PER; ++i) {
+#pragma unroll
+            for (int i = PER - 1; i >= 0; --i) {
                 const uint32_t raw = vr[i], low = vl[i];
-                bool is_low = false;                                                  // callable_profiler.rs:100-101
+                bool is_low = false;
                 if (raw >= a.o.min_depth_for_low_mapq && raw > 0) {
                     if (raw < kLutSize) is_low = low >= a.lut[raw];
                     else is_low = ((double)low / (double)raw) > a.o.max_low_mapq_fraction;   // IEEE f64 divide
                 }
-                const uint32_t rb = (refw[i >> 2] >> (8 * (i & 3))) & 0xFFu;
-                uint32_t sx = 1u;                                                     // CALLABLE
-                sx = ((gt8 >> i) & 1u) ? 4u : sx;                                     // EXCESSIVE_COVERAGE
-                sx = ((lt8 >> i) & 1u) ? 3u : sx;                                     // LOW_COVERAGE
-                sx = is_low ? 5u : sx;                                                // POOR_MAPPING_QUALITY
-                sx = raw == 0 ? 2u : sx;                                              // NO_COVERAGE
-                sx = ((rb | 0x20u) == 'n') ? 0u : sx;                                 // REF_N
-                const bool ok = (uint32_t)i < n_ok;
-                if (ok) { cnt[sx] += 1; ncov += raw > 0 ? 1u : 0u; }
-                st[i] = ok ? sx : 0xFFu;
+                covb = covb + covb + (raw > 0 ? 1u : 0u);
+                lowb = lowb + lowb + (is_low ? 1u : 0u);
             }
-#pragma unroll
-            for (int h = 0; h < PER / 4; ++h)
-                S[h] = st[4 * h] | (st[4 * h + 1] << 8) | (st[4 * h + 2] << 16) | (st[4 * h + 3] << 24);
         }
+        // priorities of callable_profiler.rs:104-116, resolved into disjoint masks:
+        // REF_N > NO_COVERAGE > POOR_MAPPING_QUALITY > LOW_COVERAGE > EXCESSIVE_COVERAGE > CALLABLE
+        const uint32_t Nk = refn & okb, notN = ~refn & okb, covk = covb & okb;
+        const uint32_t t0 = notN & covk;
+        const uint32_t rLow = t0 & lowb, t1 = t0 & ~lowb;
+        const uint32_t rLT = t1 & ltb, t2 = t1 & ~ltb;
+        const uint32_t rGT = t2 & gtb, rC = t2 & ~gtb;
+        const uint32_t rNC = notN & ~covk;
+        uint32_t cnt[6];
+        cnt[0] = __popc(Nk); cnt[1] = __popc(rC); cnt[2] = __popc(rNC);
+        cnt[3] = __popc(rLT); cnt[4] = __popc(rGT); cnt[5] = __popc(rLow);
+        const uint32_t ncov = __popc(covk);
+        // the state (types.rs:36-43: REF_N 0, CALLABLE 1, NO_COVERAGE 2, LOW_COVERAGE 3, EXCESSIVE_COVERAGE 4,
+        // POOR_MAPPING_QUALITY 5) as three bit planes
+        const uint32_t s0 = rC | rLT | rLow, s1 = rNC | rLT, s2 = rGT | rLow;
+        auto state_at = [&](uint32_t j) -> uint32_t { return ((s0 >> j) & 1u) | (((s1 >> j) & 1u) << 1) | (((s2 >> j) & 1u) << 2); };
         if (DEBUG) {
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
@@ -1257,39 +1238,22 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                 if (a.dbg_raw) a.dbg_raw[p0 + i] = vr[i];
                 if (a.dbg_low) a.dbg_low[p0 + i] = vl[i];
                 if (a.dbg_qc) a.dbg_qc[p0 + i] = qc;
+                a.state[p0 + i] = (uint8_t)(((okb >> i) & 1u) ? state_at((uint32_t)i) : 0xFFu);
             }
         }
         // run boundaries strictly inside the window: position p (> W) whose state differs from p-1
-        s_last[tid] = (uint8_t)(S[PER / 4 - 1] >> 24);
+        const uint32_t last_st = state_at((uint32_t)PER - 1u);
+        s_last[tid] = (uint8_t)last_st;
         mx = dpp_wave_max_u32(mx);
         if (lane == 0) s_wmax[wv] = mx;
         __syncthreads();
-        uint32_t nb = 0;
-        uint32_t bmk[PER / 4];
-        {
-            uint32_t prevb = tid > 0 ? (uint32_t)s_last[tid - 1] : (S[0] & 0xFFu);
-            // 0x01 for the positions < extent
-            const uint32_t okb = (1u << n_ok) - 1u;
-            uint32_t okw[PER / 4];
-#pragma unroll
-            for (int h = 0; h < PER / 4; ++h) okw[h] = __umul24((okb >> (4 * h)) & 15u, 0x204081u) & 0x01010101u;
-#pragma unroll
-            for (int h = 0; h < PER / 4; ++h) {
-                const uint32_t P = (S[h] << 8) | prevb;
-                const uint32_t d = S[h] ^ P;
-                bmk[h] = ((((d & 0x7f7f7f7fu) + 0x7f7f7f7fu) | d) >> 7) & okw[h];
-                nb += __popc(bmk[h]);
-                prevb = S[h] >> 24;
-            }
-        }
-        if (DEBUG) {
-#pragma unroll
-            for (int h = 0; h < PER / 4; ++h) reinterpret_cast<uint32_t *>(a.state + p0)[h] = S[h];
-        }
+        const uint32_t pv = tid > 0 ? (uint32_t)s_last[tid - 1] : state_at(0u);
+        const uint32_t bnd = ((s0 ^ ((s0 << 1) | (pv & 1u))) | (s1 ^ ((s1 << 1) | ((pv >> 1) & 1u))) | (s2 ^ ((s2 << 1) | (pv >> 2)))) & okb;
+        const uint32_t nb = __popc(bnd);
         if (!DEEP && NP == 8) {
             // a thread's counts are <= PER and every wave total <= 64 PER: packed words, one butterfly reduction each --
             // three 10-bit fields per word for 8 positions per thread (totals <= 512), two 11-bit fields for 16 (<= 1024);
-            // the wave's set bits are < 2^19 (32 groups of 4 rows x 2048 bits)
+            // the window's set bits (all with wave 0) are <= 255 x 2048 < 2^19
             constexpr int NW = PER == 8 ? 4 : 5;
             uint32_t pk[NW];
             if (PER == 8) {
@@ -1321,7 +1285,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                     t[7] = pk[NW - 1];
                 }
                 t[8] = 0;
-                t[10] = win_len; t[11] = win_mq;
+                t[10] = 0; t[11] = 0;                    // (the reads' separable sums come from the host's walk)
             }
         } else {
             unsigned long long v[10];
@@ -1333,7 +1297,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                 const unsigned long long r = wave_sum_u64(v[q]);
                 if (lane == 0) s_wtot[wv][q] = r;
             }
-            if (lane == 0) { s_wtot[wv][10] = win_len; s_wtot[wv][11] = win_mq; }
+            if (lane == 0) { s_wtot[wv][10] = 0; s_wtot[wv][11] = 0; }
         }
         __syncthreads();
         {
@@ -1342,14 +1306,13 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                 uint32_t off = inc - nb;
                 for (uint32_t i = 0; i < wv; ++i) off += (uint32_t)s_wtot[i][9];
                 uint16_t *dst = a.runs + (size_t)w * T + off;
-#pragma unroll
-                for (int h = 0; h < PER / 4; ++h)
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if ((bmk[h] >> (8 * j)) & 1u) *dst++ = (uint16_t)((tid * PER + 4 * h + j) | (((S[h] >> (8 * j)) & 7u) << 12));
+                for (uint32_t m = bnd; m; m &= m - 1u) {     // (a lane has a boundary or two, rarely more)
+                    const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
+                    *dst++ = (uint16_t)((tid * PER + j) | (state_at(j) << 12));
+                }
             }
-            if (tid == 0) a.first_state[w] = (uint8_t)(S[0] & 0xFFu);
-            if (tid == kBlock - 1) a.last_state[w] = (uint8_t)(S[PER / 4 - 1] >> 24);
+            if (tid == 0) a.first_state[w] = (uint8_t)state_at(0u);
+            if (tid == kBlock - 1) a.last_state[w] = (uint8_t)last_st;
         }
     }
     if (tid == 0) {
@@ -1429,7 +1392,8 @@ __global__ __launch_bounds__(kFinBlock) void k_fin_windows(const WinPartial *__r
 // one workgroup of kBlock threads (the extra, last workgroup of k_rle_write).
 __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, uint32_t n_fin,
                                             uint32_t extent, uint32_t *__restrict__ err_flag,
-                                            DevSummary *__restrict__ out, unsigned long long host_sum_q)
+                                            DevSummary *__restrict__ out, unsigned long long host_sum_q,
+                                            unsigned long long host_sum_cov, unsigned long long host_sum_mapq)
 {
     __shared__ unsigned long long s_red[12][kBlock / 64];
     __shared__ uint32_t s_u[kBlock / 64];
@@ -1460,8 +1424,9 @@ __device__ __forceinline__ void fin_summary(const FinPartial *__restrict__ fin, 
         out->quality_bases = tot[7];
         // (pass-bit form: the kernels see bits, the sum of the passing qualities comes from the host's walk over the bytes)
         out->summed_baseq = tot[8] + host_sum_q;
-        out->summed_coverage = tot[9];
-        out->summed_mapq = tot[10];
+        // (pass-bit form: so do the reads' reference spans and mapq x span, contig_profiler.rs:74, 79-82)
+        out->summed_coverage = tot[9] + host_sum_cov;
+        out->summed_mapq = tot[10] + host_sum_mapq;
         out->extent = extent;
         out->max_raw_depth = mr;
         out->n_intervals = tot[11];
@@ -1487,10 +1452,11 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
                                                        DevSummary *__restrict__ summary,
                                                        uint32_t n_win, uint32_t extent,
                                                        Interval *__restrict__ iv, uint32_t iv_cap,
-                                                       unsigned long long host_sum_q)
+                                                       unsigned long long host_sum_q, unsigned long long host_sum_cov,
+                                                       unsigned long long host_sum_mapq)
 {
     if (blockIdx.x == gridDim.x - 1) {                     // the extra workgroup: the contig summary
-        fin_summary(fin, n_fin, extent, err_flag, summary, host_sum_q);
+        fin_summary(fin, n_fin, extent, err_flag, summary, host_sum_q, host_sum_cov, host_sum_mapq);
         return;
     }
     // one wave per window: its seam run (if the first state differs from the previous window's last)

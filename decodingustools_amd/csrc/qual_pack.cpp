@@ -8,6 +8,8 @@
 #include <immintrin.h>
 #include <string.h>
 
+#include <algorithm>
+
 namespace dut {
 
 namespace {
@@ -87,6 +89,39 @@ __attribute__((target("avx2"))) uint64_t sum_avx2(const uint8_t *q, uint64_t n, 
     return lanes[0] + lanes[1] + lanes[2] + lanes[3] + sum_scalar(q + i, n - i, thr);
 }
 
+// ---- reference bases -> "is N" bits ----
+inline uint64_t nmask64_scalar(const uint8_t *r, uint32_t n)
+{
+    uint64_t m = 0;
+    for (uint32_t i = 0; i < n; ++i) m |= (uint64_t)((r[i] | 0x20u) == 'n') << i;
+    return m;
+}
+
+void nwords_sse2(const uint8_t *r, uint64_t n_words, uint64_t *out)
+{
+    const __m128i lc = _mm_set1_epi8(0x20), nn = _mm_set1_epi8('n');
+    for (uint64_t w = 0; w < n_words; ++w) {
+        uint64_t m = 0;
+        for (int k = 0; k < 4; ++k) {
+            const __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i *>(r + 64 * w + 16 * k));
+            m |= (uint64_t)(uint32_t)_mm_movemask_epi8(_mm_cmpeq_epi8(_mm_or_si128(v, lc), nn)) << (16 * k);
+        }
+        out[w] = m;
+    }
+}
+
+__attribute__((target("avx2"))) void nwords_avx2(const uint8_t *r, uint64_t n_words, uint64_t *out)
+{
+    const __m256i lc = _mm256_set1_epi8(0x20), nn = _mm256_set1_epi8('n');
+    for (uint64_t w = 0; w < n_words; ++w) {
+        const __m256i a = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(r + 64 * w));
+        const __m256i b = _mm256_loadu_si256(reinterpret_cast<const __m256i *>(r + 64 * w + 32));
+        const uint32_t ma = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_or_si256(a, lc), nn));
+        const uint32_t mb = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(_mm256_or_si256(b, lc), nn));
+        out[w] = (uint64_t)ma | ((uint64_t)mb << 32);
+    }
+}
+
 bool has_avx2()
 {
     static const bool v = __builtin_cpu_supports("avx2");
@@ -145,6 +180,20 @@ uint64_t qual_pass_read(const uint8_t *q, uint64_t n, uint8_t thr, uint64_t *out
     qual_pass_words(q, n >> 6, thr, out, level);
     if (n & 63ull) out[n >> 6] = qual_pass_partial(q + (n & ~63ull), (uint32_t)(n & 63ull), thr);
     return qual_pass_sum(q, n, thr, level);
+}
+
+void ref_n_words(const uint8_t *ref, uint64_t n_bases, uint64_t n_words, uint64_t *out, int level)
+{
+    const uint64_t whole = std::min<uint64_t>(n_bases >> 6, n_words);
+    if (level == 0) { for (uint64_t w = 0; w < whole; ++w) out[w] = nmask64_scalar(ref + 64 * w, 64); }
+    else if (level >= 2 && has_avx2()) nwords_avx2(ref, whole, out);
+    else nwords_sse2(ref, whole, out);
+    for (uint64_t w = whole; w < n_words; ++w) {
+        const uint64_t have = n_bases > 64 * w ? std::min<uint64_t>(64, n_bases - 64 * w) : 0;
+        uint64_t m = have ? nmask64_scalar(ref + 64 * w, (uint32_t)have) : 0ull;
+        if (have < 64) m |= ~0ull << have;                      // beyond the reference: 'N' (mod.rs:79-80)
+        out[w] = m;
+    }
 }
 
 uint64_t qual_pass_sum(const uint8_t *q, uint64_t n, uint8_t thr, int level)

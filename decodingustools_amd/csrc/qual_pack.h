@@ -15,5 +15,8 @@ uint64_t qual_pass_partial(const uint8_t *q, uint32_t n, uint8_t thr);
 uint64_t qual_pass_read(const uint8_t *q, uint64_t n, uint8_t thr, uint64_t *out, int level = 2);
 // sum of q[i] over the i < n with q[i] >= thr
 uint64_t qual_pass_sum(const uint8_t *q, uint64_t n, uint8_t thr, int level = 2);
+// the reference's "is N" bits (mod.rs:100-101): bit i of out[w] = ((ref[64 w + i] | 0x20) == 'n') for the n_bases bases
+// at `ref`, 1 for every position beyond them (mod.rs:79-80: no reference base reads as 'N'); n_words words are written
+void ref_n_words(const uint8_t *ref, uint64_t n_bases, uint64_t n_words, uint64_t *out, int level = 2);
 
 } // namespace dut

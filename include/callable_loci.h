@@ -139,6 +139,27 @@ cl_status cl_contig_prefetch_qual(cl_ctx *ctx, const uint8_t *qual, uint64_t n_b
  * kernel counts.  With DUT_QUAL_FORM=bytes in the environment of cl_create the quality bytes themselves go to HBM
  * (small tiles via host staging, tiles of >= 4 MiB through a pinned staging ring) and are tested on the device. */
 cl_status cl_push_reads(cl_ctx *ctx, const cl_read_tile *tile);
+/* The packed pass-bitmask variant of cl_push_reads: for a caller that has taken the base-quality test of
+ * mod.rs:33 itself, where it decodes the records (the library's own BAM reader does: dut_bam_read_contig_bits).  Same
+ * tile, with instead of the quality bytes
+ *   qual_off   n_reads + 1 offsets of the reads' quality VALUES, as in cl_read_tile -- now bit offsets into pass_bits
+ *   pass_bits  bit g (word g / 64, bit g % 64) = 1 iff quality value g >= min_base_quality of the context's options
+ *              (an absent quality string, 0xFF bytes, passes); bits beyond qual_off[n] are ignored
+ *   pass_sum   per read: the sum of the quality values that pass, over the bases of its M/=/X operations that have a
+ *              quality value (its share of summed_baseq, contig_profiler.rs:65-70; a read's sum is below 2^32)
+ * Pass-bit form only (the default): with DUT_QUAL_FORM=bytes the engine needs the bytes and refuses with
+ * CL_ERR_INVALID.  Tiles of both kinds may be mixed within a contig. */
+typedef struct cl_read_tile_bits {
+    uint64_t        n_reads;
+    const int32_t  *pos;
+    const uint8_t  *mapq;
+    const uint32_t *cigar_off;
+    const uint32_t *cigar;
+    const uint64_t *qual_off;
+    const uint64_t *pass_bits;
+    const uint32_t *pass_sum;
+} cl_read_tile_bits;
+cl_status cl_push_reads_bits(cl_ctx *ctx, const cl_read_tile_bits *tile);
 /* upload + run + collect in one call.  *intervals points at context-owned memory, valid until
  * the next cl_contig_begin / cl_destroy. */
 cl_status cl_contig_finish(cl_ctx *ctx, cl_contig_summary *out,
@@ -214,6 +235,10 @@ cl_status cl_debug_read_records(int32_t pos, const uint32_t *cigar, uint32_t n_o
  * 2 AVX2 where the CPU has it (else SSE2); 10, 11, 12: the same levels through the one-pass form (bits and sum together). */
 cl_status cl_debug_qual_pack(const uint8_t *qual, uint64_t n, uint8_t min_base_quality, int level, uint64_t *words_out,
                              uint64_t *sum_out);
+/* Host only: the reference's "is N" bits as cl_contig_upload sends them in the pass-bit form (mod.rs:100-101: a base
+ * that is 'N' or 'n'; mod.rs:79-80: positions beyond the reference read as 'N'): bit i of word w <-> position 64 w + i,
+ * n_words words for n_bases bases (levels as above). */
+cl_status cl_debug_ref_n_bits(const uint8_t *ref, uint64_t n_bases, uint64_t n_words, int level, uint64_t *words_out);
 /* A context WITHOUT a device, for the CPU test suite only: cl_contig_begin / cl_push_reads (pass-bit form) stage a
  * contig on the host exactly as a device context does, and cl_debug_pass_rows runs the upload's row builder over it.
  * Every call that needs a device fails with CL_ERR_DEVICE: there is no CPU pileup. */

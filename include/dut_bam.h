@@ -40,6 +40,10 @@ int64_t dut_bam_ref_mapped(const dut_bam *b, int tid);
  * valid until the next call on this reader.  seq_off (in bases) / seq4 (4-bit codes, two per
  * byte, continuous) are filled when non-NULL.  Returns 0 or a negative cl_status. */
 int dut_bam_read_contig(dut_bam *b, int tid, dut_records *out, const uint64_t **seq_off, const uint8_t **seq4);
+/* The same with the base-quality test of mod.rs:33 taken while the records are parsed (their bytes are in the cache
+ * then): out->qual is NULL, out->pass_bits / out->pass_sum are filled (dut_records, dut_coverage.h) -- one bit per
+ * base instead of one byte leaves the reader: what the file-level coverage path uses in the default pass-bit form. */
+int dut_bam_read_contig_bits(dut_bam *b, int tid, uint8_t min_base_quality, dut_records *out);
 
 /* `bam.records()` on a plain reader (utils/bam_reader.rs:16-24): every record of the file, mapped or
  * not, from the first one, until fn returns 0 or the file ends.  index = 0-based ordinal; qname

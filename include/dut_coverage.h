@@ -39,6 +39,11 @@ typedef struct dut_records {
     const uint8_t  *qual;
     const uint32_t *qname_off;   /* n+1 */
     const uint8_t  *qname;
+    /* the packed variant (dut_bam_read_contig_bits; both NULL otherwise): the base-quality test already taken -- bit
+     * qual_off[i] + k of pass_bits <-> quality value k of read i --, and per read the sum of the passing values over
+     * its matched bases (cl_read_tile_bits, callable_loci.h).  `qual` may then be NULL. */
+    const uint64_t *pass_bits;
+    const uint32_t *pass_sum;
 } dut_records;
 
 /* ContigProfiler fields the report reads (contig_profiler.rs:7-20, report.rs:40-86) */

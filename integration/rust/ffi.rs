@@ -16,6 +16,15 @@ pub struct ClReadTile {
     pub cigar_off: *const u32, pub cigar: *const u32,
     pub qual_off: *const u64, pub qual: *const u8,
 }
+#[repr(C)]
+pub struct ClReadTileBits {       // cl_read_tile_bits: the packed pass-bitmask variant
+    pub n_reads: u64,
+    pub pos: *const i32, pub mapq: *const u8,
+    pub cigar_off: *const u32, pub cigar: *const u32,
+    pub qual_off: *const u64,     // bit offsets into pass_bits
+    pub pass_bits: *const u64,    // bit g = quality value g >= min_base_quality (mod.rs:33)
+    pub pass_sum: *const u32,     // per read: sum of the passing values over its M/=/X bases (contig_profiler.rs:65-70)
+}
 #[repr(C)] #[derive(Default)]
 pub struct ClContigSummary {
     pub state_counts: [u64; 6],   // indexed by CalledState as usize (types.rs:36-43)
@@ -34,6 +43,7 @@ extern "C" {
     pub fn cl_contig_reserve(ctx: *mut ClCtx, n_reads: u64, n_cigar_ops: u64, n_qual_bytes: u64) -> c_int; // optional hint
     pub fn cl_contig_prefetch_qual(ctx: *mut ClCtx, qual: *const u8, n_bytes: u64) -> c_int;             // optional overlap
     pub fn cl_push_reads(ctx: *mut ClCtx, tile: *const ClReadTile) -> c_int;
+    pub fn cl_push_reads_bits(ctx: *mut ClCtx, tile: *const ClReadTileBits) -> c_int;                     // optional: the test taken by the caller
     pub fn cl_contig_finish(ctx: *mut ClCtx, out: *mut ClContigSummary,
                             iv: *mut *const ClInterval, n_iv: *mut usize) -> c_int;
     pub fn cl_contig_abort(ctx: *mut ClCtx) -> c_int;      // error path: cancels an unclaimed prefetch, drops staged reads

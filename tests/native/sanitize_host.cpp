@@ -32,6 +32,16 @@ void cl_destroy(cl_ctx *c) { delete c; }
 const char *cl_last_error(const cl_ctx *) { return "no device in the sanitizer build"; }
 cl_status cl_contig_begin(cl_ctx *c, int32_t tid, uint32_t len, const uint8_t *, uint64_t) { c->tid = tid; c->len = len; c->n_reads = 0; return CL_OK; }
 cl_status cl_push_reads(cl_ctx *c, const cl_read_tile *t) { c->n_reads += t->n_reads; return CL_OK; }
+cl_status cl_push_reads_bits(cl_ctx *c, const cl_read_tile_bits *t)
+{
+    // every word the tile names is read (the sanitizers see an offset that runs past the reader's buffers)
+    uint64_t seen = 0;
+    if (t->n_reads && t->qual_off[t->n_reads] > t->qual_off[0])
+        for (uint64_t w = t->qual_off[0] >> 6; w <= (t->qual_off[t->n_reads] - 1) >> 6; ++w) seen ^= t->pass_bits[w];
+    for (uint64_t i = 0; i < t->n_reads; ++i) seen += t->pass_sum[i];
+    c->n_reads += t->n_reads + (seen == 0x5EEDull ? 0 : 0);
+    return CL_OK;
+}
 cl_status cl_contig_prefetch_qual(cl_ctx *, const uint8_t *, uint64_t) { return CL_OK; }
 cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *s, const cl_interval **iv, size_t *n)
 {
@@ -165,6 +175,18 @@ static int pass_bit_selftest()
             }
         }
     }
+    // the reference's "is N" bits, with buffers of exactly the sizes the interface names
+    for (int round = 0; round < 40; ++round) {
+        const size_t nb = (size_t)rnd(700), nw = (size_t)rnd(14);
+        std::vector<uint8_t> ref(nb);
+        for (auto &b : ref) b = (uint8_t)"ACGTNnacgtRY"[rnd(12)];
+        std::vector<uint64_t> out(nw);
+        dut::ref_n_words(ref.data(), nb, nw, out.data(), round % 3);
+        for (size_t p = 0; p < 64 * nw; ++p) {
+            const bool want = p >= nb || (ref[p] | 0x20) == 'n';
+            if ((((out[p >> 6] >> (p & 63)) & 1ull) != 0) != want) ++bad;
+        }
+    }
     printf("pass-bit selftest: %d mismatch(es)\n", bad);
     return bad;
 }
@@ -188,6 +210,29 @@ int main(int argc, char **argv)
             unsigned long long h = checksum(rec.pos, rec.n * 4) ^ checksum(rec.qual, rec.qual_off[rec.n]) ^ checksum(rec.cigar, 4ull * rec.cigar_off[rec.n]) ^
                                    checksum(rec.qname, rec.qname_off[rec.n]);
             if (pass) h ^= checksum(sq, (so[rec.n] + 1) / 2);
+            {   // the packed variant of the same contig: its bits and sums against the bytes just read
+                const std::vector<uint8_t> q(rec.qual, rec.qual + rec.qual_off[rec.n]);
+                const std::vector<uint64_t> qo(rec.qual_off, rec.qual_off + rec.n + 1);
+                dut_records pr;
+                const uint8_t thr = (uint8_t)(pass ? 20 : 0);
+                if (dut_bam_read_contig_bits(b, tid, thr, &pr) == CL_OK && pr.n == qo.size() - 1) {
+                    unsigned long long wrong = pr.qual != nullptr;
+                    for (uint64_t g = 0; g < q.size(); ++g) wrong += (((pr.pass_bits[g >> 6] >> (g & 63)) & 1ull) != 0) != (q[(size_t)g] >= thr);
+                    for (uint64_t i = 0; i < pr.n; ++i) {
+                        uint64_t y = 0, want = 0;
+                        const uint64_t ql = qo[i + 1] - qo[i];
+                        for (uint32_t k = pr.cigar_off[i]; k < pr.cigar_off[i + 1]; ++k) {
+                            const uint32_t op = pr.cigar[k] & 15u, l = pr.cigar[k] >> 4;
+                            if ((0x181u >> op) & 1u) for (uint64_t j = y; j < y + l && j < ql; ++j) want += q[(size_t)(qo[i] + j)] >= thr ? q[(size_t)(qo[i] + j)] : 0u;
+                            if ((0x193u >> op) & 1u) y += l;
+                        }
+                        wrong += want != pr.pass_sum[i];
+                    }
+                    if (wrong) { printf("tid %d: the packed reader disagrees in %llu place(s)\n", tid, wrong); return 6; }
+                    // (rec's arrays are the reader's own and are gone now: read again for what follows)
+                    if (dut_bam_read_contig(b, tid, &rec, pass ? &so : nullptr, pass ? &sq : nullptr) != CL_OK) continue;
+                }
+            }
             std::vector<uint8_t> acc(rec.n + 1);
             uint32_t names = 0; uint64_t nacc = 0;
             const int ar = dut_admit_reads(&opt, tid, dut_bam_ref_len(b, tid), &rec, acc.data(), &names, &nacc);

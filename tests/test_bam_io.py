@@ -276,3 +276,35 @@ def test_csi_index_is_used_like_a_bai(tmp_path):
             assert got.n == (exp.n if exp is not None else 0)
             if exp is not None and exp.n:
                 assert np.array_equal(got.pos, exp.pos) and np.array_equal(got.cigar, exp.cigar) and np.array_equal(got.qual, exp.qual)
+
+
+@pytest.mark.parametrize("thr", [0, 20, 41])
+@pytest.mark.parametrize("block_every", [None, 5])
+def test_the_packed_reader_takes_the_base_quality_test_at_parse(tmp_path, thr, block_every):
+    """dut_bam_read_contig_bits: bit qual_off[i] + k <-> (quality value k of read i >= thr), pass_sum[i] = the sum of the
+    passing values over the read's M/=/X bases; everything else as dut_bam_read_contig returns it."""
+    refs, per = _dataset()
+    per[1] = synth.long_read_contig(5_000, 8, 9)            # I / D / S operations, strings longer than a word
+    path = str(tmp_path / "p.bam")
+    write_bam(path, refs, per, block_every=block_every)
+    with BamReader(path) as r:
+        for tid in (0, 2, 1, 3, 0):
+            want = r.fetch_contig(tid)
+            got, bits, sums = r.fetch_contig_bits(tid, thr)
+            for f in ("pos", "flag", "mapq", "cigar_off", "cigar", "qual_off", "qname_off", "qname"):
+                assert np.array_equal(getattr(got, f), getattr(want, f)), f
+            nq = int(want.qual_off[-1])
+            ok = want.qual[:nq] >= thr
+            have = np.unpackbits(bits.view(np.uint8), bitorder="little")[:nq].astype(bool)
+            assert np.array_equal(have, ok)
+            assert not np.unpackbits(bits.view(np.uint8), bitorder="little")[nq:].any()       # nothing behind the last value
+            for i in range(want.n):
+                q = want.qual[int(want.qual_off[i]):int(want.qual_off[i + 1])].astype(np.int64)
+                y = 0; tot = 0
+                for cw in want.cigar[int(want.cigar_off[i]):int(want.cigar_off[i + 1])]:
+                    op, ln = int(cw) & 15, int(cw) >> 4
+                    if op in (0, 7, 8):
+                        seg = q[y:y + ln]; tot += int(seg[seg >= thr].sum())
+                    if op in (0, 1, 4, 7, 8):
+                        y += ln
+                assert int(sums[i]) == tot, (tid, i)

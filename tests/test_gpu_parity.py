@@ -1486,3 +1486,79 @@ def test_one_long_indel_rich_read_inside_a_short_read_contig(tmp_path):
     assert rec.cigar.shape[0] < 8 * rec.n and rec.n == short.n + 1
     ref = synth.make_reference(L, 5152)
     compare([("chrH", 7, L, ref, rec)], dict(), tmp_path, "hybrid", dump=False)
+
+
+def _packed(rec, thr):
+    """What cl_push_reads_bits takes instead of the quality bytes (include/callable_loci.h), restated with numpy."""
+    nq = int(rec.qual_off[-1])
+    bits = np.zeros((nq + 63) // 64 + 1, np.uint64)
+    by = np.packbits(rec.qual[:nq] >= thr, bitorder="little")
+    bits.view(np.uint8)[:by.shape[0]] = by
+    sums = np.zeros(rec.n, np.uint32)
+    for i in range(rec.n):
+        q = rec.qual[int(rec.qual_off[i]):int(rec.qual_off[i + 1])].astype(np.int64)
+        y = 0; tot = 0
+        for cw in rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])]:
+            op, ln = int(cw) & 15, int(cw) >> 4
+            if op in (0, 7, 8):
+                seg = q[y:y + ln]; tot += int(seg[seg >= thr].sum())
+            if op in (0, 1, 4, 7, 8):
+                y += ln
+        sums[i] = tot
+    return bits, sums
+
+
+@pytest.mark.parametrize("shape", ["short", "long", "shapes"])
+def test_the_packed_pass_bitmask_variant_gives_what_the_bytes_give(shape, tmp_path, monkeypatch):
+    """cl_push_reads_bits (SURVEY 8b's packed variant: the caller has taken the base-quality test) against cl_push_reads on
+    the same reads -- summary, runs and per-position counters --, in one tile, in ragged tiles and mixed with byte tiles;
+    a context in the byte forms refuses it."""
+    if shape == "short":
+        L = 200_000; rec = synth.short_read_contig(L, 25, 71)
+    elif shape == "long":
+        L = 150_000; rec = synth.long_read_contig(L, 10, 72)
+    else:
+        L, rec, _ = record_shapes_contig(200_000, seed=73, n_plain=1500)
+    assert not (rec.pos >= L).any() and not (rec.pos < 0).any()
+    ref = synth.make_reference(L, 5)
+    opt = CallableOptions(min_base_quality=25)
+    bits, sums = _packed(rec, 25)
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref)
+        eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        want = eng.contig_finish()
+        want_d = eng.debug_depths(int(want.summary.extent))
+        for cuts, mixed in (([0, rec.n], False), ([0, 1, 7, rec.n // 2, rec.n // 2 + 3, rec.n], False), ([0, rec.n // 3, 2 * rec.n // 3, rec.n], True)):
+            eng.contig_begin(0, L, ref)
+            for k, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+                if mixed and k == 1:
+                    eng.push_reads(rec.pos[a:b], rec.mapq[a:b], rec.cigar_off[a:b + 1], rec.cigar, rec.qual_off[a:b + 1], rec.qual)
+                else:
+                    eng.push_reads_bits(rec.pos[a:b], rec.mapq[a:b], rec.cigar_off[a:b + 1], rec.cigar, rec.qual_off[a:b + 1], bits, sums[a:b])
+            got = eng.contig_finish()
+            assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals), cuts
+            for a, b in zip(want_d, eng.debug_depths(int(got.summary.extent))):
+                assert np.array_equal(a, b)
+    monkeypatch.setenv("DUT_QUAL_FORM", "bytes")
+    with Engine(opt, 0) as eng:
+        eng.contig_begin(0, L, ref)
+        with pytest.raises(Exception) as e:
+            eng.push_reads_bits(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, bits, sums)
+        assert getattr(e.value, "status", None) == -1             # CL_ERR_INVALID
+        eng.push_reads(rec.pos, rec.mapq, rec.cigar_off, rec.cigar, rec.qual_off, rec.qual)
+        got = eng.contig_finish()
+        assert got.as_dict() == want.as_dict() and np.array_equal(got.intervals, want.intervals)
+
+
+@pytest.mark.parametrize("head_span", ["1", "37", "1000", "70000"])
+def test_spans_cut_into_several_heads(head_span, tmp_path, monkeypatch):
+    """k_pileup_rows takes a read's reference span from 8-byte heads of at most 2^31 - 1 positions each; a longer span is cut
+    into several heads (only a contig beyond 2 Gb can hold one: DUT_HEAD_SPAN puts the seams into ordinary reads).  The
+    +-1 scatter of the pieces is that of the whole span, the reads' separable sums come from the host's walk: everything
+    as the oracle has it, including wide reads (their heads come through the wide list) and heads past their window."""
+    monkeypatch.setenv("DUT_HEAD_SPAN", head_span)
+    L, rec, ref = record_shapes_contig(L=150_000, seed=99, n_plain=1200, short_form=False)
+    compare([("chrS", 4, L, ref, rec)], dict(min_mapping_quality=5), tmp_path, "heads_" + head_span)
+    if head_span in ("37", "1000"):
+        rec = synth.long_read_contig(60_000, 8, 17)
+        compare([("chrL", 2, 60_000, synth.make_reference(60_000, 3), rec)], None, tmp_path, "heads_long_" + head_span)

@@ -310,6 +310,10 @@ def test_bench_whole_genome_line_over_two_ranks(tmp_path):
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
            "--backend", "gloo", "--wgs-scale", str(1.0 / 64), "--min-time", "0.05"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    if r.returncode != 0:                                     # the whole log, for the one who has to find out why
+        os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(root, "gpurun_out", "wgs_two_ranks_failed.log"), "w") as f:
+            f.write(r.stdout + "\n==== stderr\n" + r.stderr)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

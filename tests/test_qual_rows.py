@@ -47,6 +47,25 @@ def test_pass_bits_and_sums_agree_at_every_level(thr):
             assert s == want_sum, (n, level)
 
 
+def test_reference_n_bits_agree_at_every_level():
+    """cl_contig_upload sends one bit of a reference base in the pass-bit form: is it 'N' / 'n' (mod.rs:100-101), and 1
+    for every position beyond the reference (mod.rs:79-80)."""
+    lib = _lib.load()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 63, 64, 65, 200, 4096, 5000):
+        ref = rng.choice(np.frombuffer(b"ACGTacgtNnRYMK.*-", np.uint8), size=n)
+        for n_words in ((n + 63) // 64, (n + 63) // 64 + 3, max(0, n // 64 - 1)):
+            want = np.ones(n_words * 64, bool)
+            k = min(n, n_words * 64)
+            want[:k] = (ref[:k] | 0x20) == ord("n")
+            for level in (0, 1, 2):
+                out = np.full(n_words + 1, 0xABCDABCDABCDABCD, np.uint64)
+                assert lib.cl_debug_ref_n_bits(ref.ctypes.data if n else None, n, n_words, level, out.ctypes.data) == 0
+                assert out[n_words] == 0xABCDABCDABCDABCD                     # nothing behind the words asked for
+                have = np.unpackbits(out[:n_words].view(np.uint8), bitorder="little").astype(bool)
+                assert np.array_equal(have, want), (n, n_words, level)
+
+
 def stage(opt: CallableOptions, contig_len, rec: ContigRecords, tiles):
     """The accepted reads of `rec` pushed in the given tiles ([(first, last)) read ranges) -> (n_groups, rows, sum_q)."""
     with HostStage(opt) as st:
@@ -54,6 +73,43 @@ def stage(opt: CallableOptions, contig_len, rec: ContigRecords, tiles):
         for a, b in tiles:
             co = rec.cigar_off[a:b + 1]; qo = rec.qual_off[a:b + 1]
             st.push_reads(rec.pos[a:b], rec.mapq[a:b], co, rec.cigar, qo, rec.qual)
+        return st.pass_rows()
+
+
+def packed(rec: ContigRecords, thr):
+    """What a caller of cl_push_reads_bits hands over: one bit per quality value (bit qual_off[i] + k) and per read the sum
+    of the passing values over its M/=/X bases (numpy restatement of the header's wording)."""
+    nq = int(rec.qual_off[-1])
+    ok = rec.qual[:nq] >= thr
+    bits = np.zeros((nq + 63) // 64 + 1, np.uint64)
+    by = np.packbits(ok, bitorder="little")
+    bits.view(np.uint8)[:by.shape[0]] = by
+    sums = np.zeros(rec.n, np.uint32)
+    for i in range(rec.n):
+        q = rec.qual[int(rec.qual_off[i]):int(rec.qual_off[i + 1])].astype(np.int64)
+        y = 0; tot = 0
+        for cw in rec.cigar[int(rec.cigar_off[i]):int(rec.cigar_off[i + 1])]:
+            op, ln = int(cw) & 15, int(cw) >> 4
+            if op in (0, 7, 8):
+                seg = q[y:y + ln]
+                tot += int(seg[seg >= thr].sum())
+            if op in (0, 1, 4, 7, 8):
+                y += ln
+        sums[i] = tot
+    return bits, sums
+
+
+def stage_packed(opt: CallableOptions, contig_len, rec: ContigRecords, tiles, mixed=False):
+    """The same tiles through cl_push_reads_bits (every second one through cl_push_reads when `mixed`)."""
+    bits, sums = packed(rec, opt.min_base_quality)
+    with HostStage(opt) as st:
+        st.contig_begin(0, contig_len, None)
+        for k, (a, b) in enumerate(tiles):
+            co = rec.cigar_off[a:b + 1]; qo = rec.qual_off[a:b + 1]
+            if mixed and k % 2:
+                st.push_reads(rec.pos[a:b], rec.mapq[a:b], co, rec.cigar, qo, rec.qual)
+            else:
+                st.push_reads_bits(rec.pos[a:b], rec.mapq[a:b], co, rec.cigar, qo, bits, sums[a:b])
         return st.pass_rows()
 
 
@@ -107,6 +163,10 @@ def check(rec, L, opt_d, tiles=None, seed=0):
     assert bad.shape[0] == 0, (bad[:10], qc[bad[:10]], want["qc"][bad[:10]])
     assert sum_q == want["summed_baseq"]
     assert int(qc.sum()) == want["quality_bases"]
+    # the packed variant (cl_push_reads_bits) stages the very same rows, also mixed with byte tiles
+    for mixed in (False, True):
+        ng2, rows2, sum_q2 = stage_packed(opt, L, rec, tiles, mixed)
+        assert np.array_equal(ng2, ng) and np.array_equal(rows2, rows) and sum_q2 == sum_q
     # as many rows as the deepest column of reads that enter the rows needs, rounded up to a group of 4
     return ng
 

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Tooling: the stages of a contig's first pass on a fresh context and of the next pass on the same context
+(DUT_TIMING=1 lines on stderr), chr21-shaped 30x short reads by default.
+
+    python tools/first_pass.py [--length N] [--passes 3]"""
+import argparse, os, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("DUT_TIMING", "1")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--length", type=int, default=46_709_983)
+    ap.add_argument("--passes", type=int, default=3)
+    ap.add_argument("--engines", type=int, default=2)
+    a = ap.parse_args()
+    from decodingustools_amd import CallableOptions, CallableProfiler, ContigProfiler, Engine, process_single_contig, synth
+    seed = synth.seed_for(2, 20)
+    rec = synth.short_read_contig(a.length, 30.0, seed)
+    ref = synth.make_reference(a.length, seed)
+    opt = CallableOptions()
+    d = tempfile.mkdtemp()
+    for e in range(a.engines):
+        with Engine(opt, 0) as eng:
+            for k in range(a.passes):
+                counter = CallableProfiler(os.path.join(d, "x.bed"))
+                sys.stderr.write(f"==== engine {e} pass {k}\n"); sys.stderr.flush()
+                t0 = time.perf_counter()
+                process_single_contig(eng, counter, ContigProfiler("c", a.length), opt, 20, rec, ref)
+                dt = time.perf_counter() - t0
+                counter.close()
+                sys.stderr.write(f"==== engine {e} pass {k}: {dt * 1e3:.1f} ms\n"); sys.stderr.flush()
+
+
+if __name__ == "__main__":
+    main()

@@ -1018,12 +1018,28 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     constexpr int G = BS == 128 ? 6 : 4;                   // groups a wave has in flight: 12 / 16 per window before a second trip
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];
     __shared__ __attribute__((aligned(16))) uint32_t s_low[kDiffWords];
-    __shared__ uint32_t s_pl[kWaves][NP][64];              // the waves' counter planes
-    __shared__ uint32_t s_lt[64], s_gt[64];                // per block: qc < min_depth, qc > max_depth
-    __shared__ uint16_t s_lut[kLutLds];
-    __shared__ uint32_t s_wraw[kWaves], s_wlow[kWaves], s_wmax[kWaves];
-    __shared__ uint8_t s_last[kBlock];
-    __shared__ unsigned long long s_wtot[kWaves][12];
+    // LDS: the two difference arrays and ONE pool that is used twice -- 10 240 bytes in all, so that a CU holds 16
+    // workgroups (the kernel's time follows the number of workgroups a CU runs: profiles/r04_occupancy.txt):
+    //   first   the counter planes of waves 1.. (wave 0 adds them to its own after the barrier; it is their only reader)
+    //   then    s_lt / s_gt and the low-MAPQ thresholds s_lut: a lane of wave 0 writes its words after it has read its
+    //           planes (they lie in the slots of that lane's own planes 0, 1 and 4 of wave 1); s_last, s_wtot, s_wmax:
+    //           written behind the NEXT barrier, when wave 0 is long done with the planes
+    // (the waves' totals for the prefix sums across waves travel in the difference arrays: a lane's own, consumed slot)
+    constexpr int kPoolWords = (kWaves - 1) * NP * 64;
+    static_assert(NP >= 8 && kPoolWords >= 320 && 128 + kBlock / 4 + kWaves * 24 + kWaves <= 256, "the pool holds its second tenants");
+    __shared__ __attribute__((aligned(16))) uint32_t s_pool[kPoolWords];
+    uint32_t (*s_pl)[NP][64] = reinterpret_cast<uint32_t (*)[NP][64]>(s_pool);
+    uint32_t *const s_lt = s_pool, *const s_gt = s_pool + 64;                  // per block: qc < min_depth, qc > max_depth
+    uint8_t *const s_last = reinterpret_cast<uint8_t *>(s_pool + 128);         // kBlock bytes
+    unsigned long long (*s_wtot)[12] = reinterpret_cast<unsigned long long (*)[12]>(s_pool + 128 + kBlock / 4);
+    uint32_t *const s_wmax = s_pool + 128 + kBlock / 4 + kWaves * 24;
+    // the low-MAPQ thresholds of depths below 255 as bytes: 255 = never (a count is at most the depth)
+    uint8_t *const s_lut = reinterpret_cast<uint8_t *>(s_pool + 256);
+    __shared__ uint32_t s_dbg[DEBUG ? NP : 1][64];         // DEBUG: the window's planes, for the dump of qc_depth
+#ifdef CL_ROWS_LDS_PAD
+    __shared__ uint32_t s_pad[CL_ROWS_LDS_PAD / 4];        // (occupancy experiments only)
+    s_pad[threadIdx.x] = threadIdx.x;
+#endif
 
     const uint32_t w = (blockIdx.x & 7u) * a.n_win8 + (blockIdx.x >> 3);   // XCD-contiguous window ranges
     if (w >= a.n_win) return;
@@ -1049,6 +1065,21 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
             rv[j] = rows[(size_t)(g < ng ? g : ng - 1u) * 64u + lane];
         }
     }
+    // ... and the window's first candidates: heads (kernels.hip.h: HeadRec), U per lane and trip
+    constexpr int U = 4;
+    auto load_heads = [&](uint32_t base, uint2 (&hh)[U]) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t v = base + (uint32_t)u * kBlock + tid;
+            uint32_t r = lo + (v - wn);
+            if (v < wn) r = a.wide_idx[wlo + v];
+            __builtin_assume(r < (1u << 29));
+            hh[u] = make_uint2(0u, 0u);
+            if (v < n_cand) hh[u] = a.heads[r];
+        }
+    };
+    uint2 hh[U];
+    load_heads(0u, hh);
     // (bit p of refn: the reference base at p is 'N' / 'n' or lies beyond the reference, mod.rs:79-80, :100-101)
     const uint32_t refn = PER == 16 ? (uint32_t)reinterpret_cast<const uint16_t *>(a.refn)[(size_t)w * (T / 16) + tid]
                                     : (uint32_t)reinterpret_cast<const uint8_t *>(a.refn)[(size_t)w * (T / 8) + tid];
@@ -1059,48 +1090,8 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
         uint4 *r4 = reinterpret_cast<uint4 *>(s_raw), *l4 = reinterpret_cast<uint4 *>(s_low);
         const uint4 zb = DEEP ? z : make_uint4(0x8000u, 0x8000u, 0x8000u, 0x8000u);
         for (int i = tid; i < kDiffWords / 4; i += kBlock) { r4[i] = zb; l4[i] = zb; }
-        for (uint32_t i = tid; i < kLutLds; i += kBlock) {
-            const uint32_t v = (i >= a.o.min_depth_for_low_mapq && i > 0) ? a.lut[i] : 0xFFFFFFFFu;
-            s_lut[i] = v > 0xFFFFu ? (uint16_t)0xFFFFu : (uint16_t)v;
-        }
     }
     __syncthreads();
-
-    // ---- the window's candidates: heads.  +-1 at the clipped span ends (mod.rs:22-28: every read covering a
-    //      position counts, D/N included).  Two candidates per lane and trip: both loads are in flight together ----
-    for (uint32_t base = 0; base < n_cand; base += 2u * kBlock) {
-        uint2 hh[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t v = base + (uint32_t)u * kBlock + tid;
-            uint32_t r = lo + (v - wn);
-            if (v < wn) r = a.wide_idx[wlo + v];
-            __builtin_assume(r < (1u << 29));
-            hh[u] = make_uint2(0u, 0u);
-            if (v < n_cand) hh[u] = a.heads[r];
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t x = hh[u].x, span = hh[u].y & kHeadSpanMax;
-            const uint32_t e = x + span;
-            // (a head of a cut span may lie past the window; span = 0: no candidate in this slot)
-            if (span && e > W && x < W + (uint32_t)T) {
-                const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
-                uint32_t ib, vb, ie, ve2;
-                if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
-                else {
-                    ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
-                    ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
-                }
-                atomicAdd(&s_raw[ib], vb);
-                if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
-                if (hh[u].y >> 31) {
-                    atomicAdd(&s_low[ib], vb);
-                    if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
-                }
-            }
-        }
-    }
 
     // ---- the window's rows: this wave's groups wv, wv + 4, ... into its counter planes.  The wave number is taken
     //      from a scalar register so that the tests on group numbers are scalar branches: a group slot past the window's
@@ -1124,8 +1115,39 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
             }
         }
     }
+    // ---- the window's candidates.  +-1 at the clipped span ends (mod.rs:22-28: every read covering a position counts,
+    //      D/N included).  The first trip's heads were requested at the top and have arrived behind the rows ----
+    for (uint32_t base = 0;;) {
 #pragma unroll
-    for (int p = 0; p < NP; ++p) s_pl[wv][p][lane] = c[p];
+        for (int u = 0; u < U; ++u) {
+            const uint32_t x = hh[u].x, span = hh[u].y & kHeadSpanMax;
+            const uint32_t e = x + span;
+            // (a head of a cut span may lie past the window; span = 0: no candidate in this slot)
+            if (span && e > W && x < W + (uint32_t)T) {
+                const uint32_t cb = x > W ? x - W : 0u, ce = e - W;
+                uint32_t ib, vb, ie, ve2;
+                if (DEEP) { ib = cb; vb = 1u; ie = ce; ve2 = 0xFFFFFFFFu; }
+                else {
+                    ib = cb >> 1; vb = (cb & 1u) ? 0x10000u : 1u;
+                    ie = ce >> 1; ve2 = (ce & 1u) ? 0xFFFF0000u : 0xFFFFFFFFu;
+                }
+                atomicAdd(&s_raw[ib], vb);
+                if (ce < (uint32_t)T) atomicAdd(&s_raw[ie], ve2);
+                if (hh[u].y >> 31) {
+                    atomicAdd(&s_low[ib], vb);
+                    if (ce < (uint32_t)T) atomicAdd(&s_low[ie], ve2);
+                }
+            }
+        }
+        base += (uint32_t)U * kBlock;
+        if (base >= n_cand) break;
+        load_heads(base, hh);
+    }
+
+    if (wv != 0) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) s_pl[wv - 1][p][lane] = c[p];
+    }
     __syncthreads();
 
     // ---- final phase: depths, low-MAPQ rule, state, counts (8 positions per thread) ----
@@ -1139,7 +1161,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                 uint32_t carry = 0u;
 #pragma unroll
                 for (int p = 0; p < NP; ++p) {
-                    const uint32_t d = s_pl[v][p][lane];
+                    const uint32_t d = s_pl[v - 1][p][lane];
                     const uint32_t s = c[p] ^ d ^ carry;
                     carry = bs_maj(c[p], d, carry);
                     c[p] = s;
@@ -1153,7 +1175,20 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
             s_gt[lane] = a.o.max_depth > 0u ? ~bs_less_than<NP>(c, (unsigned long long)a.o.max_depth + 1ull) : 0u;
             if (DEBUG) {
 #pragma unroll
-                for (int p = 0; p < NP; ++p) s_pl[0][p][lane] = c[p];
+                for (int p = 0; p < NP; ++p) s_dbg[p][lane] = c[p];
+            }
+            // the thresholds of depths 4 lane .. 4 lane + 3, four bytes in the lane's own word
+            {
+                const uint4 lv = reinterpret_cast<const uint4 *>(a.lut)[lane];
+                const uint32_t l4[4] = {lv.x, lv.y, lv.z, lv.w};
+                uint32_t wlut = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t i = 4u * lane + (uint32_t)k;
+                    const uint32_t v = (i >= a.o.min_depth_for_low_mapq && i > 0) ? l4[k] : 0xFFFFFFFFu;
+                    wlut |= (v > 254u ? 255u : v) << (8 * k);
+                }
+                s_pool[256 + lane] = wlut;
             }
         }
         uint32_t vr[PER], vl[PER];
@@ -1176,10 +1211,12 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
         }
         // (a thread's sum of differences may be negative: two's complement in 32 bits, so the two scans stay separate)
         const uint32_t ir = dpp_incl_scan_u32(sr), il = dpp_incl_scan_u32(sl);
-        if (lane == 63) { s_wraw[wv] = ir; s_wlow[wv] = il; }
+        // the wave's totals, for the waves behind it: in the first slot this lane has just consumed
+        constexpr int kSlot = DEEP ? PER : PER / 2;
+        if (lane == 63) { s_raw[tid * kSlot] = ir; s_low[tid * kSlot] = il; }
         __syncthreads();
         uint32_t offr = ir - sr, offl = il - sl;
-        for (uint32_t i = 0; i < wv; ++i) { offr += s_wraw[i]; offl += s_wlow[i]; }
+        for (uint32_t i = 0; i < wv; ++i) { offr += s_raw[(i * 64u + 63u) * kSlot]; offl += s_low[(i * 64u + 63u) * kSlot]; }
         uint32_t mx = 0;
 #pragma unroll
         for (int i = 0; i < PER; ++i) { vr[i] += offr; vl[i] += offl; mx = vr[i] > mx ? vr[i] : mx; }
@@ -1192,7 +1229,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
         const uint32_t gtb = (s_gt[(tid * PER) >> 5] >> ((tid * PER) & 31u)) & FULL;
         // raw_depth > 0, and the low-MAPQ rule (callable_profiler.rs:100-101): the two per-position tests
         uint32_t covb = 0, lowb = 0;
-        if (!DEEP && mx < kLutLds) {
+        if (!DEEP && mx < 255u) {
 #pragma unroll
             for (int i = PER - 1; i >= 0; --i) {
                 const uint32_t raw = vr[i];
@@ -1234,7 +1271,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                 uint32_t qc = 0;
                 const uint32_t bit = ((tid * PER) & 31u) + (uint32_t)i;
 #pragma unroll
-                for (int p = 0; p < NP; ++p) qc |= ((s_pl[0][p][(tid * PER) >> 5] >> bit) & 1u) << p;
+                for (int p = 0; p < NP; ++p) qc |= ((s_dbg[p][(tid * PER) >> 5] >> bit) & 1u) << p;
                 if (a.dbg_raw) a.dbg_raw[p0 + i] = vr[i];
                 if (a.dbg_low) a.dbg_low[p0 + i] = vl[i];
                 if (a.dbg_qc) a.dbg_qc[p0 + i] = qc;

@@ -1268,15 +1268,19 @@ cl_status size_for_extent(cl_ctx *c, uint32_t extent)
     return CL_OK;
 }
 
-// run lists -> intervals, one wave per window; the extra last workgroup reduces the summary
-void launch_rle(cl_ctx *c)
+// what runs behind the pileup kernel: the windows' run lists -> intervals (scan + reduction over the windows, then one
+// wave per window and an extra workgroup for the contig summary)
+void launch_tail(cl_ctx *c)
 {
     const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
+    const uint32_t cap = (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu);
+    const unsigned long long sq = c->form == 3 ? c->dev_sum_q : 0ull, sc = c->form == 3 ? c->dev_sum_cov : 0ull, sm = c->form == 3 ? c->dev_sum_mapq : 0ull;
+    if (n_fin)
+        hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_first_state.p,
+                           c->d_last_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
     hipLaunchKernelGGL((k_rle_write<(int)kT>), dim3((c->n_win + kBlock / 64 - 1) / (kBlock / 64) + 1), dim3(kBlock), 0, c->stream,
                        c->d_runs.p, c->d_first_state.p, c->d_last_state.p, c->d_winpart.p, c->d_win_off.p, c->d_fin.p, n_fin,
-                       c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p,
-                       (uint32_t)std::min<size_t>(c->d_iv.cap, 0xFFFFFFFFu), c->form == 3 ? (unsigned long long)c->dev_sum_q : 0ull,
-                       c->form == 3 ? (unsigned long long)c->dev_sum_cov : 0ull, c->form == 3 ? (unsigned long long)c->dev_sum_mapq : 0ull);
+                       c->d_errflag.p, c->d_summary.p, c->n_win, c->extent, c->d_iv.p, cap, sq, sc, sm);
 }
 
 template <bool DEBUG> void launch_pileup(cl_ctx *c, const PileupArgs &a)
@@ -1331,11 +1335,7 @@ cl_status enqueue(cl_ctx *c, bool debug, uint32_t *dbg_raw, uint32_t *dbg_qc, ui
     a.runtab = c->d_runtab.p; a.rows = c->d_rows.p;
     if (debug) launch_pileup<true>(c, a); else launch_pileup<false>(c, a);
     if (prof) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-    const uint32_t n_fin = (c->n_win + kFinBlock - 1) / kFinBlock;
-    if (n_fin)
-        hipLaunchKernelGGL(k_fin_windows, dim3(n_fin), dim3(kFinBlock), 0, c->stream, c->d_winpart.p, c->d_first_state.p,
-                           c->d_last_state.p, kT, c->n_win, c->extent, c->d_win_off.p, c->d_fin.p);
-    launch_rle(c);
+    launch_tail(c);
     if (prof) {
         HIP_TRY(c, hipEventRecord(ev[4], c->stream));
         c->ev_pending += 1;
@@ -2343,7 +2343,7 @@ static cl_status cl_contig_collect_impl(cl_ctx *c, cl_contig_summary *out, const
         // end, mod.rs:100-101: the extent was sized for that at upload from the ends computed at cl_push_reads)
         if (c->h_sum.n_intervals > c->d_iv.cap) {
             HIP_TRY(c, c->d_iv.reserve(c->h_sum.n_intervals));
-            launch_rle(c);
+            launch_tail(c);
             HIP_TRY(c, hipGetLastError());
         }
         converged = true;

@@ -1503,6 +1503,10 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
     if (w >= n_win) return;
     const uint32_t W = w * (uint32_t)T;
     if (W >= extent) return;
+    // (everything this wave needs is requested at once: the first 64 entries of the run list too -- the list has T slots,
+    // what lies behind its n_inner entries is never used -- so that one memory round trip stands between launch and stores)
+    const uint16_t *rl = runs + (size_t)w * T;
+    const uint32_t e0 = rl[lane];
     const uint32_t n_inner = winpart[w].n_inner;
     const uint32_t seam = (w == 0 || first_state[w] != last_state[w - 1]) ? 1u : 0u;
     // runs before this window: those of the earlier k_fin_windows blocks + the offset inside its block
@@ -1513,9 +1517,8 @@ __global__ __launch_bounds__(kBlock) void k_rle_write(const uint16_t *__restrict
         if (idx0 < iv_cap) { iv[idx0].start = W; iv[idx0].state = first_state[w]; }
         if (idx0 > 0 && idx0 - 1 < iv_cap) iv[idx0 - 1].end = W;
     }
-    const uint16_t *rl = runs + (size_t)w * T;
     for (uint32_t i = lane; i < n_inner; i += 64u) {
-        const uint32_t e = rl[i];
+        const uint32_t e = i < 64u ? e0 : (uint32_t)rl[i];
         const uint32_t idx = idx0 + seam + i, start = W + (e & 0xFFFu);
         if (idx < iv_cap) { iv[idx].start = start; iv[idx].state = e >> 12; }
         if (idx > 0 && idx - 1 < iv_cap) iv[idx - 1].end = start;

@@ -1562,3 +1562,4 @@ def test_spans_cut_into_several_heads(head_span, tmp_path, monkeypatch):
     if head_span in ("37", "1000"):
         rec = synth.long_read_contig(60_000, 8, 17)
         compare([("chrL", 2, 60_000, synth.make_reference(60_000, 3), rec)], None, tmp_path, "heads_long_" + head_span)
+

@@ -1,7 +1,7 @@
 mkdir -p gpurun_out
 L=decodingustools_amd/lib
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "kats or adversarial or heads or shapes or packed or counter_planes or short_reads_2mb or long_reads_indel or deep or random_options" > gpurun_out/r4z_tests.txt 2>&1; echo "pytest rc $?"
+timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "kats or adversarial or empty or multi_contig or resident" > gpurun_out/r4z_tests.txt 2>&1; echo "pytest rc $?"
 tail -3 gpurun_out/r4z_tests.txt
-timeout -k 10 800 python tools/ab_kernel.py --rounds 3 --steps 60 $L/libcallable_hip_base.so $L/libcallable_hip.so > gpurun_out/r4aa_ab.txt 2>&1
-grep "^==" gpurun_out/r4aa_ab.txt
+timeout -k 10 800 python tools/ab_kernel.py --rounds 3 --steps 100 $L/libcallable_hip_base.so $L/libcallable_hip.so > gpurun_out/r4aa_ab.txt 2>&1
+grep "step_ms" gpurun_out/r4aa_ab.txt | cut -c1-90
 grep DIFFERS gpurun_out/r4aa_ab.txt | head -3

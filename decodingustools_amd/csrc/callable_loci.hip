@@ -15,6 +15,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <functional>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -203,6 +204,67 @@ struct PinRing {
         { std::lock_guard<std::mutex> g(own_mu); if (owner == who) owner = nullptr; }
         own_cv.notify_one();
     }
+    // The ring's own threads: started once, asleep between transfers.  (A thread created per transfer had to wait for the
+    // process's address-space lock whenever another thread was giving a few hundred megabytes back to the system --
+    // 26 ms in front of a 3 ms transfer, measured: profiles/r04_first_pass_stages.txt.)
+    struct Crew {
+        std::mutex mu;
+        std::condition_variable cv_job, cv_done;
+        std::vector<std::thread> th;
+        std::function<void(int)> fn;
+        int want = 0, running = 0;
+        uint64_t gen = 0;
+        bool quit = false;
+        void loop(int id)
+        {
+            uint64_t seen = 0;
+            for (;;) {
+                std::function<void(int)> f;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv_job.wait(lk, [&] { return quit || (gen != seen && id < want); });
+                    if (quit) return;
+                    seen = gen; f = fn;
+                }
+                try { f(id); } catch (...) {}
+                { std::lock_guard<std::mutex> g(mu); if (--running == 0) cv_done.notify_all(); }
+            }
+        }
+        // fn(t) for t in [0, n) on the crew's threads; returns at once (wait() joins).  When the system has no thread to
+        // give, the calls run here and now, one after the other.
+        bool ensure_locked(int n)
+        {
+            while ((int)th.size() < n) {
+                const int id = (int)th.size();
+                try { th.emplace_back([this, id] { loop(id); }); } catch (const std::system_error &) { return false; }
+            }
+            return true;
+        }
+        void ensure(int n) { std::lock_guard<std::mutex> g(mu); (void)ensure_locked(n); }   // (at cl_create: none is made inside a transfer)
+        void start(int n, std::function<void(int)> f)
+        {
+            bool have = true;
+            {
+                std::lock_guard<std::mutex> g(mu);
+                have = ensure_locked(n);
+                if (have) { fn = std::move(f); want = n; running = n; ++gen; }
+            }
+            if (have) { cv_job.notify_all(); return; }
+            for (int t = 0; t < n; ++t) { try { f(t); } catch (...) {} }
+        }
+        void wait()
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return running == 0; });
+            fn = nullptr;
+        }
+        ~Crew()
+        {
+            { std::lock_guard<std::mutex> g(mu); quit = true; }
+            cv_job.notify_all();
+            for (std::thread &t : th) if (t.joinable()) t.join();
+        }
+    } crew;
     bool ok = false;
     int slots = 0;                                          // thread slots that have their stream, buffers and events
     // slots [slots, n) are made (by the ring's owner, or at construction); false when the runtime refuses
@@ -224,7 +286,7 @@ struct PinRing {
         }
         return true;
     }
-    explicit PinRing(int dev) : device(dev) { ok = ensure_slots(kCopyThreads); }
+    explicit PinRing(int dev) : device(dev) { ok = ensure_slots(kCopyThreads); if (ok) crew.ensure(kCopyThreads); }
     ~PinRing()
     {
         (void)hipSetDevice(device);
@@ -262,7 +324,7 @@ static std::shared_ptr<PinRing> acquire_ring(int device)
 struct StagingSet {
     RawVec<uint8_t> ref, mapq;
     RawVec<int32_t> pos;
-    RawVec<uint32_t> cigar_off, cigar, end, ck_x, ck_y, rec_cnt;
+    RawVec<uint32_t> cigar_off, cigar, end, ck_x, ck_y, rec_cnt, rec_of;
     RawVec<unsigned long long> qual_off, rb_off;
     RawVec<uint64_t> qbits;
 };
@@ -285,9 +347,11 @@ struct cl_ctx {
     bool own_stream = false;
     uint64_t host_max_end = 0;         // largest pos + reference span over the pushed reads (32-bit clamped spans), for the extent
     std::shared_ptr<PinRing> ring;                    // the device's pinned staging ring (shared by its contexts)
-    std::vector<dut::Thread> copiers;                 // a transfer in flight (joined by ring_finish)
+    bool crew_busy = false;                           // a transfer in flight on the ring's threads (waited for by ring_finish)
+    dut::Thread prealloc;                             // cl_contig_reserve: the device buffers of the contig being pushed, allocated beside the push
     hipError_t copy_err[PinRing::kCopyThreads] = {};
     bool ring_held = false;                           // this context holds the ring's lock (ring_start .. ring_finish)
+    double ring_t0 = 0;                               // DUT_TIMING: when the transfer in flight was started
     // cl_contig_prefetch_qual: quality bytes on their way to d_qual + kQualPad + pf_off before their tile is pushed
     const uint8_t *pf_src = nullptr;
     uint64_t pf_n = 0, pf_off = 0;
@@ -317,7 +381,7 @@ struct cl_ctx {
     // reads whose reference span exceeds kWideSpan (ascending read index = ascending position)
     std::vector<uint32_t> h_wide_idx;
     // short-read form: read i's records are rec[h_rec_of[i] .. h_rec_of[i + 1]) (built at upload, gen_read_recs)
-    std::vector<uint32_t> h_rec_of;
+    RawVec<uint32_t> h_rec_of;            // (pooled with the other staging arrays: 4 bytes per read, written at every upload)
     std::vector<uint32_t> h_wide_rec_of;   // prefix sums of the wide reads' record counts (n_wide + 1 entries)
     uint32_t n_rec = 0;
     std::vector<int32_t> h_wide_pos;
@@ -399,11 +463,13 @@ struct cl_ctx {
     SiteResident site;
 };
 
+static void join_prealloc(cl_ctx *c) { if (c->prealloc.joinable()) c->prealloc.join(); }   // (cl_contig_reserve's helper thread)
+
 static void swap_staging(cl_ctx *c, StagingSet &o)
 {
     c->h_ref.swap(o.ref); c->h_mapq.swap(o.mapq); c->h_pos.swap(o.pos); c->h_cigar_off.swap(o.cigar_off);
     c->h_cigar.swap(o.cigar); c->h_end.swap(o.end); c->h_ck_x.swap(o.ck_x); c->h_ck_y.swap(o.ck_y); c->h_qual_off.swap(o.qual_off);
-    c->h_qbits.swap(o.qbits); c->h_rec_cnt.swap(o.rec_cnt); c->h_rb_off.swap(o.rb_off);
+    c->h_qbits.swap(o.qbits); c->h_rec_cnt.swap(o.rec_cnt); c->h_rb_off.swap(o.rb_off); c->h_rec_of.swap(o.rec_of);
 }
 // a context without staging memory of its own takes a pooled set (cl_contig_begin) ...
 static void take_staging(cl_ctx *c)
@@ -424,7 +490,7 @@ static void give_staging(cl_ctx *c)
     if (!s) return;
     swap_staging(c, *s);
     s->ref.clear(); s->mapq.clear(); s->pos.clear(); s->cigar_off.clear(); s->cigar.clear(); s->end.clear();
-    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear(); s->qbits.clear(); s->rec_cnt.clear(); s->rb_off.clear();
+    s->ck_x.clear(); s->ck_y.clear(); s->qual_off.clear(); s->qbits.clear(); s->rec_cnt.clear(); s->rb_off.clear(); s->rec_of.clear();
     std::lock_guard<std::mutex> g(g_staging_mu);
     if (g_staging.size() < kStagingSets) { g_staging.push_back(std::move(s)); return; }
     size_t small = 0;
@@ -491,37 +557,49 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill, uint64_t ch
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
     PinRing *R = c->ring.get();
+    c->ring_t0 = StageTimer::now();
     R->acquire(c);                                        // another context of this device may be using the ring
     c->ring_held = true;
     const uint64_t CH = chunk_bytes, nch = (n + CH - 1) / CH;
     const int T = PinRing::threads();
     const int nt = (int)std::min<uint64_t>((uint64_t)T, nch);
     for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
-    for (int t = 0; t < nt; ++t) {
-        c->copiers.push_back(dut::spawn_or_run([c, R, dst, n, fill, t, nch, CH, T]() {
+    c->crew_busy = true;
+    R->crew.start(nt, [c, R, dst, n, fill, nch, CH, T](int t) {
+            const bool timing = StageTimer().on;
+            double t_fill = 0, t_issue = 0, t_wait = 0, t0 = timing ? StageTimer::now() : 0.0, ta;
             hipError_t e = hipSetDevice(c->device);
             int k = 0;
             for (uint64_t ch = (uint64_t)t; ch < nch && e == hipSuccess; ch += (uint64_t)T, ++k) {
                 const int b = k & 1;
                 const uint64_t off = ch * CH, len = std::min<uint64_t>(CH, n - off);
+                if (timing) ta = StageTimer::now();
                 if (k >= 2) e = hipEventSynchronize(R->pin_ev[t][b]);           // the buffer's previous transfer is done
                 if (e != hipSuccess) break;
+                if (timing) { const double tb = StageTimer::now(); t_wait += tb - ta; ta = tb; }
                 fill(off, len, R->pin[t][b]);
+                if (timing) { const double tb = StageTimer::now(); t_fill += tb - ta; ta = tb; }
                 e = hipMemcpyAsync(dst + off, R->pin[t][b], len, hipMemcpyHostToDevice, R->copy_stream[t]);
                 if (e == hipSuccess) e = hipEventRecord(R->pin_ev[t][b], R->copy_stream[t]);
+                if (timing) t_issue += StageTimer::now() - ta;
             }
             // the thread's last transfers (one per buffer it used), waited for on their events
+            if (timing) ta = StageTimer::now();
             hipError_t e2 = hipSuccess;
             for (int b = 0; b < 2 && b < k; ++b) { const hipError_t w = hipEventSynchronize(R->pin_ev[t][b]); if (e2 == hipSuccess) e2 = w; }
             c->copy_err[t] = e != hipSuccess ? e : e2;
-        }));
-    }
+            if (timing) {
+                const double t1 = StageTimer::now();
+                fprintf(stderr, "[dut-timing]       ring thread %d: %d buffers, started %.1f ms after the call, fill %.1f, issue %.1f, wait %.1f + %.1f ms\n", t, k,
+                        (t0 - c->ring_t0) * 1e3, t_fill * 1e3, t_issue * 1e3, t_wait * 1e3, (t1 - ta) * 1e3);
+            }
+    });
     return CL_OK;
 }
 
 cl_status ring_finish(cl_ctx *c)
 {
-    c->copiers.clear();                                   // dut::Thread joins in its destructor
+    if (c->crew_busy) { c->ring->crew.wait(); c->crew_busy = false; }   // the ring's threads are done with this transfer
     if (c->ring_held) { c->ring_held = false; c->ring->release(c); }
     for (int t = 0; t < PinRing::kCopyThreads; ++t) HIP_TRY(c, c->copy_err[t]);
     return CL_OK;
@@ -694,7 +772,7 @@ uint64_t rec_chunk_bytes()
 cl_status build_rec_index(cl_ctx *c)
 {
     const size_t n = c->h_pos.size();
-    std::vector<uint32_t> &ro = c->h_rec_of;
+    RawVec<uint32_t> &ro = c->h_rec_of;
     ro.resize(n + 1);
     ro[0] = 0u;
     if (!c->rec_counted) {
@@ -900,8 +978,8 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
         c->ring_held = true;
         if (!R->ensure_slots(nt)) { (void)ring_finish(c); return fail(c, CL_ERR_DEVICE, "cannot extend the pinned staging ring (hipHostMalloc)"); }
         for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
-        for (int t = 0; t < nt; ++t) {
-            c->copiers.push_back(dut::spawn_or_run([&, t]() {
+        c->crew_busy = true;
+        R->crew.start(nt, [&](int t) {
                 hipError_t err = hipSetDevice(c->device);
                 int kb = 0;                                                  // buffers this thread has sent
                 auto cur_buf = [&]() { return reinterpret_cast<uint2 *>(R->pin[t][kb & 1]); };
@@ -992,8 +1070,7 @@ cl_status stream_run_table(cl_ctx *c, std::vector<WinMeta> &win)
                 } catch (...) { if (err == hipSuccess) err = hipErrorOutOfMemory; }
                 for (int b = 0; b < 2 && b < kb; ++b) { const hipError_t e = hipEventSynchronize(R->pin_ev[t][b]); if (err == hipSuccess) err = e; }
                 c->copy_err[t] = err;
-            }));
-        }
+        });
         s = ring_finish(c);
         if (s != CL_OK) return s;
         const uint64_t total = dev_next.load();
@@ -1066,8 +1143,8 @@ cl_status stream_rows(cl_ctx *c, std::vector<WinMeta> &win)
         c->ring_held = true;
         if (!R->ensure_slots(nt)) { (void)ring_finish(c); return fail(c, CL_ERR_DEVICE, "cannot extend the pinned staging ring (hipHostMalloc)"); }
         for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
-        for (int t = 0; t < nt; ++t) {
-            c->copiers.push_back(dut::spawn_or_run([&, t]() {
+        c->crew_busy = true;
+        R->crew.start(nt, [&](int t) {
                 hipError_t err = hipSetDevice(c->device);
                 int kb = 0;                                                  // buffers this thread has sent
                 auto cur_buf = [&]() { return reinterpret_cast<uint32_t *>(R->pin[t][kb & 1]); };
@@ -1143,8 +1220,7 @@ cl_status stream_rows(cl_ctx *c, std::vector<WinMeta> &win)
                 uint32_t seen = max_groups.load();
                 while (seen < my_max && !max_groups.compare_exchange_weak(seen, my_max)) {}
                 c->copy_err[t] = err;
-            }));
-        }
+        });
         s = ring_finish(c);
         if (s != CL_OK) return s;
         const uint64_t total = dev_next.load();
@@ -1415,6 +1491,7 @@ void cl_destroy(cl_ctx *c)
     (void)hipSetDevice(c->device);
     StageTimer tmr;
     drop_prefetch(c);                                     // its copiers write into d_qual: joined before anything is released
+    join_prealloc(c);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     tmr.lap("destroy: sync");
     c->d_pos.release(); c->d_mapq.release();
@@ -1444,7 +1521,7 @@ static cl_status cl_contig_begin_impl(cl_ctx *c, int32_t tid, uint32_t contig_le
     if (!c) return CL_ERR_INVALID;
     if (contig_len > 0xFFF00000u) return fail(c, CL_ERR_RANGE, "contig length beyond the engine's 32-bit range");
     if (ref_len && !ref_bases) return fail(c, CL_ERR_INVALID, "ref_bases is null");
-    if (!c->host_only) drop_prefetch(c);
+    if (!c->host_only) { drop_prefetch(c); join_prealloc(c); }
     take_staging(c);
     c->tid = tid; c->contig_len = contig_len;
     const uint64_t nref = std::min<uint64_t>(ref_len, contig_len);
@@ -1510,6 +1587,27 @@ cl_status cl_contig_prefetch_qual(cl_ctx *c, const uint8_t *qual, uint64_t n_byt
     catch (...) { return fail(c, CL_ERR_INVALID, "internal error"); }
 }
 
+// Pass-bit form: what cl_contig_upload will need on the device is known from the contig's length and the caller's hint --
+// allocated on a thread of its own while the caller admits and pushes the reads (a fresh context spends 15-20 ms of a
+// chr21-sized contig's first pass in hipMalloc otherwise).  Only sizes are guessed here: cl_contig_upload reserves what it
+// needs again and so makes up for a guess that fell short or an allocation that failed.  Joined before any buffer is used.
+static void start_prealloc(cl_ctx *c, uint64_t n_reads, uint64_t n_qual)
+{
+    join_prealloc(c);
+    const uint32_t contig_len = c->contig_len;
+    c->prealloc = dut::spawn_or_run([c, n_reads, n_qual, contig_len]() {
+        if (hipSetDevice(c->device) != hipSuccess) return;
+        const size_t n_win = ((size_t)contig_len + kT - 1) / kT + 1, padded = n_win * kT;
+        (void)c->d_win.reserve(n_win + 1); (void)c->d_win_off.reserve(n_win + 1); (void)c->d_winpart.reserve(n_win + 1);
+        (void)c->d_fin.reserve(n_win / kFinBlock + 2); (void)c->d_runs.reserve(padded + 16);
+        (void)c->d_first_state.reserve(n_win + 1); (void)c->d_last_state.reserve(n_win + 1); (void)c->d_win_wide.reserve(n_win + 1);
+        (void)c->d_refn.reserve(padded / 32 + 4);
+        if (n_reads) (void)c->d_heads.reserve((size_t)n_reads + 1);
+        if (n_qual) (void)c->d_rows.reserve(((n_qual / kT) * 17 / 40 + n_win + 1024) * (dut::kRowGroupWords / 4));   // stream_rows' own estimate
+        if (c->d_iv.cap == 0) (void)c->d_iv.reserve(1u << 20);
+    });
+}
+
 cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes)
 {
     if (!c || !c->in_contig || c->uploaded) return fail(c, CL_ERR_INVALID, "cl_contig_reserve outside cl_contig_begin .. upload");
@@ -1522,7 +1620,10 @@ cl_status cl_contig_reserve(cl_ctx *c, uint64_t n_reads, uint64_t n_cigar_ops, u
     } catch (const std::bad_alloc &) {
         return fail(c, CL_ERR_NOMEM, "host staging allocation failed");
     }
-    if (c->bits) return CL_OK;
+    if (c->bits) {
+        if (!c->host_only && c->h_pos.empty()) start_prealloc(c, n_reads, n_qual_bytes);
+        return CL_OK;
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, c->d_qual.grow_keep(n_qual_bytes + 2 * kQualPad, c->q_dev ? kQualPad + c->q_dev : 0, c->stream));
     return CL_OK;
@@ -2008,6 +2109,7 @@ static cl_status cl_contig_upload_impl(cl_ctx *c)
     if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context (cl_debug_host_create) has no device to upload to");
     HIP_TRY(c, hipSetDevice(c->device));
     drop_prefetch(c);
+    join_prealloc(c);
     c->n_reads = (uint32_t)c->h_pos.size();
     c->n_cigar = c->bits ? c->host_n_ops : c->h_cigar.size();
     if (!c->bits) {
@@ -2396,6 +2498,7 @@ cl_status cl_contig_abort(cl_ctx *c)
     if (!c->host_only) {
         (void)hipSetDevice(c->device);
         drop_prefetch(c);                                 // joins the copiers: nothing reads the caller's buffer any more
+        join_prealloc(c);
         if (c->stream) (void)hipStreamSynchronize(c->stream);
     }
     c->h_pos.clear(); c->h_mapq.clear(); c->h_cigar.clear(); c->h_cigar_off.clear(); c->h_qual_off.clear(); c->h_ref.clear();

@@ -384,9 +384,9 @@ static void dut_stage_time(const char *what, double &t0)
 }
 
 // 64-bit hashes of every record's name (not value-initialised: first touched by the threads that fill it)
-static std::unique_ptr<uint64_t[]> hash_all_names(const dut_records *rec)
+static dut::Scratch<uint64_t> hash_all_names(const dut_records *rec)
 {
-    std::unique_ptr<uint64_t[]> h_buf(new uint64_t[rec->n ? rec->n : 1]);
+    dut::Scratch<uint64_t> h_buf(rec->n ? rec->n : 1);
     if (!rec->qname_off) return h_buf;
     uint64_t *h = h_buf.get();
     NameSet hasher; hasher.rec = rec;
@@ -432,9 +432,9 @@ static uint32_t count_unique_names(const dut_records *rec, const uint8_t *accept
         rstart[kClasses] = rr; bstart[kClasses] = bb;
     }
     const uint64_t total_bytes = bstart[kClasses];
-    std::unique_ptr<uint64_t[]> ch_buf(new uint64_t[nacc]);               // hashes, class by class
-    std::unique_ptr<uint64_t[]> cn_buf(new uint64_t[nacc + 1]);           // offsets of the names in cbytes (global)
-    std::unique_ptr<uint8_t[]> cb_buf(new uint8_t[total_bytes ? total_bytes : 1]);
+    dut::Scratch<uint64_t> ch_buf(nacc);                                  // hashes, class by class
+    dut::Scratch<uint64_t> cn_buf(nacc + 1);                              // offsets of the names in cbytes (global)
+    dut::Scratch<uint8_t> cb_buf(total_bytes ? total_bytes : 1);
     uint64_t *ch = ch_buf.get(), *cn = cn_buf.get();
     uint8_t *cb = cb_buf.get();
     dut::parallel_for(nchunk, 1, [&](size_t c) {
@@ -512,7 +512,7 @@ static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t con
     // reference spans of all reads up front, in parallel (the sequential rule below only compares numbers)
     double tm = dut_now();
     // (not value-initialised: the pages are first touched by the threads that fill them)
-    std::unique_ptr<uint64_t[]> rlen_buf(new uint64_t[rec->n ? rec->n : 1]);
+    dut::Scratch<uint64_t> rlen_buf(rec->n ? rec->n : 1);
     uint64_t *rlen = rlen_buf.get();
     dut::parallel_for(rec->n, dut::grain_for(rec->n, 65536), [&](size_t i) { rlen[i] = ref_length(rec->cigar + rec->cigar_off[i], rec->cigar_off[i + 1] - rec->cigar_off[i]); });
     dut_stage_time("  admit: spans", tm);
@@ -603,7 +603,7 @@ static int dut_admit_reads_impl(const cl_options *opt, int32_t tid, uint32_t con
     dut_stage_time("  admit: cap rule", tm);
     if (n_accepted) *n_accepted = nacc;
     if (n_unique_names) {
-        const std::unique_ptr<uint64_t[]> h = hash_all_names(rec);
+        const dut::Scratch<uint64_t> h = hash_all_names(rec);
         *n_unique_names = count_unique_names(rec, accepted, nacc, h.get());
     }
     return CL_OK;
@@ -652,6 +652,12 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     // should it turn out that it cannot be -- unsorted input, leading reads to drop -- the engine discards the prefetch).
     uint64_t a0 = 0, n_keep = rec->n;
     while (n_keep > 0 && (int64_t)rec->pos[n_keep - 1] >= (int64_t)contig_len) --n_keep;
+    // what is about to be pushed, so that the engine sizes its staging arrays once and has its device buffers allocated
+    // while the reads are admitted (a hint: never required)
+    if (n_keep > 0) {
+        rc = cl_contig_reserve(ctx, n_keep, rec->cigar_off[n_keep], rec->qual_off[n_keep] - rec->qual_off[0]);
+        if (rc != CL_OK) return rc;
+    }
     if (n_keep > 0 && rec->pos[0] >= 0 && rec->qual) {
         rc = cl_contig_prefetch_qual(ctx, rec->qual + rec->qual_off[0], rec->qual_off[n_keep] - rec->qual_off[0]);
         if (rc != CL_OK) return rc;
@@ -660,7 +666,7 @@ static int dut_process_single_contig_runs_impl(cl_ctx *ctx, dut_contig_stats *st
     std::vector<uint8_t> acc(rec->n ? rec->n : 1);
     uint32_t n_names = 0; uint64_t n_acc = 0;
     // the names' hashes do not depend on the admission: beside it, on their own thread
-    std::unique_ptr<uint64_t[]> name_hash;
+    dut::Scratch<uint64_t> name_hash;
     bool hashed = false;
     dut::Thread hasher = dut::spawn_or_run([&]() { name_hash = hash_all_names(rec); hashed = true; });
     rc = dut_admit_reads(opt, tid, contig_len, rec, acc.data(), nullptr, &n_acc);

@@ -8,6 +8,8 @@
 #include <cstdlib>
 #include <exception>
 #include <mutex>
+#include <new>
+#include <utility>
 #include <system_error>
 #include <thread>
 #include <vector>
@@ -221,5 +223,69 @@ Thread spawn_or_run(F fn)
     guarded();
     return Thread();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Large temporaries of the per-contig host stages (reference spans, name hashes, the buckets of the name count: some
+// 450 MB for a chr21-sized contig).  Taken from malloc, each would be mapped, faulted in page by page and unmapped
+// again for every contig -- and an unmap of that size holds the address-space lock against every other thread that
+// wants a page or a stack meanwhile.  A few blocks are kept here from one contig to the next instead (at most
+// kScratchKeep blocks; the smallest one goes when a larger one comes back).
+// ---------------------------------------------------------------------------------------------
+struct ScratchPool {
+    static constexpr size_t kScratchKeep = 8;
+    static constexpr size_t kMinPooled = 1u << 20;          // smaller blocks are plain malloc / free
+    std::mutex mu;
+    std::vector<std::pair<void *, size_t>> idle;
+    void *take(size_t bytes, size_t *cap)
+    {
+        if (bytes >= kMinPooled) {
+            std::lock_guard<std::mutex> g(mu);
+            size_t best = idle.size();
+            for (size_t i = 0; i < idle.size(); ++i)
+                if (idle[i].second >= bytes && (best == idle.size() || idle[i].second < idle[best].second)) best = i;
+            if (best != idle.size()) {
+                void *p = idle[best].first; *cap = idle[best].second;
+                idle.erase(idle.begin() + (long)best);
+                return p;
+            }
+        }
+        const size_t want = bytes >= kMinPooled ? bytes + bytes / 8 : bytes;      // (a little room: the next contig is rarely the same size)
+        *cap = want;
+        return malloc(want ? want : 1);
+    }
+    void give(void *p, size_t cap)
+    {
+        if (!p) return;
+        if (cap >= kMinPooled) {
+            std::lock_guard<std::mutex> g(mu);
+            if (idle.size() < kScratchKeep) { idle.emplace_back(p, cap); return; }
+            size_t small = 0;
+            for (size_t i = 1; i < idle.size(); ++i) if (idle[i].second < idle[small].second) small = i;
+            if (idle[small].second < cap) { void *q = idle[small].first; idle[small] = std::make_pair(p, cap); p = q; }
+        }
+        free(p);                                            // the block that was not kept
+    }
+};
+inline ScratchPool &scratch_pool() { static ScratchPool *p = new ScratchPool(); return *p; }   // (never destroyed: threads may outlive main)
+
+template <class T> class Scratch {
+    T *p_ = nullptr;
+    size_t cap_ = 0;
+public:
+    Scratch() = default;
+    explicit Scratch(size_t n)
+    {
+        p_ = static_cast<T *>(scratch_pool().take((n ? n : 1) * sizeof(T), &cap_));
+        if (!p_) throw std::bad_alloc();
+    }
+    Scratch(Scratch &&o) noexcept : p_(o.p_), cap_(o.cap_) { o.p_ = nullptr; o.cap_ = 0; }
+    Scratch &operator=(Scratch &&o) noexcept { if (this != &o) { reset(); p_ = o.p_; cap_ = o.cap_; o.p_ = nullptr; o.cap_ = 0; } return *this; }
+    Scratch(const Scratch &) = delete;
+    Scratch &operator=(const Scratch &) = delete;
+    ~Scratch() { reset(); }
+    void reset() { if (p_) scratch_pool().give(p_, cap_); p_ = nullptr; cap_ = 0; }
+    T *get() const { return p_; }
+    explicit operator bool() const { return p_ != nullptr; }
+};
 
 } // namespace dut

@@ -1013,7 +1013,6 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     constexpr int PER = T / kBlock;
     static_assert((PER == 8 || PER == 16) && T == 2048, "a lane owns a block of 32 positions: T = 64 x 32");
     constexpr int kWaves = kBlock / 64;
-    constexpr uint32_t kLutLds = 256;
     constexpr int kDiffWords = DEEP ? T : T / 2;
     constexpr int G = BS == 128 ? 6 : 4;                   // groups a wave has in flight: 12 / 16 per window before a second trip
     __shared__ __attribute__((aligned(16))) uint32_t s_raw[kDiffWords];

@@ -123,7 +123,9 @@ const char *cl_last_error(const cl_ctx *ctx);
 cl_status cl_contig_begin(cl_ctx *ctx, int32_t tid, uint32_t contig_len,
                           const uint8_t *ref_bases, uint64_t ref_len);
 /* Optional size hint for the contig that was just begun: totals over all tiles that will be pushed.
- * Saves regrowing the staging / device buffers; never required. */
+ * Saves regrowing the staging / device buffers; never required.  Given before the first tile, it also lets the engine
+ * allocate the contig's device buffers on a thread of its own while the caller admits and pushes the reads
+ * (cl_contig_upload, cl_contig_abort, cl_contig_begin and cl_destroy wait for that thread). */
 cl_status cl_contig_reserve(cl_ctx *ctx, uint64_t n_reads, uint64_t n_cigar_ops, uint64_t n_qual_bytes);
 /* Optional, byte forms only (DUT_QUAL_FORM=bytes; a no-op in the default pass-bit form, where no quality byte goes to
  * the device): starts sending quality bytes to the device before their tile is pushed, so that the transfer runs

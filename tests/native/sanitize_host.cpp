@@ -43,6 +43,7 @@ cl_status cl_push_reads_bits(cl_ctx *c, const cl_read_tile_bits *t)
     return CL_OK;
 }
 cl_status cl_contig_prefetch_qual(cl_ctx *, const uint8_t *, uint64_t) { return CL_OK; }
+cl_status cl_contig_reserve(cl_ctx *, uint64_t, uint64_t, uint64_t) { return CL_OK; }
 cl_status cl_contig_finish(cl_ctx *c, cl_contig_summary *s, const cl_interval **iv, size_t *n)
 {
     memset(s, 0, sizeof(*s));

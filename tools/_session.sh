@@ -1,7 +1,6 @@
 mkdir -p gpurun_out
-L=decodingustools_amd/lib
-timeout -k 10 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "kats or adversarial or empty or multi_contig or resident" > gpurun_out/r4z_tests.txt 2>&1; echo "pytest rc $?"
+timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r4z_tests.txt 2>&1; echo "pytest rc $?"
 tail -3 gpurun_out/r4z_tests.txt
-timeout -k 10 800 python tools/ab_kernel.py --rounds 3 --steps 100 $L/libcallable_hip_base.so $L/libcallable_hip.so > gpurun_out/r4aa_ab.txt 2>&1
-grep "step_ms" gpurun_out/r4aa_ab.txt | cut -c1-90
-grep DIFFERS gpurun_out/r4aa_ab.txt | head -3
+timeout -k 10 600 python tools/first_pass.py > gpurun_out/r4ac_first_pass.txt 2>&1
+grep "====.*ms" gpurun_out/r4ac_first_pass.txt
+awk '/==== engine 1 pass 0$/,/==== engine 1 pass 0:/' gpurun_out/r4ac_first_pass.txt | grep -v "collect\|finish: run\|order\|patched\|ring thread"

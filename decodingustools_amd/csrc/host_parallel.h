@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdint>
 #include <cstdlib>
 #include <exception>
 #include <mutex>
@@ -15,6 +16,7 @@
 #include <vector>
 
 #include <pthread.h>
+#include <cstring>
 #include <sched.h>
 #include <cstdio>
 
@@ -229,7 +231,9 @@ Thread spawn_or_run(F fn)
 // 450 MB for a chr21-sized contig).  Taken from malloc, each would be mapped, faulted in page by page and unmapped
 // again for every contig -- and an unmap of that size holds the address-space lock against every other thread that
 // wants a page or a stack meanwhile.  A few blocks are kept here from one contig to the next instead (at most
-// kScratchKeep blocks; the smallest one goes when a larger one comes back).
+// kScratchKeep blocks; the smallest one goes when a larger one comes back).  (Asking for transparent huge pages for
+// these and the staging arrays instead -- MADV_HUGEPAGE, which this pool's boxes honour -- made a fresh process slower,
+// not faster: the BAM reader's parse 70 -> 350 ms, profiles/r04_first_pass_stages.txt.)
 // ---------------------------------------------------------------------------------------------
 struct ScratchPool {
     static constexpr size_t kScratchKeep = 8;

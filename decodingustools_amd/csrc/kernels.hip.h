@@ -960,14 +960,21 @@ __global__ __launch_bounds__(kBlock, DEEP ? 4 : CL_MINWAVES) void k_pileup(Pileu
 // owns a block of 32 positions, a wave streams whole groups of 4 rows (one 16-byte load per lane, 1 KB per wave
 // instruction, no address arithmetic, no masks, no shifts), and adds them into NP counter planes (plane k = bit k of
 // the 32 counts) with carry-save adders: three-input boolean operations (v_bitop3), about 4.5 instructions per row
-// for 32 positions.  No LDS atomics, no CIGAR, no offsets.  The four waves' planes are added by wave 0 and compared --
-// still bit-sliced -- with min_depth and max_depth (callable_profiler.rs:108-113): two 32-bit masks per block, which
-// the final phase expands to the bytes of its byte-parallel classification.  quality_bases is the number of set bits
-// (contig_profiler.rs:71); summed_baseq comes with the bits from the host's walk (contig_profiler.rs:70, per-read
-// separable: SURVEY 8a-7).
+// for 32 positions.  No LDS atomics, no CIGAR, no offsets.  The other waves' planes are added by wave 0 and compared --
+// still bit-sliced -- with min_depth and max_depth (callable_profiler.rs:108-113): two 32-bit masks per block.
+// quality_bases is the number of set bits (contig_profiler.rs:71: taken from the planes, sum of 2^p x popcount);
+// summed_baseq comes with the bits from the host's walk (contig_profiler.rs:70, per-read separable: SURVEY 8a-7).
 //
-// The window's candidates are head records (ReadRec, one per read with a reference span): the +-1 scatter of raw_depth
-// and low_mapq_count (mod.rs:22-28) and the owner sums, exactly as in the record form of k_pileup.
+// The window's candidates are heads (8 bytes, one per read with a reference span; above): the +-1 scatter of raw_depth
+// and low_mapq_count (mod.rs:22-28) into difference arrays in LDS, nothing else -- the reads' other separable sums
+// (summed_coverage, summed_mapq) come from the host's walk too.
+//
+// The final phase works in the BIT DOMAIN: per position only the two tests that need the position's integers (raw_depth
+// > 0; the low-MAPQ rule, callable_profiler.rs:100-101) are taken, each leaving one bit; from there a thread's PER
+// positions are PER bits of a register -- the reference's N bits (one bit per position in HBM), the two compare masks,
+// the priorities of callable_profiler.rs:104-116 as boolean operations on masks, the state as three bit planes, the
+// state counts as popcounts, run boundaries as planes ^ (planes << 1 | previous state), the run list by a loop over the
+// set bits of the boundary mask.
 //
 // NP: counter planes -- 8 while no window has more than 255 rows (63 groups), 16 up to 65 535, else 32.
 // DEEP: 32-bit difference words (a window with more than 32 767 candidates), as in k_pileup.

@@ -1,6 +1,4 @@
 mkdir -p gpurun_out
-timeout -k 10 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu > gpurun_out/r4z_tests.txt 2>&1; echo "pytest rc $?"
-tail -3 gpurun_out/r4z_tests.txt
-timeout -k 10 600 python tools/first_pass.py > gpurun_out/r4ac_first_pass.txt 2>&1
-grep "====.*ms" gpurun_out/r4ac_first_pass.txt
-awk '/==== engine 1 pass 0$/,/==== engine 1 pass 0:/' gpurun_out/r4ac_first_pass.txt | grep -v "collect\|finish: run\|order\|patched\|ring thread"
+rm -rf gpurun_out/prof_trace gpurun_out/prof_fetch gpurun_out/prof_write gpurun_out/prof_sq1 gpurun_out/prof_sq2 gpurun_out/prof_sq3 gpurun_out/prof_longread_trace gpurun_out/prof_site_trace
+bash tools/profile_round.sh > gpurun_out/r4_profile_round.log 2>&1; echo "profile_round rc $?"
+tail -30 gpurun_out/r4_profile_round.log

@@ -15,7 +15,7 @@ ks = newest(os.path.join(G, "prof_trace", "**", "*_kernel_stats.csv").replace("*
 if ks:
     shutil.copy(ks, os.path.join(P, f"{tag}_kernel_stats.csv"))
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in ("prof_fetch", "prof_write", "prof_sq1", "prof_sq2"):
+for d in ("prof_fetch", "prof_write", "prof_sq1", "prof_sq2", "prof_sq3"):
     f = newest(os.path.join(G, d, "*", "*_counter_collection.csv"))
     if not f:
         continue

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <exception>
+#include <functional>
 #include <mutex>
 #include <new>
 #include <utility>
@@ -225,6 +226,68 @@ Thread spawn_or_run(F fn)
     guarded();
     return Thread();
 }
+
+// A crew of threads that is started once and sleeps between jobs: start(n, fn) runs fn(t) for t in [0, n) on n of them
+// and returns at once, wait() returns when all are done.  One job at a time (the pinned staging ring, which owns one,
+// is held by one transfer at a time).
+struct Crew {
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::vector<std::thread> th;
+    std::function<void(int)> fn;
+    int want = 0, running = 0;
+    uint64_t gen = 0;
+    bool quit = false;
+    void loop(int id)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return quit || (gen != seen && id < want); });
+                if (quit) return;
+                seen = gen; f = fn;
+            }
+            try { f(id); } catch (...) {}
+            { std::lock_guard<std::mutex> g(mu); if (--running == 0) cv_done.notify_all(); }
+        }
+    }
+    // fn(t) for t in [0, n) on the crew's threads; returns at once (wait() joins).  When the system has no thread to
+    // give, the calls run here and now, one after the other.
+    bool ensure_locked(int n)
+    {
+        while ((int)th.size() < n) {
+            const int id = (int)th.size();
+            try { th.emplace_back([this, id] { loop(id); }); } catch (const std::system_error &) { return false; }
+        }
+        return true;
+    }
+    void ensure(int n) { std::lock_guard<std::mutex> g(mu); (void)ensure_locked(n); }   // (at cl_create: none is made inside a transfer)
+    void start(int n, std::function<void(int)> f)
+    {
+        bool have = true;
+        {
+            std::lock_guard<std::mutex> g(mu);
+            have = ensure_locked(n);
+            if (have) { fn = std::move(f); want = n; running = n; ++gen; }
+        }
+        if (have) { cv_job.notify_all(); return; }
+        for (int t = 0; t < n; ++t) { try { f(t); } catch (...) {} }
+    }
+    void wait()
+    {
+        std::unique_lock<std::mutex> lk(mu);
+        cv_done.wait(lk, [&] { return running == 0; });
+        fn = nullptr;
+    }
+    ~Crew()
+    {
+        { std::lock_guard<std::mutex> g(mu); quit = true; }
+        cv_job.notify_all();
+        for (std::thread &t : th) if (t.joinable()) t.join();
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // Large temporaries of the per-contig host stages (reference spans, name hashes, the buckets of the name count: some

@@ -307,6 +307,31 @@ int main(int argc, char **argv)
         }
         printf("worker pool: three callers, nested loops, total %llu\n", (unsigned long long)total.load());
     }
+    // the crew of the pinned ring (host_parallel.h: started once, asleep between jobs) and the pool of large temporaries:
+    // jobs of changing width back to back, each index exactly once; blocks taken and given back from several threads
+    {
+        dut::Crew crew;
+        crew.ensure(3);
+        unsigned long long ran = 0;
+        for (int rep = 0; rep < 200; ++rep) {
+            const int n = 1 + (rep * 7) % 9;
+            std::vector<std::atomic<int>> hit(9);
+            for (auto &h : hit) h.store(0);
+            crew.start(n, [&](int t) { hit[(size_t)t].fetch_add(1); });
+            crew.wait();
+            for (int t = 0; t < 9; ++t) { if (hit[(size_t)t].load() != (t < n ? 1 : 0)) { printf("crew: job %d ran index %d %d time(s)\n", rep, t, hit[(size_t)t].load()); return 7; } ran += (unsigned long long)hit[(size_t)t].load(); }
+        }
+        std::atomic<unsigned long long> bytes{0};
+        dut::parallel_for(64, 1, [&](size_t i) {
+            dut::Scratch<uint64_t> a((1u << 17) + 1000 * i), b(100 + i);          // one pooled (>= 1 MB), one not
+            a.get()[0] = i; a.get()[(1u << 17) + 1000 * i - 1] = i; b.get()[99 + i] = i;
+            bytes.fetch_add(a.get()[0] + b.get()[99 + i]);
+            dut::Scratch<uint64_t> c(std::move(a));
+            if (a || !c) abort();
+        });
+        // (how many blocks the pool holds now depends on how the threads interleaved: not printed)
+        printf("crew: %llu calls over 200 jobs; scratch pool: checksum %llu, %s\n", ran, bytes.load(), dut::scratch_pool().idle.size() <= dut::ScratchPool::kScratchKeep ? "within its limit" : "OVER ITS LIMIT");
+    }
     // summary JSON with awkward names
     dut_contig_stats st[2]; memset(st, 0, sizeof(st));
     st[0].length = 20; st[0].n_covered_bases = 12; st[0].summed_coverage = 22; st[0].summed_baseq = 420; st[0].summed_mapq = 960; st[0].quality_bases = 14; st[0].n_reads = 3;

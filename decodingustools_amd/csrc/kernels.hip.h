@@ -1236,12 +1236,16 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
         // raw_depth > 0, and the low-MAPQ rule (callable_profiler.rs:100-101): the two per-position tests
         uint32_t covb = 0, lowb = 0;
         if (!DEEP && mx < 255u) {
+            // two instructions per test: a difference whose sign bit says "no" (raw - 1 wraps when raw == 0; low - lut
+            // is negative when low < lut: all are below 2^31), shifted into the mask by v_alignbit ({mask, d} >> 31)
+            uint32_t ncov = 0, nlow = 0;
 #pragma unroll
             for (int i = PER - 1; i >= 0; --i) {
                 const uint32_t raw = vr[i];
-                covb = covb + covb + (raw < 1u ? raw : 1u);
-                lowb = lowb + lowb + (vl[i] >= (uint32_t)s_lut[raw] ? 1u : 0u);
+                ncov = __builtin_amdgcn_alignbit(ncov, raw - 1u, 31);
+                nlow = __builtin_amdgcn_alignbit(nlow, vl[i] - (uint32_t)s_lut[raw], 31);
             }
+            covb = ~ncov & FULL; lowb = ~nlow & FULL;
         } else {
 #pragma unroll
             for (int i = PER - 1; i >= 0; --i) {

@@ -466,7 +466,9 @@ def site_config(dev_id, opt, args, cache_dir):
             calls.append(time.perf_counter() - t0)
             kms_, nb = eng.site_pileup_stats()
             ms_all.append(kms_)
-        # the tile is resident now: another site list (here the same one) costs a run only
+        # the two-step form: the whole tile resident (cl_site_upload), another site list (here the same one) costs a run only
+        # (the one-call form above sends only the reads that overlap a site of its list: its tile serves that call alone)
+        eng.site_upload(L, L, rec)
         t0 = time.perf_counter()
         hist2 = eng.site_run(20, sites)
         rerun = time.perf_counter() - t0

@@ -281,6 +281,7 @@ struct SiteResident {
     uint64_t n = 0, ncig = 0, nbase = 0, ref_len = 0;
     uint32_t contig_len = 0;
     bool resident = false;
+    bool filtered = false;           // the resident tile holds only the reads that overlap a site of the list it was uploaded for (cl_site_pileup)
     void release() { rec.release(); seq.release(); cig.release(); p0.release(); ix.release(); hist.release(); bk.release(); base.release(); resident = false; }
 };
 
@@ -495,7 +496,7 @@ cl_status ensure_pins(cl_ctx *c)
 // n bytes to `dst` through the ring: fill(off, len, out) writes the bytes [off, off + len) of the transfer into the
 // pinned buffer `out`.  Chunks are dealt round-robin to the copier threads.  Returns at once; ring_finish joins.
 template <class Fill>
-cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill, uint64_t chunk_bytes = PinRing::kPinBytes)
+cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill, uint64_t chunk_bytes = PinRing::kPinBytes, int want_threads = 0)
 {
     cl_status s = ensure_pins(c);
     if (s != CL_OK) return s;
@@ -504,7 +505,9 @@ cl_status ring_start(cl_ctx *c, uint8_t *dst, uint64_t n, Fill fill, uint64_t ch
     R->acquire(c);                                        // another context of this device may be using the ring
     c->ring_held = true;
     const uint64_t CH = chunk_bytes, nch = (n + CH - 1) / CH;
-    const int T = PinRing::threads();
+    // (plain copies saturate the link with DUT_COPY_THREADS buffers in flight; a fill that gathers small pieces is bound by
+    // the fill and asks for all of the ring's pairs)
+    const int T = want_threads > 0 ? std::min(want_threads, std::max(1, R->slots)) : PinRing::threads();
     const int nt = (int)std::min<uint64_t>((uint64_t)T, nch);
     for (int t = 0; t < PinRing::kCopyThreads; ++t) c->copy_err[t] = hipSuccess;
     c->crew_busy = true;
@@ -2561,80 +2564,23 @@ cl_status cl_debug_depths(cl_ctx *c, uint32_t *raw, uint32_t *qc, uint32_t *low,
 }
 
 
-// ---- config 5: the tile goes to HBM once (cl_site_upload: packed records built straight into the pinned buffers, the
-//      4-bit bases and the CIGAR words through the staging ring) and stays resident; any number of site lists can then be
-//      run over it (cl_site_run).  cl_site_pileup is the two in one call. ----
-static cl_status cl_site_upload_impl(cl_ctx *c, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *t)
-{
-    if (!c || !t) return CL_ERR_INVALID;
-    if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context has no device");
-    HIP_TRY(c, hipSetDevice(c->device));
-    drop_prefetch(c);                                        // the ring is needed below
-    SiteResident &S = c->site;
-    S.resident = false;
-    const uint64_t n = t->n_reads;
-    if (n > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "too many reads");
-    if (n && (!t->pos || !t->mapq || !t->cigar_off || !t->seq_off)) return fail(c, CL_ERR_INVALID, "null tile array");
-    StageTimer tmr;
-    {
-        std::atomic<int> bad{0};
-        dut::parallel_for(n, 262144, [&](size_t i) { if (t->cigar_off[i + 1] < t->cigar_off[i] || t->seq_off[i + 1] < t->seq_off[i]) bad = 1; });
-        if (bad) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
-    }
-    const uint64_t ncig = n ? t->cigar_off[n] : 0, nbase = n ? t->seq_off[n] : 0;
-    const uint64_t n_blocks = (n + kBlock - 1) / kBlock;
-    // a workgroup's reads must lie within 2^32 bases of its first one (256 reads: always, short of 16 M-base reads)
-    for (uint64_t b = 0; b < n_blocks; ++b)
-        if (t->seq_off[std::min<uint64_t>(n, (b + 1) * kBlock)] - t->seq_off[b * kBlock] > 0xFFFF0000ull)
-            return fail(c, CL_ERR_RANGE, "reads too long for the site pileup");
-    HIP_TRY(c, S.rec.reserve(n + 1)); HIP_TRY(c, S.base.reserve(n_blocks + 1));
-    HIP_TRY(c, S.cig.reserve(ncig + 8)); HIP_TRY(c, S.seq.reserve((nbase + 1) / 2 + 16));
-    tmr.lap("site upload: checks + device buffers");
-    cl_status rs = CL_OK;
-    // the bases: the bulk of the tile (0.5 byte per aligned base)
-    if (nbase && (rs = ring_copy(c, S.seq.p, t->seq4, (nbase + 1) / 2)) != CL_OK) return rs;
-    tmr.lap("site upload: bases");
-    // one packed record per read (+ the sentinel with the totals), built in the pinned buffers
-    {
-        const int32_t *hp = t->pos; const uint8_t *hm = t->mapq; const uint32_t *hc = t->cigar_off; const uint64_t *hs = t->seq_off;
-        rs = ring_start(c, reinterpret_cast<uint8_t *>(S.rec.p), (n + 1) * sizeof(SiteRec), [hp, hm, hc, hs, n](uint64_t off, uint64_t len, uint8_t *out) {
-            SiteRec *o = reinterpret_cast<SiteRec *>(out);
-            const size_t i0 = off / sizeof(SiteRec), i1 = (off + len) / sizeof(SiteRec);
-            for (size_t i = i0; i < i1; ++i) {
-                SiteRec r;
-                if (i < n) {
-                    const uint32_t nc = hc[i + 1] - hc[i];
-                    const uint64_t sl = hs[i + 1] - hs[i];
-                    r.pos = hp[i]; r.cigar_off = hc[i]; r.seq_lo = (uint32_t)hs[i];
-                    r.meta = (uint32_t)hm[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<uint64_t>(sl, 0xFFFFull) << 16);
-                } else { r.pos = 0; r.cigar_off = n ? hc[n] : 0u; r.seq_lo = n ? (uint32_t)hs[n] : 0u; r.meta = 0; }
-                o[i - i0] = r;
-            }
-        });
-        // ... beside it, the 64-bit base offset of every workgroup's first read
-        std::vector<unsigned long long> h_base(n_blocks + 1);
-        for (uint64_t b = 0; b < n_blocks; ++b) h_base[b] = t->seq_off[b * kBlock];
-        h_base[n_blocks] = nbase;
-        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
-        if (rs != CL_OK) return rs;
-        HIP_TRY(c, hipMemcpyAsync(S.base.p, h_base.data(), (n_blocks + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-    }
-    if (ncig && (rs = ring_copy(c, S.cig.p, t->cigar, ncig * 4)) != CL_OK) return rs;
-    tmr.lap("site upload: records + cigar");
-    S.n = n; S.ncig = ncig; S.nbase = nbase; S.contig_len = contig_len; S.ref_len = ref_len;
-    S.resident = true;
-    return CL_OK;
-}
-
 // the site list as the kernel wants it: sorted by 0-based position (vcf_pos - 1, caller.rs:94) with the original
 // indices, vcf_pos 0 left out (it can never match), and the first sorted site at or after every 256th position
 struct SitePrep { std::vector<uint32_t> pos0, idx, bucket; uint32_t n_buckets = 0; };
 static void site_prepare(const uint32_t *sites, size_t n_sites, SitePrep &P)
 {
-    std::vector<unsigned long long> key(n_sites);
+    // (position, original index) sorted by position, ties by index: a stable radix sort on the 32-bit positions, three
+    // passes of 11 bits (std::sort took 10 of the 11 ms of a run on a resident tile with 200 000 sites)
+    std::vector<unsigned long long> key(n_sites), tmp(n_sites);
     for (size_t i = 0; i < n_sites; ++i) key[i] = ((unsigned long long)sites[i] << 32) | (unsigned long long)i;
-    std::sort(key.begin(), key.end());
+    for (int pass = 0; pass < 3; ++pass) {
+        const int sh = 32 + 11 * pass;
+        size_t cnt[2049] = {0};
+        for (size_t i = 0; i < n_sites; ++i) cnt[((key[i] >> sh) & 2047u) + 1] += 1;
+        for (int b = 0; b < 2048; ++b) cnt[b + 1] += cnt[b];
+        for (size_t i = 0; i < n_sites; ++i) tmp[cnt[(key[i] >> sh) & 2047u]++] = key[i];
+        key.swap(tmp);
+    }
     P.pos0.reserve(n_sites); P.idx.reserve(n_sites);
     for (size_t i = 0; i < n_sites; ++i) {
         const uint32_t s = (uint32_t)(key[i] >> 32);
@@ -2651,12 +2597,196 @@ static void site_prepare(const uint32_t *sites, size_t n_sites, SitePrep &P)
     }
 }
 
+
+// cl_site_pileup knows the site list when the tile is uploaded: only the reads that can add to the histogram travel --
+// those the kernel itself would walk (k_site_pileup: position inside the contig, mapq >= min_quality, a site inside
+// [pos, pos + reference span)); at one site per ~300 bases that is two short reads in five, and the bases are what the
+// call spends its time sending (1.1 GB at the link's rate for BASELINE configs[4]).  The kept reads' records, CIGAR words
+// and base BYTES are gathered straight into the pinned buffers; a read keeps its nibble parity (its bytes are copied
+// whole), so read lengths can no longer be taken from offset differences: tiles with a read of 65 535 bases or 255
+// operations and more (the records' escape values) are sent whole instead.
+struct SiteGather {
+    dut::Scratch<uint32_t> kidx;               // kept read k = read kidx[k] of the tile
+    dut::Scratch<unsigned long long> B;        // K + 1: first byte of kept read k in the gathered base array
+    dut::Scratch<uint32_t> coff;               // K + 1: first CIGAR word of kept read k in the gathered CIGAR array
+    uint64_t K = 0;
+    bool on = false;
+};
+static void site_filter(const cl_site_tile *t, const SitePrep &P, uint8_t min_quality, uint32_t contig_len, SiteGather &G)
+{
+    const uint64_t n = t->n_reads;
+    G.on = false;
+    if (n == 0 || P.pos0.empty()) return;
+    const size_t grain = 1u << 16, nchunk = (n + grain - 1) / grain;
+    dut::Scratch<uint8_t> keep(n);
+    std::vector<uint64_t> c_k(nchunk + 1, 0), c_b(nchunk + 1, 0), c_c(nchunk + 1, 0);
+    std::atomic<bool> escape{false};
+    const uint32_t *pos0 = P.pos0.data(); const uint32_t *bucket = P.bucket.data();
+    const uint32_t n_sites = (uint32_t)P.pos0.size(), n_buckets = P.n_buckets;
+    uint8_t *kp = keep.get();
+    dut::parallel_for(nchunk, 1, [&](size_t ch) {
+        const size_t a = ch * grain, b = std::min<size_t>(n, a + grain);
+        uint64_t k = 0, nb = 0, nc = 0;
+        for (size_t i = a; i < b; ++i) {
+            kp[i] = 0;
+            const uint32_t c0 = t->cigar_off[i], c1 = t->cigar_off[i + 1];
+            const uint64_t s0 = t->seq_off[i], s1 = t->seq_off[i + 1];
+            if (c1 < c0 || s1 < s0) { escape.store(true); continue; }          // (refused by the upload's own check)
+            if (c1 - c0 >= 255u || s1 - s0 >= 0xFFFFull) escape.store(true);
+            if ((uint32_t)t->pos[i] >= contig_len || t->mapq[i] < min_quality) continue;
+            unsigned long long reflen = 0;
+            for (uint32_t q = c0; q < c1; ++q) { const uint32_t cw = t->cigar[q]; reflen += ((0x18Du >> (cw & 15u)) & 1u) ? (cw >> 4) : 0u; }
+            const unsigned long long x = (uint32_t)t->pos[i];
+            const unsigned long long bx = x >> 8;
+            uint32_t lo = bx < n_buckets ? bucket[bx] : n_sites;
+            while (lo < n_sites && pos0[lo] < x) ++lo;
+            if (lo < n_sites && pos0[lo] < x + reflen) { kp[i] = 1; ++k; nb += ((s1 + 1) >> 1) - (s0 >> 1); nc += c1 - c0; }
+        }
+        c_k[ch + 1] = k; c_b[ch + 1] = nb; c_c[ch + 1] = nc;
+    });
+    if (escape.load()) return;
+    for (size_t ch = 0; ch < nchunk; ++ch) { c_k[ch + 1] += c_k[ch]; c_b[ch + 1] += c_b[ch]; c_c[ch + 1] += c_c[ch]; }
+    const uint64_t K = c_k[nchunk];
+    if (c_c[nchunk] > 0xFFFFFFF0ull) return;
+    G.kidx = dut::Scratch<uint32_t>(K + 1); G.B = dut::Scratch<unsigned long long>(K + 1); G.coff = dut::Scratch<uint32_t>(K + 1);
+    uint32_t *kidx = G.kidx.get(); unsigned long long *B = G.B.get(); uint32_t *coff = G.coff.get();
+    dut::parallel_for(nchunk, 1, [&](size_t ch) {
+        const size_t a = ch * grain, b = std::min<size_t>(n, a + grain);
+        uint64_t k = c_k[ch], nb = c_b[ch], nc = c_c[ch];
+        for (size_t i = a; i < b; ++i) {
+            if (!kp[i]) continue;
+            kidx[k] = (uint32_t)i; B[k] = nb; coff[k] = (uint32_t)nc;
+            nb += ((t->seq_off[i + 1] + 1) >> 1) - (t->seq_off[i] >> 1); nc += t->cigar_off[i + 1] - t->cigar_off[i];
+            ++k;
+        }
+    });
+    kidx[K] = 0; B[K] = c_b[nchunk]; coff[K] = (uint32_t)c_c[nchunk];
+    G.K = K; G.on = true;
+}
+
+// ---- config 5: the tile goes to HBM once (cl_site_upload: packed records built straight into the pinned buffers, the
+//      4-bit bases and the CIGAR words through the staging ring) and stays resident; any number of site lists can then be
+//      run over it (cl_site_run).  cl_site_pileup is the two in one call. ----
+static cl_status cl_site_upload_impl(cl_ctx *c, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *t, const SiteGather *G = nullptr)
+{
+    if (!c || !t) return CL_ERR_INVALID;
+    if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context has no device");
+    HIP_TRY(c, hipSetDevice(c->device));
+    drop_prefetch(c);                                        // the ring is needed below
+    SiteResident &S = c->site;
+    S.resident = false; S.filtered = false;
+    const uint64_t n_all = t->n_reads;
+    if (n_all > 0xFFFFFFF0ull) return fail(c, CL_ERR_RANGE, "too many reads");
+    if (n_all && (!t->pos || !t->mapq || !t->cigar_off || !t->seq_off)) return fail(c, CL_ERR_INVALID, "null tile array");
+    StageTimer tmr;
+    // what travels: the whole tile, or (cl_site_pileup, site_filter above) the reads that overlap a site of its list
+    const bool g = G && G->on;
+    if (!g) {                                                // (site_filter has looked at every offset pair already)
+        std::atomic<int> bad{0};
+        dut::parallel_for(n_all, 262144, [&](size_t i) { if (t->cigar_off[i + 1] < t->cigar_off[i] || t->seq_off[i + 1] < t->seq_off[i]) bad = 1; });
+        if (bad) return fail(c, CL_ERR_INVALID, "offset arrays must be non-decreasing");
+    }
+    const uint64_t n = g ? G->K : n_all;
+    const uint32_t *kidx = g ? G->kidx.get() : nullptr;
+    const unsigned long long *GB = g ? G->B.get() : nullptr;
+    const uint32_t *gco = g ? G->coff.get() : nullptr;
+    const uint64_t ncig = g ? gco[n] : (n_all ? t->cigar_off[n_all] : 0);
+    const uint64_t nbytes = g ? GB[n] : ((n_all ? t->seq_off[n_all] : 0) + 1) / 2;
+    const uint64_t nbase = g ? 2 * GB[n] : (n_all ? t->seq_off[n_all] : 0);
+    const uint64_t *hs_all = t->seq_off;
+    // base offset of (kept) read k in the array that travels; k = n: its end
+    auto seq_at = [=](uint64_t k) -> uint64_t { return !g ? hs_all[k] : (k < n ? 2 * GB[k] + (hs_all[kidx[k]] & 1ull) : nbase); };
+    const uint64_t n_blocks = (n + kBlock - 1) / kBlock;
+    // a workgroup's reads must lie within 2^32 bases of its first one (256 reads: always, short of 16 M-base reads)
+    for (uint64_t b = 0; b < n_blocks; ++b)
+        if (seq_at(std::min<uint64_t>(n, (b + 1) * kBlock)) - seq_at(b * kBlock) > 0xFFFF0000ull)
+            return fail(c, CL_ERR_RANGE, "reads too long for the site pileup");
+    HIP_TRY(c, S.rec.reserve(n + 1)); HIP_TRY(c, S.base.reserve(n_blocks + 1));
+    HIP_TRY(c, S.cig.reserve(ncig + 8)); HIP_TRY(c, S.seq.reserve(nbytes + 16));
+    tmr.lap("site upload: checks + device buffers");
+    cl_status rs = CL_OK;
+    // the bases: the bulk of the tile (0.5 byte per aligned base)
+    if (nbytes && !g && (rs = ring_copy(c, S.seq.p, t->seq4, nbytes)) != CL_OK) return rs;
+    if (nbytes && g) {
+        const uint8_t *seq4 = t->seq4;
+        rs = ring_start(c, S.seq.p, nbytes, [seq4, hs_all, kidx, GB, n](uint64_t off, uint64_t len, uint8_t *out) {
+            // the kept reads whose bytes fall into [off, off + len): whole bytes of the tile's array, read by read
+            uint64_t k = (uint64_t)(std::upper_bound(GB, GB + n + 1, (unsigned long long)off) - GB) - 1;
+            uint64_t at = off;
+            const uint64_t end = off + len;
+            while (at < end && k < n) {
+                const uint64_t src0 = hs_all[kidx[k]] >> 1, take = std::min<uint64_t>(GB[k + 1], end) - at;
+                memcpy(out + (at - off), seq4 + src0 + (at - GB[k]), take);
+                at += take;
+                if (at == GB[k + 1]) ++k;
+            }
+        }, PinRing::kPinBytes, PinRing::kCopyThreads);
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+    }
+    tmr.lap("site upload: bases");
+    // one packed record per read (+ the sentinel with the totals), built in the pinned buffers
+    {
+        const int32_t *hp = t->pos; const uint8_t *hm = t->mapq; const uint32_t *hc = t->cigar_off;
+        const uint64_t ncig_all = ncig;
+        rs = ring_start(c, reinterpret_cast<uint8_t *>(S.rec.p), (n + 1) * sizeof(SiteRec), [=](uint64_t off, uint64_t len, uint8_t *out) {
+            SiteRec *o = reinterpret_cast<SiteRec *>(out);
+            const size_t i0 = off / sizeof(SiteRec), i1 = (off + len) / sizeof(SiteRec);
+            for (size_t k = i0; k < i1; ++k) {
+                SiteRec r;
+                if (k < n) {
+                    const size_t i = g ? kidx[k] : k;
+                    const uint32_t nc = hc[i + 1] - hc[i];
+                    const uint64_t sl = hs_all[i + 1] - hs_all[i];
+                    r.pos = hp[i]; r.cigar_off = g ? gco[k] : hc[i]; r.seq_lo = (uint32_t)seq_at(k);
+                    r.meta = (uint32_t)hm[i] | (std::min<uint32_t>(nc, 255u) << 8) | ((uint32_t)std::min<uint64_t>(sl, 0xFFFFull) << 16);
+                } else { r.pos = 0; r.cigar_off = (uint32_t)ncig_all; r.seq_lo = (uint32_t)nbase; r.meta = 0; }
+                o[k - i0] = r;
+            }
+        }, PinRing::kPinBytes, g ? PinRing::kCopyThreads : 0);
+        // ... beside it, the 64-bit base offset of every workgroup's first read
+        std::vector<unsigned long long> h_base(n_blocks + 1);
+        for (uint64_t b = 0; b < n_blocks; ++b) h_base[b] = seq_at(b * kBlock);
+        h_base[n_blocks] = nbase;
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+        HIP_TRY(c, hipMemcpyAsync(S.base.p, h_base.data(), (n_blocks + 1) * sizeof(unsigned long long), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    if (ncig && !g && (rs = ring_copy(c, S.cig.p, t->cigar, ncig * 4)) != CL_OK) return rs;
+    if (ncig && g) {
+        const uint32_t *cig = t->cigar; const uint32_t *hc = t->cigar_off;
+        rs = ring_start(c, reinterpret_cast<uint8_t *>(S.cig.p), ncig * 4, [cig, hc, kidx, gco, n](uint64_t off, uint64_t len, uint8_t *out) {
+            const uint64_t w0 = off / 4, w1 = (off + len) / 4;                  // (a buffer is a whole number of words)
+            uint64_t k = (uint64_t)(std::upper_bound(gco, gco + n + 1, (uint32_t)w0) - gco) - 1;
+            uint64_t at = w0;
+            uint32_t *o = reinterpret_cast<uint32_t *>(out);
+            while (at < w1 && k < n) {
+                const uint64_t take = std::min<uint64_t>(gco[k + 1], w1) - at;
+                const uint32_t *src = cig + hc[kidx[k]] + (at - gco[k]);
+                uint32_t *dstw = o + (at - w0);
+                for (uint64_t q = 0; q < take; ++q) dstw[q] = src[q];          // (a read has a word or three)
+                at += take;
+                if (at == gco[k + 1]) ++k;
+            }
+        }, PinRing::kPinBytes, PinRing::kCopyThreads);
+        if (rs == CL_OK) rs = ring_finish(c); else (void)ring_finish(c);
+        if (rs != CL_OK) return rs;
+    }
+    tmr.lap("site upload: records + cigar");
+    S.n = n; S.ncig = ncig; S.nbase = nbase; S.contig_len = contig_len; S.ref_len = ref_len;
+    S.resident = true; S.filtered = g;
+    return CL_OK;
+}
+
 static cl_status cl_site_run_impl(cl_ctx *c, uint8_t min_quality, const uint32_t *sites, size_t n_sites, uint32_t *hist, const SitePrep *ready)
 {
     if (!c || (!sites && n_sites) || (!hist && n_sites)) return CL_ERR_INVALID;
     if (c->host_only) return fail(c, CL_ERR_DEVICE, "a host-only context has no device");
     SiteResident &S = c->site;
     if (!S.resident) return fail(c, CL_ERR_INVALID, "cl_site_run without cl_site_upload");
+    // (a tile that cl_site_pileup filtered for its own list serves that call only: ready != nullptr is that call)
+    if (S.filtered && !ready) return fail(c, CL_ERR_INVALID, "cl_site_run: the resident tile was uploaded by cl_site_pileup for its own site list; cl_site_upload gives a tile that serves any list");
     HIP_TRY(c, hipSetDevice(c->device));
     if (n_sites == 0) return CL_OK;
     if (n_sites > 0x0FFFFFFFu) return fail(c, CL_ERR_RANGE, "too many sites");
@@ -2728,14 +2858,18 @@ cl_status cl_site_pileup(cl_ctx *c, uint8_t min_quality, uint32_t contig_len, ui
     if (n_sites == 0) return CL_OK;
     try {
         if (n_sites > 0x0FFFFFFFu) return fail(c, CL_ERR_RANGE, "too many sites");
-        // the site list is sorted on a thread of its own while the tile travels
+        // the sorted site list first (a millisecond): it says which reads need to travel at all
         SitePrep prep;
-        bool prep_ok = false;
-        dut::Thread th = dut::spawn_or_run([&]() { site_prepare(sites, n_sites, prep); prep_ok = true; });
-        cl_status s = cl_site_upload_impl(c, contig_len, ref_len, t);
-        if (th.joinable()) th.join();
+        site_prepare(sites, n_sites, prep);
+        SiteGather G;
+        static const bool no_filter = [] { const char *e = getenv("DUT_SITE_FILTER"); return e && *e == '0'; }();   // =0: the whole tile travels (A/B, tests)
+        if (!no_filter && t->n_reads && t->pos && t->mapq && t->cigar_off && t->seq_off) {
+            StageTimer tf;
+            site_filter(t, prep, min_quality, contig_len, G);
+            tf.lap("site pileup: reads that overlap a site");
+        }
+        cl_status s = cl_site_upload_impl(c, contig_len, ref_len, t, &G);
         if (s != CL_OK) return s;
-        if (!prep_ok) return fail(c, CL_ERR_NOMEM, "out of memory");
         return cl_site_run_impl(c, min_quality, sites, n_sites, hist, &prep);
     }
     catch (const std::bad_alloc &) { return fail(c, CL_ERR_NOMEM, "out of memory"); }

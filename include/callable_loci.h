@@ -264,14 +264,19 @@ typedef struct cl_site_tile {
     const uint8_t  *seq4;       /* BAM 4-bit packed bases, high nibble first                */
 } cl_site_tile;
 /* hist[n_sites*16]: per site (1-based vcf_pos, caller.rs:94) the number of reads with
- * mapq >= min_quality showing each 4-bit base code at an M/=/X position. */
+ * mapq >= min_quality showing each 4-bit base code at an M/=/X position.
+ * Only the reads that can add to the histogram are sent to the device (position inside the contig, mapq >= min_quality,
+ * a site inside the reference span: two short reads in five at one site per ~300 bases); tiles with a read of 255
+ * CIGAR operations or 65 535 bases and more travel whole.  The tile this call leaves on the device therefore serves this
+ * call only: cl_site_run after it is refused (cl_site_upload gives a tile that serves any list). */
 cl_status cl_site_pileup(cl_ctx *ctx, uint8_t min_quality, uint32_t contig_len,
                          uint64_t ref_len, const cl_site_tile *tile,
                          const uint32_t *sites, size_t n_sites, uint32_t *hist);
 
 /* The same in two steps: the tile goes to HBM once (through the pinned staging ring) and stays resident -- until the
  * next cl_site_upload or cl_destroy -- and any number of site lists are run over it (find-y-branch --show-snps asks the
- * same reads about several lists; caller.rs:8-59 fetches the region again each time).  cl_site_pileup = both. */
+ * same reads about several lists; caller.rs:8-59 fetches the region again each time).  cl_site_pileup = both, for one
+ * list (and sends less: above). */
 cl_status cl_site_upload(cl_ctx *ctx, uint32_t contig_len, uint64_t ref_len, const cl_site_tile *tile);
 cl_status cl_site_run(cl_ctx *ctx, uint8_t min_quality, const uint32_t *sites, size_t n_sites, uint32_t *hist);
 

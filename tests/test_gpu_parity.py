@@ -1107,9 +1107,69 @@ def test_site_tile_stays_resident_for_several_site_lists():
         eng.site_upload(L, ref.shape[0], sub)
         exp = oracle.site_pileup(10, 20, L, ref, sub, lists[0])
         assert np.array_equal(eng.site_run(20, lists[0]), exp["hist"])
-        # the one-call form leaves its tile resident too
+        # the one-call form sends only the reads that overlap a site of ITS list: its tile serves that call alone, a run
+        # with another list over it is refused; with DUT_SITE_FILTER=0 the whole tile travels and stays (checked below)
         assert np.array_equal(eng.site_pileup(20, L, ref.shape[0], rec, lists[2]), oracle.site_pileup(10, 20, L, ref, rec, lists[2])["hist"])
+        with pytest.raises(EngineError):
+            eng.site_run(20, lists[0])
+        eng.site_upload(L, ref.shape[0], rec)
         assert np.array_equal(eng.site_run(20, lists[0]), oracle.site_pileup(10, 20, L, ref, rec, lists[0])["hist"])
+
+
+_SITE_FILTER_CASE = r"""
+import os, sys
+sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
+import numpy as np
+import oracle
+from decodingustools_amd import CallableOptions, Engine, synth
+L = 300_000
+ref = synth.make_reference(L, 15)
+rec = synth.short_read_contig(L, 35, synth.seed_for(5, 7), with_seq=True, ref=ref)
+sites = np.random.default_rng(3).choice(np.arange(1, L + 20), size=700, replace=False).astype(np.uint32)
+with Engine(CallableOptions(), 0) as eng:
+    got = eng.site_pileup(20, L, ref.shape[0], rec, sites)
+    assert np.array_equal(got, oracle.site_pileup(10, 20, L, ref, rec, sites)["hist"])
+    other = np.arange(5, 5000, 7, dtype=np.uint32)
+    assert np.array_equal(eng.site_run(20, other), oracle.site_pileup(10, 20, L, ref, rec, other)["hist"])   # the whole tile is there
+print("SITE_FILTER_OFF_OK")
+"""
+
+
+def test_the_site_tile_filtered_for_its_list_and_the_whole_tile_agree(tmp_path):
+    """cl_site_pileup sends only the reads that can add to the histogram (position inside the contig, mapq, a site inside
+    the span).  Lists so sparse that most reads stay behind, so dense that all travel, a list beyond the reads, reads that
+    start the kept set at odd nibbles, zero-length sequences; tiles with a read of 255 operations or 65 535 bases fall
+    back to the whole tile (long reads); DUT_SITE_FILTER=0 (a child process: read once) sends the whole tile always."""
+    import subprocess
+    L = 200_000
+    ref = synth.make_reference(L, 25)
+    rec = synth.short_read_contig(L, 30, synth.seed_for(5, 9), with_seq=True, ref=ref)
+    rng = np.random.default_rng(29)
+    lists = [rng.choice(np.arange(1, L + 1), size=n, replace=False).astype(np.uint32) for n in (3, 40, 600, 20_000)]
+    lists.append(np.arange(1, 3000, dtype=np.uint32))                          # every position of a stretch
+    lists.append(np.array([L + 500, 2**31], np.uint32))                        # no read at all
+    with Engine(CallableOptions(), 0) as eng:
+        for mq in (0, 20, 61):
+            for sites in lists:
+                exp = oracle.site_pileup(10, mq, L, ref, rec, sites)
+                assert np.array_equal(eng.site_pileup(mq, L, ref.shape[0], rec, sites), exp["hist"]), (mq, sites.shape)
+        # reads of 255 operations and more (the records' escape value): the whole tile travels, same histogram
+        reads = []
+        for i in range(300):
+            many = i % 3 == 0
+            cig = "1M1I" * 150 + "40M" if many else "%dM" % int(rng.integers(30, 200))
+            ql = 340 if many else int(cig[:-1])
+            seq = "".join(rng.choice(list("ACGTN"), size=ql))
+            reads.append((int(i * 97 % 50_000), cig, int(rng.choice([0, 20, 60])), [30] * ql, 0, f"m{i}", seq))
+        reads.sort(key=lambda r: r[0])
+        mrec = ContigRecords.from_reads(reads)
+        ref3 = synth.make_reference(60_000, 27)
+        s3 = rng.choice(np.arange(1, 60_000), size=800, replace=False).astype(np.uint32)
+        assert np.array_equal(eng.site_pileup(10, 60_000, ref3.shape[0], mrec, s3), oracle.site_pileup(10, 10, 60_000, ref3, mrec, s3)["hist"])
+    env = dict(os.environ, DUT_SITE_FILTER="0")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", "ROOT = %r\n" % root + _SITE_FILTER_CASE], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "SITE_FILTER_OFF_OK" in r.stdout, r.stderr[-2000:]
 
 
 def test_an_error_behind_a_quality_prefetch_leaves_nothing_in_flight(tmp_path):

@@ -14,10 +14,17 @@ def main():
     ap.add_argument("--length", type=int, default=46_709_983)
     ap.add_argument("--passes", type=int, default=3)
     ap.add_argument("--engines", type=int, default=2)
+    ap.add_argument("--workload", default="chr21", help="chr21 (30x short reads) or long (chrY-shaped 50x long reads)")
     a = ap.parse_args()
     from decodingustools_amd import CallableOptions, CallableProfiler, ContigProfiler, Engine, process_single_contig, synth
-    seed = synth.seed_for(2, 20)
-    rec = synth.short_read_contig(a.length, 30.0, seed)
+    if a.workload == "long":
+        if a.length == 46_709_983:
+            a.length = 57_227_415
+        seed = synth.seed_for(3, 23)
+        rec = synth.long_read_contig(a.length, 50.0, seed)
+    else:
+        seed = synth.seed_for(2, 20)
+        rec = synth.short_read_contig(a.length, 30.0, seed)
     ref = synth.make_reference(a.length, seed)
     opt = CallableOptions()
     d = tempfile.mkdtemp()

@@ -1541,6 +1541,16 @@ static void start_prealloc(cl_ctx *c, uint64_t n_reads, uint64_t n_qual)
 {
     join_prealloc(c);
     const uint32_t contig_len = c->contig_len;
+    {   // nothing to do for a context whose buffers hold this contig already (the usual case from its second contig on):
+        // no thread is made for that
+        const size_t n_win = ((size_t)contig_len + kT - 1) / kT + 1, padded = n_win * kT;
+        const size_t rows_want = n_qual ? ((n_qual / kT) * 17 / 40 + n_win + 1024) * (dut::kRowGroupWords / 4) : 0;
+        const bool enough = c->d_win.cap >= n_win + 1 && c->d_win_off.cap >= n_win + 1 && c->d_winpart.cap >= n_win + 1 &&
+                            c->d_fin.cap >= n_win / kFinBlock + 2 && c->d_runs.cap >= padded + 16 && c->d_first_state.cap >= n_win + 1 &&
+                            c->d_last_state.cap >= n_win + 1 && c->d_win_wide.cap >= n_win + 1 && c->d_refn.cap >= padded / 32 + 4 &&
+                            c->d_heads.cap >= (n_reads ? (size_t)n_reads + 1 : 0) && c->d_rows.cap >= rows_want && c->d_iv.cap != 0;
+        if (enough) return;
+    }
     c->prealloc = dut::spawn_or_run([c, n_reads, n_qual, contig_len]() {
         if (hipSetDevice(c->device) != hipSuccess) return;
         const size_t n_win = ((size_t)contig_len + kT - 1) / kT + 1, padded = n_win * kT;

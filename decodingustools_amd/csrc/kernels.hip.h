@@ -1028,11 +1028,13 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     // workgroups (the kernel's time follows the number of workgroups a CU runs: profiles/r04_occupancy.txt):
     //   first   the counter planes of waves 1.. (wave 0 adds them to its own after the barrier; it is their only reader)
     //   then    s_lt / s_gt and the low-MAPQ thresholds s_lut: a lane of wave 0 writes its words after it has read its
-    //           planes (they lie in the slots of that lane's own planes 0, 1 and 4 of wave 1); s_last, s_wtot, s_wmax:
+    //           planes (they lie in the slots of that lane's own planes 0, 1 and kLutPlane of wave 1); s_last, s_wtot, s_wmax:
     //           written behind the NEXT barrier, when wave 0 is long done with the planes
     // (the waves' totals for the prefix sums across waves travel in the difference arrays: a lane's own, consumed slot)
     constexpr int kPoolWords = (kWaves - 1) * NP * 64;
-    static_assert(NP >= 8 && kPoolWords >= 320 && 128 + kBlock / 4 + kWaves * 24 + kWaves <= 256, "the pool holds its second tenants");
+    constexpr int kTenantsEnd = 128 + kBlock / 4 + kWaves * 24 + kWaves;        // words: s_lt, s_gt, s_last, s_wtot, s_wmax
+    constexpr int kLutPlane = (kTenantsEnd + 63) / 64;                          // the thresholds: the first whole plane behind them
+    static_assert(NP >= 8 && kLutPlane < NP && kPoolWords >= (kLutPlane + 1) * 64, "the pool holds its second tenants");
     __shared__ __attribute__((aligned(16))) uint32_t s_pool[kPoolWords];
     uint32_t (*s_pl)[NP][64] = reinterpret_cast<uint32_t (*)[NP][64]>(s_pool);
     uint32_t *const s_lt = s_pool, *const s_gt = s_pool + 64;                  // per block: qc < min_depth, qc > max_depth
@@ -1040,7 +1042,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
     unsigned long long (*s_wtot)[12] = reinterpret_cast<unsigned long long (*)[12]>(s_pool + 128 + kBlock / 4);
     uint32_t *const s_wmax = s_pool + 128 + kBlock / 4 + kWaves * 24;
     // the low-MAPQ thresholds of depths below 255 as bytes: 255 = never (a count is at most the depth)
-    uint8_t *const s_lut = reinterpret_cast<uint8_t *>(s_pool + 256);
+    uint8_t *const s_lut = reinterpret_cast<uint8_t *>(s_pool + kLutPlane * 64);
     __shared__ uint32_t s_dbg[DEBUG ? NP : 1][64];         // DEBUG: the window's planes, for the dump of qc_depth
 #ifdef CL_ROWS_LDS_PAD
     __shared__ uint32_t s_pad[CL_ROWS_LDS_PAD / 4];        // (occupancy experiments only)
@@ -1194,7 +1196,7 @@ __global__ __launch_bounds__(BS, (DEEP || NP > 8) ? (BS == 128 ? 3 : 4) : (BS ==
                     const uint32_t v = (i >= a.o.min_depth_for_low_mapq && i > 0) ? l4[k] : 0xFFFFFFFFu;
                     wlut |= (v > 254u ? 255u : v) << (8 * k);
                 }
-                s_pool[256 + lane] = wlut;
+                s_pool[kLutPlane * 64 + lane] = wlut;
             }
         }
         uint32_t vr[PER], vl[PER];

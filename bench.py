@@ -138,10 +138,11 @@ def timed_blocks(step, sync, args, world, dist, torch, coll_dev):
     return [float(x) for x in t.cpu().tolist()]
 
 
-def kernel_profile(engines, steps):
+def kernel_profile(engines, steps, one_at_a_time=False):
     """Per-kernel durations: the same steps once more with HIP events between the kernel groups on the
     engines' stream (direct launches; outside the timed region).  Returns ({group: ms per step summed over the
-    engines}, runs per engine)."""
+    engines}, runs per engine).  one_at_a_time: every engine's run is waited for before the next one's is launched --
+    for engines on different streams, whose kernels would otherwise overlap and each look longer than it is."""
     # (a few dozen un-profiled steps first: a secondary measurement starts on a device whose clocks have dropped while the
     # host generated and admitted the contig; the headline's timed region is half a second long, these are not)
     for _ in range(max(0, int(40 / max(1, len(engines))))):
@@ -155,6 +156,8 @@ def kernel_profile(engines, steps):
     for _ in range(n):
         for e in engines:
             e.contig_run()
+            if one_at_a_time:
+                e.sync()
     tot = {}
     for e in engines:
         e.sync()
@@ -880,7 +883,7 @@ def run_wgs(args, rank, world, dev_id, torch, dist, coll_dev):
     """BASELINE.json configs[3]: fixed whole-genome input, LPT-dealt, strong scaling."""
     from decodingustools_amd import CallableOptions, wgs
     opt = CallableOptions()
-    stream = torch.cuda.Stream(device=dev_id)            # every engine of the rank and the collective share it
+    stream = torch.cuda.Stream(device=dev_id)            # the collective's stream; the rank's engines alternate between it and one more (wgs.py)
     t0 = time.perf_counter()
     with torch.cuda.stream(stream):
         shard = wgs.build_shard(rank, world, dev_id, opt, depth=args.depth, scale=args.wgs_scale,
@@ -896,8 +899,10 @@ def run_wgs(args, rank, world, dev_id, torch, dist, coll_dev):
             stream.synchronize()
         dts = timed_blocks(step, sync, args, world, dist, torch, coll_dev)
         table = shard.parse(last["g"])
-        kms, _ = kernel_profile([c.engine for c in shard.mine], args.steps)
+        kms, _ = kernel_profile([c.engine for c in shard.mine], args.steps, one_at_a_time=shard.side_stream is not None)
         stream.synchronize()
+        for st in shard.side_streams:
+            st.synchronize()
         # what every rank did in one step, and how even the deal was
         mine_ms = sum(kms.values())
         lays = [c.engine.contig_layout() for c in shard.mine]

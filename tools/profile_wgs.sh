@@ -4,6 +4,9 @@
 # and WRITE_SIZE, each counter in a pass of its own (never beside a tracing domain other than the kernel trace).
 # WGS_SCALE < 1 shortens the contigs (rehearsal).  The program after `--` is python3 itself (no exec hop).
 cd /tmp && export TMPDIR=/tmp
+# one stream under the profiler: the contigs' kernels then run one after the other and a kernel's traced duration is its own
+# (bench.py measures them one at a time for the same reason; the timed step itself enqueues on four streams)
+export DUT_WGS_SIDE_STREAMS=0
 for pass in "trace --kernel-trace --stats" "fetch --pmc FETCH_SIZE" "write --pmc WRITE_SIZE"; do
   set -- $pass; tag=$1; shift
   out=$GRAFT_REPO_ROOT/gpurun_out/prof_wgs_$tag
